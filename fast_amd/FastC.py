@@ -1,0 +1,782 @@
+"""Host-side solver state for the FastS time step: the mirror of the reference's
+``FastC.PyTree`` services that ``FastS.PyTree.warmup`` relies on.
+
+What is restated here, with the reference location each part follows:
+
+* numerics dictionaries -> ``.Solver#define`` nodes        Fast/FastC/FastC/PyTree.py:107-135
+* ``_buildOwnData``: ``.Solver#define`` + ReferenceState -> ``Parameter_int`` /
+  ``Parameter_real`` / ``.Solver#dtloc``                   Fast/FastC/FastC/PyTree.py:918-2053
+* zone sizes, zone type, metric sizes (what ``fasts.allocate_metric`` writes into
+  ``Parameter_int``)                Fast/FastS/FastS/Metric/allocate_metric.cpp:124-256,398-462
+  and Fast/FastC/FastC/Metric/nature_geom_dom.for:186-503
+* metrics of a Cartesian zone       Fast/FastC/FastC/Metric/cp_tijk.for:291-322, cp_vol.for:148-175
+* BC table appended to ``Parameter_int``   Fast/FastC/FastC/PyTree.py:2789-3017 and
+  Fast/FastC/FastC/getRange.cpp:57-115
+* primitive variables / three time levels / compaction     Fast/FastC/FastC/PyTree.py:214-640,2230-2271
+* time-level pointer rotation                               Fast/FastC/FastC/PyTree.py:2292-2315
+
+The arrays are laid out exactly as the reference lays them out (index constants below are
+those of Fast/FastS/FastS/param_solver.h:77-306) because the device library consumes them
+as-is.
+"""
+import os
+import math
+import numpy
+
+try:  # pragma: no cover - Cassiopee is optional
+    import Converter.Internal as Internal
+    import Converter.PyTree as _C
+
+    def _getState(ref):
+        return _C.getState(ref)
+except Exception:  # stand-alone mode
+    from . import Internal
+    from . import pytree_lite as _C
+
+    def _getState(ref):
+        return _C.getState(ref)
+
+# --- Parameter_int indices (Fast/FastS/FastS/param_solver.h:77-214) -------------------
+NIJK = 0; NIJK_MTR = 5; NIJK_XYZ = 10; NIJK_VENT = 15; IJKV = 20
+NDIMD_SDM = 23; MXSSDOM_LU = 24; ITYPZONE = 25; ITYPVENT = 26; IFLOW = 27; ILES = 28
+ITYPCP = 29; SIZE_SSDOM = 30; KFLUDOM = 33; LALE = 34; IFLAGFLT = 35
+NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NEQ_COE = 39; NEQ_VENT = 40
+NDIMDX = 41; NDIMDX_XYZ = 42; NDIMDX_MTR = 43; NDIMDX_VENT = 44
+IO_THREAD = 45; DTLOC = 46; SA_INT = 47; RK = 52; LEVEL = 53; EXPLOC = 54
+EXPLOCTYPE = 55; LEVELG = 56; LEVELD = 57; NSSITER = 58
+CACHEBLCKI = 59; CACHEBLCKJ = 60; CACHEBLCKK = 61; SFD = 62; SFD_INIT_IT = 63
+SLOPE = 64; NIT_INFLOW = 65; SHIFTVAR = 66; EXTRACT_RES = 67; SA_DEBUG = 68
+PT_OMP = 69; PT_BC = 70; NB_RELAX = 71; NB_RESTART = 72; NB_KRYLOV = 73
+IMPLICITSOLVER = 74; LU_MATCH = 75; IBC = 76; SRC = 83; MESHTYPE = 84
+SENSORTYPE = 85; SCHEDULER = 86; WM_FUNCTION = 87; WM_SAMPLING = 88
+NEQ_LBM = 89; LBM_COL_OP = 92; LBM_SPONGE = 102
+IBC_PT_FLUX = 129; SA_LOW_RE = 130; SA_ROT_CORR = 131; SA_DIST = 132
+PT_INTERP = 133; NONZ = 134; PT_VOL = 135
+BC_TYPE = 0; BC_IDIR = 1; BC_FEN = 2; BC_NBDATA = 8
+# --- Parameter_real indices (param_solver.h:225-306) ----------------------------------
+DTC = 0; GAMMA = 1; CVINF = 2; ROINF = 3; PINF = 4; VINF = 5; TINF = 6; MINF = 7
+RONUTILDEINF = 8; REYNOLDS = 9; PRANDT = 10; XMUL0 = 11; TEMP0 = 12; CS = 13
+EPSI_NEWTON = 14; CFL = 15; SA_REAL = 16; VXINF = 19; VYINF = 20; VZINF = 21
+TEMPS = 22; PSIROE = 34; EPSI_INFLOW = 37; PRANDT_TUR = 38; EPSI_LINEAR = 39
+HPC_CUPS = 40
+
+# Boundary-condition tags (Fast/FastC/FastC/PyTree.py:30-82)
+tagBCDict = {
+    "BCExtrapolate": 0, "BCDegenerateLine": 0, "BCFarfield": 1, "BCInflowSupersonic": 2,
+    "BCWallInviscid": 3, "BCSymmetryPlane": 3, "BCWall": 4, "FamilySpecified": 5,
+    "BCWallViscous": 6, "BCWallViscous_isot_fich": 7, "BC_fich": 8, "Nearmatch": 9,
+    "BCOutflow": 10, "BCautoperiod": 11, "BCWallViscous_transition": 12, "BCInflow": 13,
+    "BCExtrapolateRANS": 14, "BCPeriodic": 15, "BCOutpres": 16, "BCInj1": 17,
+    "BCRacinf": 18, "BCInflowLund": 19, "BCInjMFR": 20, "BCOutMFR": 21, "BCOverlap": 22,
+    "BCWallModel": 30, "BCWallExchange": 31, "BCWallViscousIsothermal": 32,
+}
+
+varsN = ['Density']
+varsP = ['Density_P1']
+varsM = ['Density_M1']
+
+OMP_NUM_THREADS = 1          # the device engine has no host thread team
+MX_SYNCHRO = 1000
+MX_SSZONE = 10
+MX_OMP_SIZE_INT = -1
+OMP_MODE = 0
+FIRST_IT = 0
+HOOK = None
+
+
+def tagBC(bcname):
+    tag = tagBCDict.get(bcname, -1)
+    if tag == -1:
+        print("Warning: Fast: unknown BC type %s." % bcname)
+    return tag
+
+
+# ======================================================================================
+def _setNum2Zones(a, num):
+    """Set numeric data dictionary in zones (Fast/FastC/FastC/PyTree.py:113-121)."""
+    zones = Internal.getNodesFromType2(a, 'Zone_t')
+    for z in zones:
+        cont = Internal.createUniqueChild(z, '.Solver#define', 'UserDefinedData_t')
+        for k in num:
+            Internal.createUniqueChild(cont, k, 'DataArray_t', num[k])
+    return None
+
+
+def setNum2Zones(a, num):
+    ap = Internal.copyRef(a)
+    _setNum2Zones(ap, num)
+    return ap
+
+
+def _setNum2Base(a, num):
+    """Set numeric data dictionary in bases (Fast/FastC/FastC/PyTree.py:130-135).
+    As in the reference, the node is attached to ``a`` itself (the tree root)."""
+    cont = Internal.createUniqueChild(a, '.Solver#define', 'UserDefinedData_t')
+    for k in num:
+        Internal.createUniqueChild(cont, k, 'DataArray_t', num[k])
+    return None
+
+
+def setNum2Base(a, num):
+    ap = Internal.copyRef(a)
+    _setNum2Base(ap, num)
+    return ap
+
+
+def _reorder(t, tc=None):
+    """Order the zones of tc like those of t (Fast/FastC/FastC/PyTree.py:140-210; the
+    OpenMP cost sort of the reference is irrelevant on the device and is not applied)."""
+    if tc is None:
+        return None
+    for b, bc in zip(Internal.getBases(t), Internal.getBases(tc)):
+        names = [z[0] for z in Internal.getZones(b)]
+        zc = {z[0]: z for z in Internal.getZones(bc)}
+        others = [c for c in bc[2] if c[3] != 'Zone_t']
+        bc[2] = others + [zc[n] for n in names if n in zc]
+    return None
+
+
+def _get(d, key, default):
+    if d is None:
+        return default
+    a = Internal.getNodeFromName1(d, key)
+    if a is None:
+        return default
+    return Internal.getValue(a)
+
+
+# ======================================================================================
+def _buildOwnData(t, Padding=None):
+    """Create .Solver#ownData (Parameter_int / Parameter_real) on every zone and
+    .Solver#dtloc on the tree.  Follows Fast/FastC/FastC/PyTree.py:918-2053 for the keys
+    the structured Navier-Stokes time step reads."""
+    global MX_OMP_SIZE_INT
+    zones = Internal.getZones(t)
+    d = Internal.getNodeFromName1(t, '.Solver#define')
+    temporal_scheme = _get(d, 'temporal_scheme', 'implicit')
+    ss_iteration = int(_get(d, 'ss_iteration', 30))
+    rk = int(_get(d, 'rk', 3))
+    modulo_verif = int(_get(d, 'modulo_verif', 200))
+    restart_fields = int(_get(d, 'restart_fields', 1))
+    ompmode = int(_get(d, 'omp_mode', OMP_MODE))
+    exploc = 0
+    maxlevel = 1
+    if temporal_scheme in ('implicit', 'implicit_local'):
+        rk = 3
+    if temporal_scheme == 'explicit':
+        nssiter = {1: 1, 2: 2, 3: 3}.get(rk, 3)
+    elif temporal_scheme in ('implicit', 'implicit_local'):
+        nssiter = ss_iteration + 1
+    else:
+        raise ValueError("fast_amd: temporal_scheme '%s' is not supported "
+                         "(explicit | implicit)." % temporal_scheme)
+
+    timelevel_motion = 0; timelevel_target = 0; timelevel_prfile = 0; it0 = 0
+    first = Internal.getNodeFromName1(t, 'Iteration')
+    if first is not None:
+        it0 = int(Internal.getValue(first))
+    temps = 0.
+    first = Internal.getNodeFromName1(t, 'Time')
+    if first is not None:
+        temps = float(Internal.getValue(first))
+
+    o = Internal.createUniqueChild(t, '.Solver#ownData', 'UserDefinedData_t')
+    if MX_OMP_SIZE_INT == -1:
+        ntask = len(zones) * 2
+        size_task = (6 + 7 * OMP_NUM_THREADS) * ntask
+        MX_OMP_SIZE_INT = 1 + nssiter * (2 + size_task)
+    size_omp = MX_OMP_SIZE_INT
+    dtdim = 12 + 1
+    datap = numpy.zeros(dtdim + size_omp, Internal.E_NpyInt)
+    datap[0] = nssiter
+    datap[1] = modulo_verif
+    datap[2] = restart_fields - 1
+    datap[3] = timelevel_motion
+    datap[4] = timelevel_target
+    datap[5] = timelevel_prfile
+    datap[6] = rk
+    datap[7] = it0
+    datap[8] = ompmode
+    datap[9] = maxlevel
+    datap[10] = 0
+    datap[11] = dtdim
+    datap[12] = 1
+    datap[dtdim:dtdim + nssiter] = -1
+    Internal.createUniqueChild(o, '.Solver#dtloc', 'DataArray_t', datap)
+
+    ndom = 0
+    for b in Internal.getBases(t):
+        for z in Internal.getZones(b):
+            oz = Internal.createUniqueChild(z, '.Solver#ownData', 'UserDefinedData_t')
+            dz = Internal.getNodeFromName1(z, '.Solver#define')
+            model = 'Euler'
+            a = Internal.getNodeFromName2(z, 'GoverningEquations')
+            if a is None:
+                a = Internal.getNodeFromName2(b, 'GoverningEquations')
+            if a is not None:
+                model = Internal.getValue(a)
+            ref = Internal.getNodeFromName1(z, 'ReferenceState')
+            if ref is None:
+                ref = Internal.getNodeFromName1(b, 'ReferenceState')
+            adim = None
+            prandtltb = 1.
+            if ref is not None:
+                adim = _getState(ref)
+                prandtltb = adim[18]
+            else:
+                print('Warning: Fast: can not find a refState.')
+
+            scheme = _get(dz, 'scheme', 'ausmpred')
+            slope = _get(dz, 'slope', 'o3')
+            motion = _get(dz, 'motion', 'none')
+            dtnature = _get(dz, 'time_step_nature', 'global')
+            dtc = float(_get(dz, 'time_step', -0.000001))
+            epsi_newton = float(_get(dz, 'epsi_newton', 0.1))
+            epsi_linear = float(_get(dz, 'epsi_linear', 0.01))
+            cfl = float(_get(dz, 'cfl', 1.))
+            psiroe = float(_get(dz, 'psiroe', 0.1))
+            prandtltb = float(_get(dz, 'prandtltb', prandtltb))
+            ratiom = float(_get(dz, 'ratiom', 10000.))
+            senseurtype = int(_get(dz, 'senseurType', 1))
+            cacheblckI = int(_get(dz, 'cache_blocking_I', 2048))
+            cacheblckJ = int(_get(dz, 'cache_blocking_J', 2))
+            cacheblckK = int(_get(dz, 'cache_blocking_K', 7))
+            shiftvar = int(_get(dz, 'shiftvar', 0))
+            io_th = int(_get(dz, 'io_thread', 0))
+            nbr_relax = int(_get(dz, 'nb_relax', 1))
+            lu_match = int(_get(dz, 'lu_match', 0))
+            extract_res = int(_get(dz, 'extract_res', 0))
+            sgsmodel = _get(dz, 'sgsmodel', 'Miles')
+            implicit_solver = _get(dz, 'implicit_solver', 'lussor')
+            nit_inflow = int(_get(dz, 'inj1_newton_nit', 10))
+            epsi_inflow = float(_get(dz, 'inj1_newton_tol', 1.e-5))
+
+            sa_dist = 0
+            sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+            if sol is not None and Internal.getNodeFromName1(sol, 'TurbulentDistance') is not None:
+                sa_dist = 1
+
+            iflow = 1
+            ides = 0; idist = 1; ispax = 2; izgris = 0; iprod = 0
+            azgris = 0.01; addes = 0.2
+            if model in ('Euler', 'euler'): iflow = 1
+            elif model in ('NSLaminar', 'nslaminar', 'NSLes', 'nsles'): iflow = 2
+            elif model in ('nsspalart', 'NSTurbulent'): iflow = 3
+            else:
+                raise ValueError('fast_amd: model %s is invalid.' % model)
+            iles = 0
+            if sgsmodel != 'Miles':
+                raise ValueError("fast_amd: sgsmodel '%s' is not supported (Miles only)." % sgsmodel)
+            if motion != 'none':
+                raise ValueError("fast_amd: motion '%s' is not supported (none only)." % motion)
+            lale = 0
+            itypcp = 2 if temporal_scheme == 'explicit' else 1
+            size_ssdom = [100, 10, 10]
+            islope = {'o1': 1, 'o2': 4, 'o3': 2, 'o5': 5, 'minmod': 3, 'o3sc': 6, 'o5sc': 7}.get(slope, 2)
+            if scheme == 'ausmpred': kfludom = 1
+            elif scheme == 'senseur': kfludom = 2
+            elif scheme == 'roe_kap': kfludom = 5; islope = 2
+            elif scheme == 'roe_min': kfludom = 5; islope = 3
+            elif scheme == 'roe_nul': kfludom = 5; islope = 1
+            elif scheme == 'roe': kfludom = 5
+            else:
+                raise ValueError('fast_amd: scheme %s is invalid.' % scheme)
+            dtloc = {'global': 0, 'local': 1}[dtnature]
+            ImplicitSolverNum = {'lussor': 0, 'gmres': 1}[implicit_solver]
+
+            pint = numpy.empty(137, Internal.E_NpyInt)
+            pint[:] = -1000
+            pint[0:25] = -1
+            pint[25] = 0; pint[26] = 0
+            pint[27] = iflow; pint[28] = iles; pint[29] = itypcp
+            pint[30:33] = size_ssdom
+            pint[33] = kfludom; pint[34] = lale; pint[35] = 0
+            pint[36:45] = -1
+            pint[45] = io_th; pint[46] = dtloc
+            pint[47] = ides; pint[48] = idist; pint[49] = ispax; pint[50] = izgris; pint[51] = iprod
+            pint[52] = rk; pint[53] = 1; pint[54] = exploc; pint[55] = 0; pint[56] = 1; pint[57] = 0
+            pint[58] = nssiter
+            pint[59] = cacheblckI; pint[60] = cacheblckJ; pint[61] = cacheblckK
+            pint[62] = 0; pint[63] = 1; pint[64] = islope; pint[65] = nit_inflow
+            pint[66] = shiftvar; pint[67] = extract_res; pint[68] = 0
+            pint[69] = 0; pint[70] = 0
+            pint[71] = nbr_relax; pint[72] = 1; pint[73] = 20
+            pint[74] = ImplicitSolverNum; pint[75] = lu_match
+            pint[76:83] = 0
+            pint[83] = 0; pint[84] = 1; pint[85] = senseurtype; pint[86] = -1
+            pint[87] = 0; pint[88] = 4
+            pint[89:129] = 0
+            pint[NEQ_LBM] = 19; pint[LBM_COL_OP] = 1
+            pint[105:109] = 1
+            pint[IBC_PT_FLUX] = -1
+            pint[SA_LOW_RE] = 0; pint[SA_ROT_CORR] = 0; pint[SA_DIST] = sa_dist
+            pint[NONZ] = ndom
+            Internal.createUniqueChild(oz, 'Parameter_int', 'DataArray_t', pint)
+
+            preal = numpy.zeros(72, numpy.float64)
+            if dtc < 0:
+                print('Warning: Fast: time_step set to default value (0.0001).')
+                dtc = 0.0001
+            preal[0] = dtc
+            if adim is not None:
+                preal[1] = adim[11]; preal[2] = adim[7]; preal[3] = adim[0]; preal[4] = adim[5]
+                preal[5] = math.sqrt(adim[1] ** 2 + adim[2] ** 2 + adim[3] ** 2) / adim[0]
+                preal[6] = adim[6]; preal[7] = adim[8]; preal[8] = adim[14]; preal[9] = adim[9]
+                preal[10] = adim[18]; preal[11] = adim[15]; preal[12] = adim[17]; preal[13] = adim[16]
+                preal[19] = adim[1] / adim[0]; preal[20] = adim[2] / adim[0]; preal[21] = adim[3] / adim[0]
+            preal[14] = epsi_newton; preal[15] = cfl
+            preal[16] = azgris; preal[17] = addes; preal[18] = ratiom
+            preal[22] = temps
+            preal[34] = psiroe; preal[35] = 0.; preal[36] = 1.e15
+            preal[37] = epsi_inflow; preal[38] = prandtltb; preal[39] = epsi_linear
+            preal[40] = 1.
+            preal[42] = 1. / math.sqrt(3.); preal[43] = 0.5; preal[51] = 0.985; preal[52] = 1.
+            preal[55] = 0.009; preal[56] = 0.015
+            preal[60] = numpy.sqrt(((0.25 * 0.1) ** 2 + 1)) - 0.25 * 0.1
+            preal[61] = 0.1; preal[62] = 0.1; preal[63] = 0.1
+            preal[65] = 1.
+            preal[66:72] = [0., 1., 1., 1., 0., 0.]
+            Internal.createUniqueChild(oz, 'Parameter_real', 'DataArray_t', preal)
+
+            Internal.createUniqueChild(oz, 'CFL_minmaxmoy', 'DataArray_t',
+                                       numpy.zeros(3, numpy.float64))
+            Internal.createUniqueChild(oz, 'type_zone', 'DataArray_t', 0)
+            Internal.createUniqueChild(oz, 'model', 'DataArray_t', model)
+            Internal.createUniqueChild(oz, 'temporal_scheme', 'DataArray_t', temporal_scheme)
+            Internal.createUniqueChild(oz, 'exp_local', 'DataArray_t', exploc)
+            Internal.createUniqueChild(oz, 'rk', 'DataArray_t', rk)
+            ndom += 1
+    return None
+
+
+def _build_omp(t):
+    """Reserve the (empty, for structured zones) thread-map area at the end of
+    Parameter_int and record its offset (Fast/FastC/FastC/PyTree.py:870-913)."""
+    for z in Internal.getZones(t):
+        o = Internal.getNodeFromName1(z, '.Solver#ownData')
+        p = Internal.getNodeFromName1(o, 'Parameter_int')
+        c = p[1].size
+        datap = numpy.zeros(c, Internal.E_NpyInt)
+        datap[:c] = p[1][:c]
+        datap[PT_OMP] = c
+        datap[SCHEDULER] = c
+        p[1] = datap
+    return None
+
+
+# ======================================================================================
+def nature_geom_dom(x, y, z, ific, ifick):
+    """Zone type detection (0 curvilinear, 1 k-homogeneous, 2 Cartesian constant step,
+    3 two-dimensional), vectorised restatement of
+    Fast/FastC/FastC/Metric/nature_geom_dom.for:186-503 (tolerance 2e-8, :29).
+    x, y, z are node arrays (ni, nj, nk).  Collapsed cells (:52-180) are ignored in the
+    tests, as in the reference.  Returns (typ_zone, nijk_mtr[5], ndimdx_mtr, neq_ij, neq_k)."""
+    eps = 2.e-8
+    ni, nj, nk = x.shape
+    if nk == 2:
+        return 3, [1, ni, 0, ific, ifick], ni * nj, 2, 0
+
+    def seg(a, b):
+        return numpy.sqrt((x[a] - x[b]) ** 2 + (y[a] - y[b]) ** 2 + (z[a] - z[b]) ** 2)
+
+    def sl(di, dj, dk):
+        return (slice(di, ni - 1 + di), slice(dj, nj - 1 + dj), slice(dk, nk - 1 + dk))
+    deg = numpy.zeros((ni - 1, nj - 1, nk - 1), dtype=bool)
+    # a cell is collapsed when its four edges along one direction have zero length
+    dirs = [
+        [((0, 0, 0), (1, 0, 0)), ((0, 1, 0), (1, 1, 0)), ((0, 1, 1), (1, 1, 1)), ((0, 0, 1), (1, 0, 1))],
+        [((0, 0, 0), (0, 1, 0)), ((1, 0, 0), (1, 1, 0)), ((1, 0, 1), (1, 1, 1)), ((0, 0, 1), (0, 1, 1))],
+        [((0, 0, 0), (0, 0, 1)), ((1, 0, 0), (1, 0, 1)), ((1, 1, 0), (1, 1, 1)), ((0, 1, 0), (0, 1, 1))],
+    ]
+    for edges in dirs:
+        allz = numpy.ones_like(deg)
+        for (a, b) in edges:
+            allz &= seg(sl(*a), sl(*b)) <= eps
+        deg |= allz
+    ok = ~deg
+    # index (1,1,1) of the reference = first interior node = [ific, ific, ifick]
+    i1, j1, k1 = ific, ific, ifick
+
+    def plane_const(a, axis, ref_idx):
+        # |a(ref line) - a(i,j,k)| and |... a(i+1,j+1 / k+1 ...)| both on plane and plane+1
+        if axis == 2:
+            r0 = a[i1, j1, :]
+            t1 = numpy.abs(r0[None, None, :-1] - a[:-1, :-1, :-1]); t2 = numpy.abs(r0[None, None, :-1] - a[1:, 1:, :-1])
+            t3 = numpy.abs(r0[None, None, 1:] - a[:-1, :-1, 1:]); t4 = numpy.abs(r0[None, None, 1:] - a[1:, 1:, 1:])
+        elif axis == 1:
+            r0 = a[i1, :, k1]
+            t1 = numpy.abs(r0[None, :-1, None] - a[:-1, :-1, :-1]); t2 = numpy.abs(r0[None, :-1, None] - a[1:, :-1, 1:])
+            t3 = numpy.abs(r0[None, 1:, None] - a[:-1, 1:, :-1]); t4 = numpy.abs(r0[None, 1:, None] - a[1:, 1:, 1:])
+        else:
+            r0 = a[:, j1, k1]
+            t1 = numpy.abs(r0[:-1, None, None] - a[:-1, :-1, :-1]); t2 = numpy.abs(r0[:-1, None, None] - a[:-1, 1:, 1:])
+            t3 = numpy.abs(r0[1:, None, None] - a[1:, :-1, :-1]); t4 = numpy.abs(r0[1:, None, None] - a[1:, 1:, 1:])
+        bad = ((t1 >= eps) | (t2 >= eps) | (t3 >= eps) | (t4 >= eps)) & ok
+        return not bad.any()
+
+    def step_const(a, axis):
+        if axis == 2:
+            cible = a[i1, j1, k1 + 1] - a[i1, j1, k1]; dd = a[:-1, :-1, 1:] - a[:-1, :-1, :-1]
+        elif axis == 1:
+            cible = a[i1, j1 + 1, k1] - a[i1, j1, k1]; dd = a[:-1, 1:, :-1] - a[:-1, :-1, :-1]
+        else:
+            cible = a[i1 + 1, j1, k1] - a[i1, j1, k1]; dd = a[1:, :-1, :-1] - a[:-1, :-1, :-1]
+        bad = (numpy.abs(dd - cible) >= eps) & ok
+        return not bad.any()
+
+    zcart = plane_const(z, 2, 0); zcte = step_const(z, 2)
+    ycart = plane_const(y, 1, 0); ycte = step_const(y, 1)
+    xcart = plane_const(x, 0, 0); xcte = step_const(x, 0)
+    if xcart and xcte and ycart and ycte and zcart and zcte:
+        return 2, [0, 0, 0, 0, 0], 1, 1, 1
+    if zcart and zcte:
+        def kinv(a):
+            r = a[:, :, k1]
+            t1 = numpy.abs(r[:-1, :-1, None] - a[:-1, :-1, :-1]); t2 = numpy.abs(r[1:, 1:, None] - a[1:, 1:, :-1])
+            t3 = numpy.abs(r[:-1, :-1, None] - a[:-1, :-1, 1:]); t4 = numpy.abs(r[1:, 1:, None] - a[1:, 1:, 1:])
+            bad = ((t1 >= eps) | (t2 >= eps) | (t3 >= eps) | (t4 >= eps)) & ok
+            return not bad.any()
+        if kinv(x) and kinv(y):
+            return 1, [1, ni, 0, ific, 0], ni * nj, 2, 1
+    return 0, [1, ni, ni * nj, ific, ifick], ni * nj * nk, 3, 3
+
+
+def cart_metrics(x, y, z, ific, ifick):
+    """ti, tj, tk, vol of a Cartesian zone, evaluated on the first interior cell exactly as
+    Fast/FastC/FastC/Metric/cp_tijk.for:295-321 and cp_vol.for:150-172 do (same operand
+    order, so the result is bit-identical to the reference's)."""
+    def X(a, di, dj, dk):
+        return float(a[ific + di, ific + dj, ifick + dk])
+    def p(a, n):  # node n of the cell, numbered l0..l7 as in the reference
+        d = {0: (0, 0, 0), 1: (0, 1, 0), 2: (0, 0, 1), 3: (0, 1, 1),
+             4: (1, 0, 0), 5: (1, 1, 0), 6: (1, 0, 1), 7: (1, 1, 1)}[n]
+        return X(a, *d)
+    tix10 = (p(y, 1) - p(y, 0)) * (p(z, 3) - p(z, 0)) - (p(z, 1) - p(z, 0)) * (p(y, 3) - p(y, 0))
+    tix11 = (p(y, 2) - p(y, 3)) * (p(z, 0) - p(z, 2)) - (p(z, 2) - p(z, 3)) * (p(y, 0) - p(y, 2))
+    ti = .5 * (tix10 + tix11)
+    tjy10 = (p(z, 0) - p(z, 4)) * (p(x, 2) - p(x, 0)) - (p(x, 0) - p(x, 4)) * (p(z, 2) - p(z, 0))
+    tjy11 = (p(z, 6) - p(z, 2)) * (p(x, 4) - p(x, 6)) - (p(x, 6) - p(x, 2)) * (p(z, 4) - p(z, 6))
+    tj = .5 * (tjy10 + tjy11)
+    tkz10 = (p(x, 4) - p(x, 0)) * (p(y, 5) - p(y, 4)) - (p(y, 4) - p(y, 0)) * (p(x, 5) - p(x, 4))
+    tkz11 = (p(x, 1) - p(x, 5)) * (p(y, 0) - p(y, 1)) - (p(y, 1) - p(y, 5)) * (p(x, 0) - p(x, 1))
+    tk = .5 * (tkz10 + tkz11)
+    ax = .25 * ((p(x, 4) + p(x, 5) + p(x, 7) + p(x, 6)) * ti - (p(x, 0) + p(x, 1) + p(x, 3) + p(x, 2)) * ti)
+    ay = .25 * ((p(y, 1) + p(y, 3) + p(y, 5) + p(y, 7)) * tj - (p(y, 0) + p(y, 2) + p(y, 4) + p(y, 6)) * tj)
+    az = .25 * ((p(z, 2) + p(z, 3) + p(z, 6) + p(z, 7)) * tk - (p(z, 0) + p(z, 1) + p(z, 4) + p(z, 5)) * tk)
+    vol = max((ax + ay + az) / 3., 1.e-30)
+    return ti, tj, tk, vol
+
+
+def allocate_metric_zone(z, nssiter):
+    """Fill the size/type entries of Parameter_int and return the per-zone ``metrics`` list
+    ``[mtr, mtr0, vent, mtr_df, rdm, ind_dm, it_lu_ssdom, degen]``
+    (Fast/FastS/FastS/Metric/allocate_metric.cpp:99-256,398-471).  For zone type 2 the
+    metric array [ti,tj,tk,vol] is computed here too (fastc.init_metric's job in the
+    reference, Fast/FastC/FastC/Metric/init_metric.cpp:264-322)."""
+    o = Internal.getNodeFromName1(z, '.Solver#ownData')
+    if o is None:
+        raise ValueError("metric: numerics is missing for zone %s." % z[0])
+    pint = Internal.getNodeFromName1(o, 'Parameter_int')[1]
+    preal = Internal.getNodeFromName1(o, 'Parameter_real')[1]
+    g = Internal.getNodeFromName1(z, 'GridCoordinates')
+    if g is None:
+        raise ValueError("Coord missing for metric computation")
+    x = Internal.getNodeFromName1(g, 'CoordinateX')[1]
+    y = Internal.getNodeFromName1(g, 'CoordinateY')[1]
+    zz = Internal.getNodeFromName1(g, 'CoordinateZ')[1]
+    ni, nj, nk = x.shape
+    nfic = 2
+    if pint[SLOPE] in (5, 7):
+        raise ValueError("fast_amd: o5 slopes need 3 ghost layers and are not supported.")
+    ific = nfic; ifick = nfic if nk != 2 else 0
+    pint[NIJK_XYZ:NIJK_XYZ + 5] = [ni, nj, nk, ific, ifick]
+    pint[NIJK:NIJK + 5] = [ni - 1, nj - 1, nk - 1, ific, ifick]
+    pint[IJKV] = pint[NIJK] - 2 * ific
+    pint[IJKV + 1] = pint[NIJK + 1] - 2 * ific
+    pint[IJKV + 2] = pint[NIJK + 2] - 2 * ifick
+    pint[NDIMDX] = pint[NIJK] * pint[NIJK + 1] * pint[NIJK + 2] + pint[SHIFTVAR]
+    pint[NDIMDX_XYZ] = ni * nj * nk
+    typ, nijk_mtr, ndimdx_mtr, neq_ij, neq_k = nature_geom_dom(x, y, zz, ific, ifick)
+    pint[NIJK_MTR:NIJK_MTR + 5] = nijk_mtr
+    pint[NDIMDX_MTR] = ndimdx_mtr
+    pint[ITYPZONE] = typ
+    pint[NEQ_IJ] = neq_ij
+    pint[NEQ_K] = neq_k
+    coe_shift = 1 if pint[ITYPCP] == 2 else 0
+    if pint[IFLOW] == 3 and pint[ILES] == 0:
+        pint[NEQ_COE] = 6 - coe_shift * 5
+    else:
+        pint[NEQ_COE] = 5 - coe_shift * 4
+    pint[NEQ] = 6 if pint[IFLOW] == 3 else 5
+    # fixed mesh: ITYPVENT = 2 (or 3 in 2-D), Fast/FastS/FastS/Metric/allocate_metric.cpp:188-252
+    pint[ITYPVENT] = 3 if typ == 3 else 2
+    if pint[ITYPVENT] == 2:
+        pint[NEQ_VENT] = 3; pint[NDIMDX_VENT] = 1; pint[NIJK_VENT:NIJK_VENT + 5] = 0
+    else:
+        pint[NEQ_VENT] = 2; pint[NDIMDX_VENT] = ni * nj
+        pint[NIJK_VENT:NIJK_VENT + 5] = [1, ni, 0, ific, ifick]
+    pint[PT_VOL] = 0
+    tz = Internal.getNodeFromName1(o, 'type_zone')
+    tz[1][0] = typ
+
+    ss = pint[SIZE_SSDOM:SIZE_SSDOM + 3]
+    iv_lu = max(1, pint[IJKV] // ss[0]); jv_lu = max(1, pint[IJKV + 1] // ss[1]); kv_lu = max(1, pint[IJKV + 2] // ss[2])
+    nisdom_lu = int(iv_lu * jv_lu * kv_lu)
+    ndimdx_dm = 6 * nisdom_lu * nssiter + nssiter + nssiter + 1
+    pint[NDIMD_SDM] = ndimdx_dm
+    pint[MXSSDOM_LU] = nisdom_lu
+    neq = int(pint[NEQ])
+    rdm = numpy.zeros(nisdom_lu * neq * 2 * nssiter, numpy.float64)
+    it_lu_ssdom = numpy.zeros(nisdom_lu * 5, Internal.E_NpyInt)
+    ind_dm = numpy.zeros(ndimdx_dm, Internal.E_NpyInt)
+    for nit in range(nssiter):
+        nds = 0
+        for k in range(kv_lu):
+            for j in range(jv_lu):
+                for i in range(iv_lu):
+                    p = nit * nisdom_lu * 6 + nds * 6
+                    ind_dm[p:p + 6] = [1 + ss[0] * i, ss[0] * (i + 1), 1 + ss[1] * j, ss[1] * (j + 1),
+                                       1 + ss[2] * k, ss[2] * (k + 1)]
+                    if i + 1 == iv_lu: ind_dm[p + 1] = pint[IJKV]
+                    if j + 1 == jv_lu: ind_dm[p + 3] = pint[IJKV + 1]
+                    if k + 1 == kv_lu: ind_dm[p + 5] = pint[IJKV + 2]
+                    nds += 1
+    it_lu_ssdom[0:nisdom_lu] = nssiter
+    it_lu_ssdom[nisdom_lu:2 * nisdom_lu] = nssiter
+    it_lu_ssdom[4 * nisdom_lu:5 * nisdom_lu] = numpy.arange(1, nisdom_lu + 1)
+
+    neq_mtr = 2 * neq_ij + neq_k + 1
+    mtr = numpy.zeros(ndimdx_mtr * neq_mtr, numpy.float64)
+    if typ == 2:
+        mtr[0:4] = cart_metrics(x, y, zz, ific, ifick)
+    else:
+        raise ValueError("fast_amd: zone %s is not Cartesian with constant step (zone type %d); "
+                         "only zone type 2 is implemented on the device." % (z[0], typ))
+    degen = numpy.zeros(1, Internal.E_NpyInt)
+    return [mtr, mtr, None, mtr, rdm, ind_dm, it_lu_ssdom, degen]
+
+
+# ======================================================================================
+def getRange(in_bc, pint):
+    """CGNS node window of a BC -> interior-cell window + face index 1..6
+    (Fast/FastC/FastC/getRange.cpp:57-115)."""
+    ific = int(pint[NIJK + 3]); ifick = int(pint[NIJK + 4])
+    iv, jv, kv = int(pint[IJKV]), int(pint[IJKV + 1]), int(pint[IJKV + 2])
+    f = [0] * 6
+    if in_bc[0] == in_bc[1]:
+        f[0] = in_bc[0] - 1 if in_bc[0] > 1 else in_bc[0]
+        f[0] = max(1, f[0] - 2 * ific); f[1] = f[0]
+        f[2] = max(in_bc[2] - ific, 1); f[3] = min(in_bc[3] - ific - 1, jv)
+        f[4] = max(in_bc[4] - ifick, 1); f[5] = min(in_bc[5] - ifick - 1, kv)
+    elif in_bc[2] == in_bc[3]:
+        f[2] = in_bc[2] - 1 if in_bc[2] > 1 else in_bc[2]
+        f[2] = max(1, f[2] - 2 * ific); f[3] = f[2]
+        f[0] = max(in_bc[0] - ific, 1); f[1] = min(in_bc[1] - ific - 1, iv)
+        f[4] = max(in_bc[4] - ifick, 1); f[5] = min(in_bc[5] - ifick - 1, kv)
+    elif in_bc[4] == in_bc[5]:
+        f[4] = in_bc[4] - 1 if in_bc[4] > 1 else in_bc[4]
+        f[4] = max(1, f[4] - 2 * ifick); f[5] = f[4]
+        f[0] = max(in_bc[0] - ific, 1); f[1] = min(in_bc[1] - ific - 1, iv)
+        f[2] = max(in_bc[2] - ific, 1); f[3] = min(in_bc[3] - ific - 1, jv)
+    idir = 0
+    if f[0] == f[1] and f[0] == 1: idir = 1
+    elif f[0] == f[1] and f[0] == iv: idir = 2
+    elif f[2] == f[3] and f[2] == 1: idir = 3
+    elif f[2] == f[3] and f[2] == jv: idir = 4
+    elif f[4] == f[5] and f[4] == 1: idir = 5
+    elif f[4] == f[5] and f[4] == kv: idir = 6
+    return f, idir
+
+
+def _BCcompact(t):
+    """Append the BC table to Parameter_int / Parameter_real
+    (Fast/FastC/FastC/PyTree.py:2789-3017).  Layout from PT_BC = Parameter_int[70]:
+    [nb_bc, ptr_int(nb_bc), ptr_real(nb_bc), {type, idir, imin,imax,jmin,jmax,kmin,kmax,
+    nbdata, cumulated sizes(nbdata)} per BC]."""
+    for z in Internal.getZones(t):
+        o = Internal.getNodeFromName1(z, '.Solver#ownData')
+        bcs = Internal.getNodesFromType2(z, 'BC_t')
+        nb = len(bcs)
+        size_int = 1 + nb * 2 + 9 * nb
+        size_real = 0
+        for bc in bcs:
+            data = _bc_data_arrays(bc)
+            size_int += len(data) * len(data)
+            for d in data:
+                size_real += d[1].size
+        pi = Internal.getNodeFromName1(o, 'Parameter_int')
+        pr = Internal.getNodeFromName1(o, 'Parameter_real')
+        c_int = pi[1].size; c_real = pr[1].size
+        datap = numpy.zeros(size_int + c_int, Internal.E_NpyInt)
+        datap[0:c_int] = pi[1]
+        pi[1] = datap
+        if size_real != 0:
+            datar = numpy.zeros(size_real + c_real, numpy.float64)
+            datar[0:c_real] = pr[1]
+            pr[1] = datar
+        pint = pi[1]; preal = pr[1]
+        pt_bcs = c_int
+        pint[PT_BC] = pt_bcs
+        pint[pt_bcs] = nb
+        i = 1; sz_i = 1 + 2 * nb; sz_r = 0
+        for bc in bcs:
+            pint[pt_bcs + i] = sz_i + pt_bcs
+            pint[pt_bcs + i + nb] = sz_r + c_real
+            pt_bc = int(pint[pt_bcs + i])
+            btype = Internal.getValue(bc)
+            pint[pt_bc] = tagBC(btype)
+            rng = Internal.getNodeFromType1(bc, 'IndexRange_t')[1]
+            in_bc = [int(rng[0][0]), int(rng[0][1]), int(rng[1][0]), int(rng[1][1]),
+                     int(rng[2][0]), int(rng[2][1])]
+            fen, idir = getRange(in_bc, pint)
+            pint[pt_bc + 1] = idir
+            pint[pt_bc + 2:pt_bc + 8] = fen
+            data = _bc_data_arrays(bc)
+            pint[pt_bc + 8] = len(data)
+            ctot = 0; j = 1
+            for d in data:
+                c = d[1].size
+                ctot += c
+                pint[pt_bc + 8 + j] = ctot
+                deb = c_real + sz_r
+                preal[deb:deb + c] = d[1].reshape(-1, order='F')
+                d[1] = preal[deb:deb + c]
+                sz_r += c; j += 1
+            sz_i += 9 + len(data)
+            i += 1
+    return None
+
+
+def _bc_data_arrays(bc):
+    out = []
+    for c in bc[2]:
+        for d in c[2]:
+            for e in d[2]:
+                if e[3] == 'DataArray_t':
+                    out.append(e)
+    return out
+
+
+# ======================================================================================
+_VARS_P = ['Density', 'VelocityX', 'VelocityY', 'VelocityZ', 'Temperature']
+
+
+def zone_vars(z):
+    o = Internal.getNodeFromName1(z, '.Solver#ownData')
+    model = Internal.getValue(Internal.getNodeFromName1(o, 'model'))
+    v = list(_VARS_P)
+    if model in ('nsspalart', 'NSTurbulent'):
+        v.append('TurbulentSANuTilde')
+    return v
+
+
+def _createPrimVars(t):
+    """Primitive variables + the _M1/_P1 time levels, then compaction of each level into one
+    contiguous buffer with stride NDIMDX (Fast/FastC/FastC/PyTree.py:443-520,2230-2271).
+    Returns FIRST_IT (1 when the tree already carried a _M1 level)."""
+    first_it = 1
+    for b in Internal.getBases(t):
+        for z in Internal.getZones(b):
+            sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+            if sol is None:
+                raise ValueError("createPrimVars: FlowSolution#Centers missing in zone %s." % z[0])
+            ref = Internal.getNodeFromName2(z, 'ReferenceState')
+            if ref is None:
+                ref = Internal.getNodeFromName2(b, 'ReferenceState')
+            if ref is None:
+                raise ValueError("createPrimVars: ReferenceState is missing in t.")
+            adim = _getState(ref)
+            gamma = adim[11]; cv = adim[7]
+            ro = Internal.getNodeFromName1(sol, 'Density')[1]
+            names = {'VelocityX': 'MomentumX', 'VelocityY': 'MomentumY', 'VelocityZ': 'MomentumZ'}
+            for v, m in names.items():
+                if Internal.getNodeFromName1(sol, v) is None:
+                    mom = Internal.getNodeFromName1(sol, m)
+                    if mom is None:
+                        raise ValueError("createPrimVars: %s or %s required in zone %s." % (v, m, z[0]))
+                    Internal.createChild(sol, v, 'DataArray_t', numpy.asfortranarray(mom[1] / ro))
+            if Internal.getNodeFromName1(sol, 'Temperature') is None:
+                e = Internal.getNodeFromName1(sol, 'EnergyStagnationDensity')
+                if e is None:
+                    raise ValueError("createPrimVars: Temperature or EnergyStagnationDensity required.")
+                u = Internal.getNodeFromName1(sol, 'VelocityX')[1]
+                v_ = Internal.getNodeFromName1(sol, 'VelocityY')[1]
+                w = Internal.getNodeFromName1(sol, 'VelocityZ')[1]
+                T = (e[1] / ro - 0.5 * (u * u + v_ * v_ + w * w)) / cv
+                Internal.createChild(sol, 'Temperature', 'DataArray_t', numpy.asfortranarray(T))
+            for m in ('MomentumX', 'MomentumY', 'MomentumZ', 'EnergyStagnationDensity',
+                      'TurbulentSANuTildeDensity'):
+                sol[2] = [c for c in sol[2] if c[0] != m]
+            vars_ = zone_vars(z)
+            for v in vars_:
+                if Internal.getNodeFromName1(sol, v) is None:
+                    raise ValueError("createPrimVars: field %s missing in zone %s." % (v, z[0]))
+            pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
+            ndimdx = int(pint[NDIMDX])
+            for suffix in ('', '_M1', '_P1'):
+                buf = numpy.empty(len(vars_) * ndimdx, dtype=numpy.float64)
+                for c, v in enumerate(vars_):
+                    src = Internal.getNodeFromName1(sol, v + suffix)
+                    if src is None:
+                        if suffix == '_M1':
+                            first_it = 0
+                        src = Internal.getNodeFromName1(sol, v)
+                        node = Internal.createChild(sol, v + suffix, 'DataArray_t', None)
+                    else:
+                        node = src
+                    a = src[1]
+                    sh = a.shape
+                    view = buf[c * ndimdx:c * ndimdx + a.size]
+                    view[:] = a.reshape(-1, order='F')
+                    node[1] = view.reshape(sh, order='F')
+    return first_it
+
+
+def switchPointers__(zones, case, order=3):
+    """M1 <- current, current <- P1, P1 <- M1 (case 1) by swapping the numpy references in
+    the tree (Fast/FastC/FastC/PyTree.py:2292-2315)."""
+    if order == 2:
+        return None
+    for z in zones:
+        sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+        for v in zone_vars(z):
+            ca = Internal.getNodeFromName1(sol, v)
+            caM1 = Internal.getNodeFromName1(sol, v + '_M1')
+            caP1 = Internal.getNodeFromName1(sol, v + '_P1')
+            if case == 1:
+                ta = caM1[1]; caM1[1] = ca[1]; ca[1] = caP1[1]; caP1[1] = ta
+            elif case == 2:
+                ta = caP1[1]; caP1[1] = ca[1]; ca[1] = caM1[1]; caM1[1] = ta
+    return None
+
+
+def level_buffer(z, suffix=''):
+    """The contiguous (NEQ*NDIMDX) buffer behind one time level of a compacted zone."""
+    sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+    a = Internal.getNodeFromName1(sol, 'Density' + suffix)[1]
+    base = a
+    while isinstance(base.base, numpy.ndarray):
+        base = base.base
+    return base
+
+
+def fill_task_records(dtloc, zones):
+    """Single-thread task records after .Solver#dtloc[dtdim]: nbtask(nssiter), ptiter(nssiter),
+    then per sub-iteration one record per zone [nd, nd_subzone, thread_map(1), nthreads,
+    topo(3), ind_dm(6)] (record layout: Fast/FastC/FastC/HPC_LAYER/distributeThreads.cpp:520-538,
+    consumed at Fast/FastS/FastS/Compute/rhs.cpp:8-12)."""
+    nssiter = int(dtloc[0]); sh = int(dtloc[11])
+    omp = dtloc[sh:]
+    stride = 6 + 7 * 1
+    need = 2 * nssiter + nssiter * len(zones) * stride
+    if need > omp.size:
+        raise ValueError("resize MX_OMP_SIZE_INT: need %d, have %d" % (need, omp.size))
+    pos = 2 * nssiter
+    for n in range(nssiter):
+        omp[n] = len(zones)
+        omp[nssiter + n] = pos
+        for nd, z in enumerate(zones):
+            pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
+            omp[pos:pos + stride] = [nd, 0, 0, 1, 1, 1, 1, 1, pint[IJKV], 1, pint[IJKV + 1], 1, pint[IJKV + 2]]
+            pos += stride
+    return None

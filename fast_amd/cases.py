@@ -1,0 +1,130 @@
+"""Synthetic FastS cases (deterministic, no RNG) in the pyTree layout of the reference's
+own scripts.
+
+* ``tgv``    : Taylor-Green vortex on [-pi,pi]^3, field formulas of
+               Fast/FastS/test/tgvMpi.py:54-58, NSLaminar, M=0.1, Re=1600, 6 x BCautoperiod
+               (tgvMpi.py:66-74) or split in match-joined blocks.
+* ``vortex`` : inviscid isentropic vortex advected along x on a periodic box
+               (the 64^3 Euler / Roe / RK3 case).
+Zones carry their two ghost layers in the mesh, as in tgvMpi.py:41-50.
+"""
+import math
+import numpy
+from . import Internal
+from . import pytree_lite as C
+from . import FastC
+
+
+def _box(n, length, origin, name):
+    """n interior cells per direction + 2 ghost layers each side."""
+    h = [length[d] / n[d] for d in range(3)]
+    o = [origin[d] - 2 * h[d] for d in range(3)]
+    return C.cart(o, h, (n[0] + 5, n[1] + 5, n[2] + 5), name=name)
+
+
+def _periodic_faces(z, faces=('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')):
+    for f in faces:
+        C.addBC2Zone(z, 'period ' + f, 'BCautoperiod', f)
+
+
+def tgv_fields(t, state, L0=1.):
+    """Density / velocity / temperature of tgvMpi.py:54-58 with P0, T0 taken from the
+    reference state (rho0 = U0 = T0 = 1)."""
+    P0 = state[5]; RO0 = state[0]; T0 = state[6]; U0 = 1.
+    K0 = RO0 * U0 * U0 / 16.
+    O0 = P0 / (RO0 * T0) * T0
+    C._initVars(t, 'centers:Density',
+                lambda x, y, z: (P0 + K0 * (numpy.cos(2. * x / L0) + numpy.cos(2. * y / L0))
+                                 * (numpy.cos(2. * z / L0) + 2.)) / O0)
+    C._initVars(t, 'centers:VelocityX',
+                lambda x, y, z: U0 * numpy.sin(x / L0) * numpy.cos(y / L0) * numpy.cos(z / L0))
+    C._initVars(t, 'centers:VelocityY',
+                lambda x, y, z: -U0 * numpy.cos(x / L0) * numpy.sin(y / L0) * numpy.cos(z / L0))
+    C._initVars(t, 'centers:VelocityZ', 0.)
+    C._initVars(t, 'centers:Temperature', T0)
+
+
+def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
+        temporal_scheme='explicit', modulo_verif=50, extra_numz=None):
+    """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
+    whole box; blocks = (bi,bj,bk) split.  Returns t."""
+    L1 = 2. * math.pi
+    nb = [n // blocks[d] for d in range(3)]
+    zones = []
+    for kb in range(blocks[2]):
+        for jb in range(blocks[1]):
+            for ib in range(blocks[0]):
+                org = [-0.5 * L1 + ib * L1 / blocks[0], -0.5 * L1 + jb * L1 / blocks[1],
+                       -0.5 * L1 + kb * L1 / blocks[2]]
+                ln = [L1 / blocks[0], L1 / blocks[1], L1 / blocks[2]]
+                name = 'cart%d' % (ib + jb * blocks[0] + kb * blocks[0] * blocks[1])
+                z = _box(nb, ln, org, name)
+                faces = []
+                if blocks[0] == 1: faces += ['imin', 'imax']
+                if blocks[1] == 1: faces += ['jmin', 'jmax']
+                if blocks[2] == 1: faces += ['kmin', 'kmax']
+                _periodic_faces(z, faces)
+                zones.append(z)
+    t = C.newPyTree(['Base'] + zones)
+    C.addState(t, 'GoverningEquations', model)
+    C.addState(t, adim='adim2funk', MInf=0.1, ReInf=1600.)
+    state = C.getState(Internal.getNodeFromName(t, 'ReferenceState'))
+    tgv_fields(t, state)
+    if time_step is None:
+        time_step = 0.003 * 32. / n          # tgvMpi.py:271 scaled with the mesh size
+    numb = {'temporal_scheme': temporal_scheme, 'modulo_verif': modulo_verif}
+    numz = {'time_step': time_step, 'scheme': scheme}
+    if extra_numz:
+        numz.update(extra_numz)
+    FastC._setNum2Zones(t, numz)
+    FastC._setNum2Base(t, numb)
+    return t
+
+
+def vortex(n=64, scheme='roe', time_step=None, extra_numz=None):
+    """Isentropic vortex (strength beta=5, core radius 1) in a 10^3 periodic box, free
+    stream along x at M=0.5, Euler, sound-speed scaling (rho_inf = c_inf = T_inf = 1)."""
+    Lb = 10.
+    z = _box((n, n, n), (Lb, Lb, Lb), (0., 0., 0.), 'cart')
+    _periodic_faces(z)
+    t = C.newPyTree(['Base', z])
+    C.addState(t, 'GoverningEquations', 'Euler')
+    C.addState(t, adim='adim1', MInf=0.5, ReInf=1.e8)
+    st = C.getState(Internal.getNodeFromName(t, 'ReferenceState'))
+    gam = st[11]; cv = st[7]; rgp = cv * (gam - 1.)
+    roinf, pinf, Tinf = st[0], st[5], st[6]
+    uinf = st[1] / st[0]
+    beta = 5.; xc = yc = 0.5 * Lb
+
+    def dT(x, y):
+        r2 = (x - xc) ** 2 + (y - yc) ** 2
+        return -(gam - 1.) * beta * beta / (8. * gam * math.pi ** 2) * numpy.exp(1. - r2)
+
+    def T(x, y, z):
+        return Tinf * (1. + dT(x, y) * gam)   # T_inf = 1, c_inf^2 = gamma R T_inf = 1
+
+    def ro(x, y, z):
+        return roinf * (T(x, y, z) / Tinf) ** (1. / (gam - 1.))
+
+    def u(x, y, z):
+        r2 = (x - xc) ** 2 + (y - yc) ** 2
+        return uinf - beta / (2. * math.pi) * numpy.exp(0.5 * (1. - r2)) * (y - yc)
+
+    def v(x, y, z):
+        r2 = (x - xc) ** 2 + (y - yc) ** 2
+        return beta / (2. * math.pi) * numpy.exp(0.5 * (1. - r2)) * (x - xc)
+
+    C._initVars(t, 'centers:Density', ro)
+    C._initVars(t, 'centers:VelocityX', u)
+    C._initVars(t, 'centers:VelocityY', v)
+    C._initVars(t, 'centers:VelocityZ', 0.)
+    C._initVars(t, 'centers:Temperature', T)
+    if time_step is None:
+        time_step = 0.5 * (Lb / n) / (uinf + 1.)     # CFL ~ 0.5 on (u+c)
+    numb = {'temporal_scheme': 'explicit', 'modulo_verif': 50}
+    numz = {'time_step': time_step, 'scheme': scheme}
+    if extra_numz:
+        numz.update(extra_numz)
+    FastC._setNum2Zones(t, numz)
+    FastC._setNum2Base(t, numb)
+    return t

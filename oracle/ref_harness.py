@@ -1,0 +1,269 @@
+"""Driver for the compiled reference Fortran (oracle/_ref/libfast_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by fast_amd/.
+
+The reference's C++/Python glue cannot be built here (it needs Cassiopee), so this file
+restates, for ONE thread and ONE sub-zone per zone, the orchestration that glue performs
+around the Fortran entry points:
+
+  * one sub-iteration = navier_stokes_struct (RHS + RK stage) -> joins -> BCs -> corner fix
+        Fast/FastS/FastS/Compute/gsdr3.cpp:125-146,251-269,343-349,403-422
+        Fast/FastS/FastS/Compute/rhs.cpp:40-58, bcs.cpp:30-41
+  * BC dispatch over the table in Parameter_int        Fast/FastS/FastS/BC/BCzone.cpp:193-226,560-568
+  * time-level rotation after the last sub-iteration   Fast/FastS/FastS/Compute/computePT.cpp:673-677
+  * match-join ghost transfer = indexed copy           Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:440-935
+
+All numerical work is done by the reference's own routines, called through ctypes with
+every argument by reference (INTEGER*4 / REAL*8).
+"""
+import ctypes
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libfast_ref.so")
+
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Open with RTLD_LAZY: the library carries one undefined symbol of the (unused)
+    GMRES path, which an eager bind would trip over."""
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(LIB_PATH, mode=os.RTLD_LAZY)
+    return _lib
+
+
+def _i(v):
+    return ctypes.byref(ctypes.c_int32(int(v)))
+
+
+def _d(v):
+    return ctypes.byref(ctypes.c_double(float(v)))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# Parameter_int / Parameter_real slots used here (Fast/FastS/FastS/param_solver.h)
+NIJK = 0; IJKV = 20; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NEQ_COE = 39; NDIMDX = 41
+NDIMDX_MTR = 43; ITYPCP = 29; KFLUDOM = 33; PT_BC = 70; ITYPZONE = 25; NSSITER = 58
+IFLOW = 27; SLOPE = 64
+DTC = 0; GAMMA = 1; ROINF = 3; PINF = 4; VXINF = 19; VYINF = 20; VZINF = 21; RONUTILDEINF = 8
+
+
+class RefZone:
+    """Host arrays of one zone, laid out as the reference's pyTree + HOOK hold them."""
+
+    def __init__(self, param_int, param_real, x, y, z, ro, mtr):
+        self.pint = np.ascontiguousarray(param_int, dtype=np.int32).copy()
+        self.preal = np.ascontiguousarray(param_real, dtype=np.float64).copy()
+        self.x = np.ascontiguousarray(x.reshape(-1, order='F'), dtype=np.float64)
+        self.y = np.ascontiguousarray(y.reshape(-1, order='F'), dtype=np.float64)
+        self.z = np.ascontiguousarray(z.reshape(-1, order='F'), dtype=np.float64)
+        p = self.pint
+        self.neq = int(p[NEQ]); self.ndimdx = int(p[NDIMDX])
+        n = self.neq * self.ndimdx
+        self.ro = np.ascontiguousarray(ro, dtype=np.float64).reshape(-1).copy()
+        assert self.ro.size == n
+        self.ro_m1 = self.ro.copy()
+        self.ro_p1 = self.ro.copy()
+        nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
+        self.mtr = np.ascontiguousarray(mtr, dtype=np.float64).copy()
+        self.ti = self.mtr[0:nm * nij]
+        self.tj = self.mtr[nm * nij:2 * nm * nij]
+        self.tk = self.mtr[2 * nm * nij:2 * nm * nij + nm * nk]
+        self.vol = self.mtr[2 * nm * nij + nm * nk:]
+        self.drodm = np.zeros(n)
+        self.coe = np.zeros(self.ndimdx * int(p[NEQ_COE]))
+        self.xmut = np.zeros(self.ndimdx * 4)
+        nwig = 3 * self.ndimdx * (2 if p[SLOPE] in (6, 7) and p[KFLUDOM] == 2 else 1)
+        self.wig = np.zeros(nwig)
+        self.cfl = np.zeros(3)
+        self.iv = int(p[IJKV]); self.jv = int(p[IJKV + 1]); self.kv = int(p[IJKV + 2])
+        self.ind_dm = np.array([1, self.iv, 1, self.jv, 1, self.kv], dtype=np.int32)
+
+
+def ref_metrics(param_int, param_real, x, y, z):
+    """ti,tj,tk,vol through the reference's cp_tijk_ / cp_vol_
+    (Fast/FastC/FastC/Metric/init_metric.cpp:264-275) for a Cartesian zone
+    (loop range (1,1,1,1,1,1), Fast/FastC/FastC/Metric/indice_omp1.h:24-28)."""
+    L = lib()
+    p = np.ascontiguousarray(param_int, dtype=np.int32)
+    assert p[ITYPZONE] == 2, "ref_metrics: Cartesian zones only"
+    nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
+    mtr = np.zeros(nm * (2 * nij + nk + 1))
+    ti = mtr[0:nm * nij]; tj = mtr[nm * nij:2 * nm * nij]
+    tk = mtr[2 * nm * nij:2 * nm * nij + nm * nk]; vol = mtr[2 * nm * nij + nm * nk:]
+    xf = np.ascontiguousarray(x.reshape(-1, order='F')); yf = np.ascontiguousarray(y.reshape(-1, order='F'))
+    zf = np.ascontiguousarray(z.reshape(-1, order='F'))
+    ind = np.ones(6, dtype=np.int32)
+    L.cp_tijk_(_p(p), _p(xf), _p(yf), _p(zf), _p(ti), _p(tj), _p(tk), _p(ti), _p(tj), _p(tk), _p(ind))
+    L.cp_vol_(_p(p), _p(xf), _p(yf), _p(zf), _p(ti), _p(tj), _p(tk), _p(ti), _p(tj), _p(tk), _p(vol), _p(ind))
+    return mtr
+
+
+def ref_nature_geom_dom(x, y, z, ific, ifick):
+    """Zone type through the reference's nature_geom_dom_."""
+    L = lib()
+    ni, nj, nk = x.shape
+    nijk_xyz = np.array([ni, nj, nk, ific, ifick], dtype=np.int32)
+    nijk_mtr = np.zeros(5, dtype=np.int32)
+    degen = np.zeros(ni * nj * nk, dtype=np.int32)
+    ndimdx_mtr = ctypes.c_int32(0); neq_ij = ctypes.c_int32(0); neq_k = ctypes.c_int32(0)
+    typ = ctypes.c_int32(0)
+    preal = np.zeros(80)
+    xf = np.ascontiguousarray(x.reshape(-1, order='F')); yf = np.ascontiguousarray(y.reshape(-1, order='F'))
+    zf = np.ascontiguousarray(z.reshape(-1, order='F'))
+    L.nature_geom_dom_(_p(nijk_xyz), _i(ni * nj * nk), _p(xf), _p(yf), _p(zf), _p(degen), _i(0), _p(preal),
+                       _p(nijk_mtr), ctypes.byref(ndimdx_mtr), ctypes.byref(neq_ij), ctypes.byref(neq_k),
+                       ctypes.byref(typ))
+    return typ.value, nijk_mtr.tolist(), ndimdx_mtr.value, neq_ij.value, neq_k.value
+
+
+class RefSolver:
+    """Runs explicit (RK) time steps of a list of RefZone on the reference Fortran."""
+
+    def __init__(self, zones, joins=None):
+        self.zones = zones
+        self.joins = joins or []   # list of (rcv_zone, rcv_idx int32[n], dnr_zone, dnr_idx int32[n])
+        self.first_it = 0
+        self.mx_synchro = 1000
+        self.lok = np.zeros(self.mx_synchro * 4, dtype=np.int32)
+        self.timer = np.zeros(64)
+        self.stage1_rhs = None
+
+    # -- one sub-iteration of one zone: RHS + update -------------------------------------
+    def _navier_stokes(self, nd, zn, nitrun, nstep, ro_ssiter):
+        L = lib()
+        p = zn.pint
+        nssiter = int(p[NSSITER])
+        ijkv_sdm = np.zeros(3, dtype=np.int32)
+        ind_dm_socket = np.zeros(12, dtype=np.int32)
+        topo_socket = np.ones(3, dtype=np.int32)
+        topo_omp = np.ones(3, dtype=np.int32)
+        lmin = 4 if p[ITYPCP] == 2 else 10
+        L.indice_boucle_lu_(_i(nd), _i(1), _i(1), _i(lmin), _p(zn.ind_dm), _p(topo_socket), _p(ind_dm_socket))
+        temps = (nitrun - 1) * zn.preal[DTC]
+        self.lok[:] = 0
+        norm_kry = ctypes.c_double(0.)
+        alias = zn.ro
+        L.navier_stokes_struct_(
+            _i(nd), _i(1), _i(1), _i(1), _i(0), _i(1), _i(1), _i(1), _i(self.mx_synchro),
+            _i(0), _i(0), _i(1), _i(nstep), _i(nssiter), _i(nitrun), _i(self.first_it),
+            _i(0), _i(0),
+            _p(p), _p(zn.preal), _d(temps),
+            _p(ijkv_sdm), _p(zn.ind_dm), _p(ind_dm_socket), _p(zn.ind_dm), _p(topo_socket),
+            _p(self.lok), _p(topo_omp), _p(self.timer),
+            _p(alias), ctypes.byref(norm_kry), _p(zn.cfl),
+            _p(zn.x), _p(zn.y), _p(zn.z), _p(alias), _p(alias),
+            _p(zn.ro), _p(zn.ro_m1), _p(zn.ro_p1), _p(ro_ssiter),
+            _p(zn.xmut),
+            _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.vol),
+            _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.vol),
+            _p(alias), _p(alias), _p(alias),
+            _p(zn.wig), _p(zn.wig), _p(zn.wig),
+            _p(zn.drodm), _p(zn.coe), _p(alias), _p(alias), _p(alias))
+
+    # -- BCs of one zone on array `rop` ------------------------------------------------------
+    def _bczone(self, nd, zn, nstep, rop):
+        L = lib()
+        p = zn.pint
+        pt_bcs = int(p[PT_BC]); nb_bc = int(p[pt_bcs])
+        state = np.zeros(6)
+        r = zn.preal
+        state[0] = r[ROINF]; state[1] = r[VXINF] * r[ROINF]; state[2] = r[VYINF] * r[ROINF]
+        state[3] = r[VZINF] * r[ROINF]
+        state[4] = r[PINF] / (r[GAMMA] - 1.) + 0.5 * (r[VXINF] * state[1] + r[VYINF] * state[2] + r[VZINF] * state[3])
+        state[5] = r[RONUTILDEINF]
+        ind_cl = np.zeros(6, dtype=np.int32); ind_cl119 = np.zeros(6, dtype=np.int32)
+        lskip = ctypes.c_int32(0)
+        for ndf in range(nb_bc):
+            pt_bc = int(p[pt_bcs + 1 + ndf])
+            idir = int(p[pt_bc + 1]); btype = int(p[pt_bc])
+            fen = np.ascontiguousarray(p[pt_bc + 2:pt_bc + 8])
+            if idir <= 2: tijk, neq_mtr = zn.ti, int(p[NEQ_IJ])
+            elif idir <= 4: tijk, neq_mtr = zn.tj, int(p[NEQ_IJ])
+            else: tijk, neq_mtr = zn.tk, int(p[NEQ_K])
+            L.indice_cl_sdm_(_i(idir), _i(0), ctypes.byref(lskip), _i(btype), _i(p[NIJK + 3]), _i(p[NIJK + 4]),
+                             _p(np.ascontiguousarray(p[IJKV:IJKV + 3])), _p(fen), _p(zn.ind_dm), _p(zn.ind_dm),
+                             _p(ind_cl), _p(ind_cl119))
+            if lskip.value != 0:
+                continue
+            if btype == 11:
+                L.bvbs_periodique_(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl119),
+                                   _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+                                   _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
+            elif btype == 0:
+                L.bvbs_extrapolate_(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl119),
+                                    _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+                                    _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
+            elif btype == 22:
+                pass   # BCOverlap: ghost cells come from the join transfer
+            else:
+                raise NotImplementedError("ref_harness: BC tag %d" % btype)
+        L.correct_coins_(_i(nd), _p(p), _p(zn.ind_dm), _p(rop))
+
+    def _transfers(self, arrays):
+        """type-0 ('direct') match joins: rcv[rcvPts] = dnr[donorPts] for every variable."""
+        for (zr, ridx, zd, didx) in self.joins:
+            nr = self.zones[zr].ndimdx; ndd = self.zones[zd].ndimdx
+            for v in range(self.zones[zr].neq):
+                arrays[zr][v * nr + ridx] = arrays[zd][v * ndd + didx]
+
+    def fill_ghostcells(self, which='ro'):
+        arrays = [getattr(z, which) for z in self.zones]
+        self._transfers(arrays)
+        for nd, zn in enumerate(self.zones):
+            self._bczone(nd, zn, 1, arrays[nd])
+
+    def step(self, nitrun):
+        """One time step = nssiter sub-iterations, then M1 <- N <- P1 rotation."""
+        z0 = self.zones[0]
+        nssiter = int(z0.pint[NSSITER])
+        assert z0.pint[ITYPCP] == 2, "RefSolver.step: explicit schemes only"
+        for nstep in range(1, nssiter + 1):
+            cl = []
+            for nd, zn in enumerate(self.zones):
+                if nstep == 1: ssiter, c = zn.ro, zn.ro_p1
+                elif nstep % 2 == 0: ssiter, c = zn.ro_p1, zn.ro
+                else: ssiter, c = zn.ro, zn.ro_p1
+                if nstep == 1:
+                    zn.preal[22] = 0. if nd == 0 else zn.preal[22]   # gsdr3.cpp:155
+                self._navier_stokes(nd, zn, nitrun, nstep, ssiter)
+                if nstep == 1:
+                    zn.stage1_rhs = zn.drodm.copy()
+                cl.append(c)
+            self._transfers(cl)
+            for nd, zn in enumerate(self.zones):
+                self._bczone(nd, zn, nstep, cl[nd])
+        self.first_it = 1
+        for zn in self.zones:
+            zn.ro_m1, zn.ro, zn.ro_p1 = zn.ro, zn.ro_p1, zn.ro_m1
+
+    def residuals(self):
+        """Per zone, per equation: sqrt(sum (coe*drodm)^2 / ncell)/dt and max|coe*drodm|/dt of
+        the first-stage balance, over interior cells (the norm of
+        Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:128-141 applied to the explicit
+        stage-1 increment; the reference only tabulates it for implicit zones)."""
+        out = []
+        for zn in self.zones:
+            p = zn.pint
+            ni, nj, nk = int(p[NIJK]), int(p[NIJK + 1]), int(p[NIJK + 2])
+            f = int(p[NIJK + 3]); fk = int(p[NIJK + 4])
+            d = zn.stage1_rhs.reshape(zn.neq, -1)[:, :ni * nj * nk].reshape(zn.neq, nk, nj, ni)
+            d = d[:, fk:nk - fk, f:nj - f, f:ni - f]
+            c = zn.coe[:zn.ndimdx][:ni * nj * nk].reshape(nk, nj, ni)[fk:nk - fk, f:nj - f, f:ni - f]
+            r = d * c[None]
+            n = r[0].size
+            dt = zn.preal[DTC]
+            out.append((np.sqrt((r * r).reshape(zn.neq, -1).sum(axis=1) / n) / dt,
+                        np.abs(r).reshape(zn.neq, -1).max(axis=1) / dt))
+        return out
