@@ -1,0 +1,206 @@
+"""MI355X counterpart of ``FastS.PyTree``: same entry points, same pyTree in / out.
+
+    (t, tc, metrics) = warmup(t, tc)              Fast/FastS/FastS/PyTree.py:332-536
+    _compute(t, metrics, nitrun, tc)              Fast/FastS/FastS/PyTree.py:42-241
+    _applyBC / _fillGhostcells                    Fast/FastS/FastS/PyTree.py:1146-1218
+    display_temporal_criteria                     Fast/FastS/FastS/PyTree.py:2030-2066
+
+The time step itself runs in libfasts_hip.so (HIP kernels, include/fasts_hip.h); nothing is
+computed in Python and there is no CPU fallback.  Device copies of the fields are kept
+resident; after ``_compute`` the host arrays of the current time level are refreshed unless
+the environment variable FASTS_HIP_LAZY_SYNC=1 is set (then call ``sync_to_host``).
+"""
+import os
+import numpy
+
+from . import FastC
+from . import _capi
+from .FastC import Internal
+
+__all__ = ['warmup', '_compute', '_applyBC', '_fillGhostcells', 'allocate_metric', '_init_metric',
+           'display_temporal_criteria', 'sync_to_host', 'sync_to_device']
+
+
+def _lazy():
+    return os.environ.get('FASTS_HIP_LAZY_SYNC', '0') == '1'
+
+
+def _ctx():
+    if FastC.HOOK is None or FastC.HOOK.get('ctx') is None:
+        raise _capi.FastsHipError("fast_amd: call warmup(t, tc) before computing")
+    return FastC.HOOK['ctx']
+
+
+def allocate_metric(t):
+    """Per-zone metrics lists (Fast/FastS/FastS/PyTree.py:272-295)."""
+    own = Internal.getNodeFromName1(t, '.Solver#ownData')
+    dtloc = Internal.getNodeFromName1(own, '.Solver#dtloc')[1]
+    nssiter = int(dtloc[0])
+    return [FastC.allocate_metric_zone(z, nssiter) for z in Internal.getZones(t)]
+
+
+def _init_metric(t, metrics, hook):
+    """Kept for API compatibility: Cartesian metrics are produced by allocate_metric here
+    (Fast/FastS/FastS/PyTree.py:314-326 calls fastc.init_metric in the reference)."""
+    return None
+
+
+def joins_from_tc(t, tc):
+    """Match joins stored in the connectivity tree, 'inverse' storage: donor zone carries a
+    ZoneSubRegion_t 'ID_<receiver>' with PointList (donor cells) and PointListDonor (receiver
+    cells), 0-based ghost-inclusive linear indices (Fast/FastS/test/tgvMpi.py:132-195).
+    Returns [(rcv_zone_name, donor_zone_name, rcv_pts, donor_pts)]."""
+    out = []
+    if tc is None:
+        return out
+    for zd in Internal.getZones(tc):
+        for sr in Internal.getNodesFromType1(zd, 'ZoneSubRegion_t'):
+            if not sr[0].startswith('ID_'):
+                continue
+            rcv_name = Internal.getValue(sr)
+            pl = Internal.getNodeFromName1(sr, 'PointList')
+            pld = Internal.getNodeFromName1(sr, 'PointListDonor')
+            if pl is None or pld is None:
+                raise ValueError("warmup: join %s of zone %s lacks PointList/PointListDonor" % (sr[0], zd[0]))
+            typ = Internal.getNodeFromName1(sr, 'InterpolantsType')
+            if typ is not None and numpy.any(numpy.asarray(typ[1]) > 1):
+                raise ValueError("warmup: only match ('direct') joins are supported (%s/%s)" % (zd[0], sr[0]))
+            out.append((rcv_name, zd[0], numpy.asarray(pld[1], dtype=numpy.int32).ravel(),
+                        numpy.asarray(pl[1], dtype=numpy.int32).ravel()))
+    return out
+
+
+def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_graph=None, Padding=None,
+           verbose=0, device=0):
+    """Perform necessary operations for the solver to run (same signature as the reference plus
+    the HIP device index)."""
+    if infos_ale is not None or Adjoint or tmy is not None:
+        raise ValueError("fast_amd.warmup: ALE, adjoint and running statistics are not supported")
+    FastC._reorder(t, tc)
+    FastC._buildOwnData(t, Padding)
+    own = Internal.getNodeFromName1(t, '.Solver#ownData')
+    dtloc = Internal.getNodeFromName1(own, '.Solver#dtloc')[1]
+    zones = Internal.getZones(t)
+    FastC._build_omp(t)
+    metrics = allocate_metric(t)
+    FastC._BCcompact(t)
+    FastC.fill_task_records(dtloc, zones)
+    FastC.FIRST_IT = FastC._createPrimVars(t)
+
+    if FastC.HOOK is not None and FastC.HOOK.get('ctx') is not None:
+        FastC.HOOK['ctx'].close()
+    ctx = _capi.Context(device)
+    ctx.set_verif(int(dtloc[1]))
+    names = {}
+    for nd, (z, m) in enumerate(zip(zones, metrics)):
+        o = Internal.getNodeFromName1(z, '.Solver#ownData')
+        pint = Internal.getNodeFromName1(o, 'Parameter_int')[1]
+        preal = Internal.getNodeFromName1(o, 'Parameter_real')[1]
+        ctx.zone_add(pint, preal, FastC.level_buffer(z, ''), FastC.level_buffer(z, '_M1'),
+                     FastC.level_buffer(z, '_P1'), m[0])
+        names[z[0]] = nd
+    for (rn, dn, rpts, dpts) in joins_from_tc(t, tc):
+        if rn not in names or dn not in names:
+            raise ValueError("warmup: join %s <- %s refers to a zone that is not in t" % (rn, dn))
+        ctx.join_add(names[rn], names[dn], rpts, dpts)
+    ctx.upload()
+    FastC.HOOK = {'ctx': ctx, 'dtloc': dtloc, 'FIRST_IT': FastC.FIRST_IT, 'param_int_tc': None,
+                  'param_real_tc': None, 'mpi': 0, 'zone_index': names,
+                  'MX_SSZONE': FastC.MX_SSZONE, 'MX_SYNCHRO': FastC.MX_SYNCHRO,
+                  'MX_OMP_SIZE_INT': FastC.MX_OMP_SIZE_INT, 'lssiter_loc': 0, 'neq_max': 5}
+    # ghost cells of the initial field: joins, BCs, edges (Fast/FastS/FastS/PyTree.py:520-527)
+    ctx.fill_ghostcells(_capi.FS_LEVEL_N)
+    ctx.download(_capi.FS_LEVEL_N)
+    return (t, tc, metrics)
+
+
+def _compute(t, metrics, nitrun, tc=None, graph=None, tc2=None, graph2=None, layer="c", NIT=1,
+             ucData=None, vtune=None):
+    """Compute a given number of iterations."""
+    if tc2 is not None or ucData is not None:
+        raise ValueError("fast_amd._compute: tc2 / ucData are not supported")
+    ctx = _ctx()
+    own = Internal.getNodeFromName1(t, '.Solver#ownData')
+    dtloc = Internal.getNodeFromName1(own, '.Solver#dtloc')[1]
+    nitmax = int(dtloc[0])
+    zones = Internal.getZones(t)
+    if layer == "Python":
+        # one sub-iteration per native call, transfers and BCs driven from here
+        # (Fast/FastS/FastS/PyTree.py:119-209)
+        for nstep in range(1, nitmax + 1):
+            ctx.stage(nitrun, nstep)
+            ctx.local_joins(nstep)
+            ctx.bcs(nstep)
+        if nitmax % 2 == 1:
+            ctx.rotate()
+        nit = 1
+    else:
+        ctx.compute(nitrun, 1, nitmax, NIT)
+        nit = NIT
+    # switch pointers at the end of the time step (Fast/FastS/FastS/PyTree.py:231-233)
+    case = nit % 3
+    if case != 0:
+        FastC.switchPointers__(zones, case, nitmax % 2 + 2)
+    FastC.HOOK["FIRST_IT"] = 1
+    FastC.FIRST_IT = 1
+    if not _lazy():
+        ctx.download(_capi.FS_LEVEL_N)
+    if vtune is None:
+        return None
+    return 0., 0.
+
+
+def sync_to_host(t=None, levels=_capi.FS_LEVEL_N | _capi.FS_LEVEL_M1 | _capi.FS_LEVEL_P1):
+    """Refresh the host arrays of the pyTree from the device."""
+    _ctx().download(levels)
+
+
+def sync_to_device(t=None):
+    """Push the host arrays of the pyTree to the device (after editing fields in Python)."""
+    _ctx().upload()
+
+
+def _level_of(var):
+    if var.endswith('_P1'):
+        return _capi.FS_LEVEL_P1
+    if var.endswith('_M1'):
+        return _capi.FS_LEVEL_M1
+    return _capi.FS_LEVEL_N
+
+
+def _applyBC(t, metrics, hook1=None, nstep=1, var="Density"):
+    """Apply the BCs (+ edge/corner fix) on the time level named by var."""
+    ctx = _ctx()
+    ctx.apply_bc(nstep, _level_of(var))
+    if not _lazy():
+        ctx.download(_level_of(var))
+    return None
+
+
+def _fillGhostcells(zones, tc, metrics, timelevel_target, vars, nstep, omp_mode, hook1, nitmax=1,
+                    rk=1, exploc=0, num_passage=1, gradP=False, TBLE=False, isWireModel=False):
+    """Joins then BCs on the time level named by vars[0]."""
+    ctx = _ctx()
+    ctx.fill_ghostcells(_level_of(vars[0]))
+    if not _lazy():
+        ctx.download(_level_of(vars[0]))
+    return None
+
+
+def display_temporal_criteria(t, metrics, nitrun, format=None, gmres=None, verbose='firstlast',
+                              stopAtNan=True):
+    """Residual norms of the last verification iteration.  Returns {zone: (L2[5], Loo[5])}.
+    The reference prints these only for implicit zones
+    (Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:107); for the explicit scheme the same
+    norm is applied to the first-stage increment."""
+    ctx = _ctx()
+    out = {}
+    for nd, z in enumerate(Internal.getZones(t)):
+        l2, loo = ctx.residuals(nd)
+        out[z[0]] = (l2, loo)
+        if format is None or format in ('single', 'double', 'flush'):
+            print("%-24s nitrun=%d  L2 = %s  Loo = %s" % (
+                z[0], nitrun, ' '.join('%.6e' % v for v in l2), ' '.join('%.6e' % v for v in loo)))
+        if stopAtNan and not numpy.all(numpy.isfinite(l2)):
+            raise FloatingPointError("NaN in the residual of zone %s at iteration %d" % (z[0], nitrun))
+    return out

@@ -1,0 +1,177 @@
+"""ctypes binding of libfasts_hip.so (C ABI: include/fasts_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, FastsHipError is
+raised with the library's message.
+"""
+import ctypes
+import os
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libfasts_hip.so")
+
+FS_LEVEL_N, FS_LEVEL_M1, FS_LEVEL_P1 = 1, 2, 4
+
+SYMBOLS = [
+    "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif",
+    "fs_zone_add", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
+    "fs_stage", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
+    "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_sync",
+    "fs_stage_kernel_ms", "fs_debug_fetch",
+]
+
+
+class FastsHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FastsHipError(
+                "fast_amd: native library %s is missing; build it with "
+                "`make -C fast_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.fs_version.restype = ctypes.c_char_p
+        L.fs_last_error.restype = ctypes.c_char_p
+        L.fs_last_error.argtypes = [ctypes.c_void_p]
+        L.fs_destroy.restype = None
+        L.fs_destroy.argtypes = [ctypes.c_void_p]
+        for name in SYMBOLS:
+            f = getattr(L, name)
+            if name not in ("fs_version", "fs_last_error", "fs_destroy"):
+                f.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _pi(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def _pd(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class Context:
+    """One solver context = one GPU."""
+
+    def __init__(self, device=0):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        rc = L.fs_create(ctypes.byref(self._h), ctypes.c_int(device))
+        if rc != 0:
+            raise FastsHipError("fs_create failed (%d): %s" % (rc, L.fs_last_error(None).decode()))
+        self._keep = []   # host arrays the library borrows
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise FastsHipError("%s failed (%d): %s" % (what, rc, lib().fs_last_error(self._h).decode()))
+        return rc
+
+    def close(self):
+        if self._h:
+            lib().fs_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib().fs_set_stream(self._h, ctypes.c_void_p(stream_ptr)), "fs_set_stream")
+
+    def set_verif(self, modulo_verif):
+        self._chk(lib().fs_set_verif(self._h, ctypes.c_int(int(modulo_verif))), "fs_set_verif")
+
+    def zone_add(self, param_int, param_real, ro, ro_m1, ro_p1, mtr):
+        for a in (ro, ro_m1, ro_p1):
+            if a.dtype != numpy.float64 or not a.flags['C_CONTIGUOUS'] or a.ndim != 1:
+                raise FastsHipError("zone_add: time levels must be flat contiguous float64 buffers")
+        pi = numpy.ascontiguousarray(param_int, dtype=numpy.int32)
+        pr = numpy.ascontiguousarray(param_real, dtype=numpy.float64)
+        mt = numpy.ascontiguousarray(mtr, dtype=numpy.float64)
+        self._keep += [ro, ro_m1, ro_p1]
+        return self._chk(lib().fs_zone_add(self._h, _pi(pi), ctypes.c_int(pi.size), _pd(pr),
+                                           ctypes.c_int(pr.size), _pd(ro), _pd(ro_m1), _pd(ro_p1),
+                                           _pd(mt), ctypes.c_int(mt.size)), "fs_zone_add")
+
+    def join_add(self, rcv_zone, donor_zone, rcv_pts, donor_pts):
+        r = numpy.ascontiguousarray(rcv_pts, dtype=numpy.int32)
+        d = numpy.ascontiguousarray(donor_pts, dtype=numpy.int32) if donor_pts is not None else None
+        self._chk(lib().fs_join_add(self._h, ctypes.c_int(rcv_zone), ctypes.c_int(donor_zone), _pi(r),
+                                    _pi(d) if d is not None else None, ctypes.c_int(r.size)), "fs_join_add")
+
+    def send_add(self, donor_zone, peer_tag, donor_pts):
+        d = numpy.ascontiguousarray(donor_pts, dtype=numpy.int32)
+        self._chk(lib().fs_send_add(self._h, ctypes.c_int(donor_zone), ctypes.c_int(peer_tag), _pi(d),
+                                    ctypes.c_int(d.size)), "fs_send_add")
+
+    def upload(self):
+        self._chk(lib().fs_upload(self._h), "fs_upload")
+
+    def download(self, mask=FS_LEVEL_N):
+        self._chk(lib().fs_download(self._h, ctypes.c_int(mask)), "fs_download")
+
+    def compute(self, nitrun, nstep_deb, nstep_fin, nit_c=1):
+        t = ctypes.c_double(0.)
+        self._chk(lib().fs_compute(self._h, ctypes.c_int(nitrun), ctypes.c_int(nstep_deb),
+                                   ctypes.c_int(nstep_fin), ctypes.c_int(nit_c), ctypes.byref(t)), "fs_compute")
+        return t.value
+
+    def stage(self, nitrun, nstep):
+        self._chk(lib().fs_stage(self._h, ctypes.c_int(nitrun), ctypes.c_int(nstep)), "fs_stage")
+
+    def halo_count(self, peer_tag, is_send):
+        return self._chk(lib().fs_halo_count(self._h, ctypes.c_int(peer_tag), ctypes.c_int(int(is_send))),
+                         "fs_halo_count")
+
+    def halo_pack(self, nstep, peer_tag, dev_ptr, n):
+        self._chk(lib().fs_halo_pack(self._h, ctypes.c_int(nstep), ctypes.c_int(peer_tag),
+                                     ctypes.c_void_p(dev_ptr), ctypes.c_int(n)), "fs_halo_pack")
+
+    def halo_unpack(self, nstep, peer_tag, dev_ptr, n):
+        self._chk(lib().fs_halo_unpack(self._h, ctypes.c_int(nstep), ctypes.c_int(peer_tag),
+                                       ctypes.c_void_p(dev_ptr), ctypes.c_int(n)), "fs_halo_unpack")
+
+    def local_joins(self, nstep):
+        self._chk(lib().fs_local_joins(self._h, ctypes.c_int(nstep)), "fs_local_joins")
+
+    def bcs(self, nstep):
+        self._chk(lib().fs_bcs(self._h, ctypes.c_int(nstep)), "fs_bcs")
+
+    def rotate(self):
+        self._chk(lib().fs_rotate(self._h), "fs_rotate")
+
+    def fill_ghostcells(self, level=FS_LEVEL_N):
+        self._chk(lib().fs_fill_ghostcells(self._h, ctypes.c_int(level)), "fs_fill_ghostcells")
+
+    def apply_bc(self, nstep, level):
+        self._chk(lib().fs_apply_bc(self._h, ctypes.c_int(nstep), ctypes.c_int(level)), "fs_apply_bc")
+
+    def residuals(self, zone=0):
+        l2 = numpy.zeros(5); loo = numpy.zeros(5)
+        self._chk(lib().fs_residuals(self._h, ctypes.c_int(zone), _pd(l2), _pd(loo), ctypes.c_int(5)),
+                  "fs_residuals")
+        return l2, loo
+
+    def sync(self):
+        self._chk(lib().fs_sync(self._h), "fs_sync")
+
+    def stage_kernel_ms(self, reset=False):
+        avg = ctypes.c_double(0.); n = ctypes.c_int(0)
+        self._chk(lib().fs_stage_kernel_ms(self._h, ctypes.c_int(int(reset)), ctypes.byref(avg),
+                                           ctypes.byref(n)), "fs_stage_kernel_ms")
+        return avg.value, n.value
+
+    def debug_fetch(self, zone, which, n):
+        out = numpy.zeros(n)
+        self._chk(lib().fs_debug_fetch(self._h, ctypes.c_int(zone), ctypes.c_int(which), _pd(out),
+                                       ctypes.c_int(n)), "fs_debug_fetch")
+        return out

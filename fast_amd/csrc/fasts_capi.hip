@@ -1,0 +1,637 @@
+// C ABI of libfasts_hip.so: context, zones, the sub-iteration sequence and data movement.
+// Declarations and the reference interfaces they replace: include/fasts_hip.h.
+#include "../../include/fasts_hip.h"
+#include "fasts_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// Parameter_int / Parameter_real slots (Fast/FastS/FastS/param_solver.h:77-306)
+enum { NIJK = 0, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
+       NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
+       SLOPE = 64, PT_BC = 70, SENSORTYPE = 85 };
+enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
+       PSIROE = 34 };
+
+struct Zone {
+  FsZone z;
+  std::vector<int32_t> pint;
+  std::vector<double> preal;
+  double *host[3] = {nullptr, nullptr, nullptr};  // roles: 0 = N, 1 = M1, 2 = P1
+  double *dev[3] = {nullptr, nullptr, nullptr};
+  double *drodm = nullptr, *xmut = nullptr, *wig = nullptr;
+  double *res_part = nullptr, *res_out = nullptr;
+  FsBcWin *bc_dev = nullptr;
+  std::vector<FsBcWin> bc;
+  long long bc_max_cells = 0;
+  bool have_res = false;
+};
+
+struct Join {
+  int rcv_zone, donor_zone, peer_tag, npts;
+  int *rcv_dev = nullptr, *dnr_dev = nullptr;
+};
+
+struct Send {
+  int donor_zone, peer_tag, npts;
+  int *pts_dev = nullptr;
+};
+
+}  // namespace
+
+struct fs_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<Zone> zones;
+  std::vector<Join> joins;
+  std::vector<Send> sends;
+  bool uploaded = false;
+  int modulo_verif = 200;
+  std::string err;
+  // stage-kernel timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+};
+
+static std::string g_create_err;
+
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      return FS_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+static int fail(fs_ctx *ctx, int code, const std::string &msg)
+{
+  ctx->err = msg;
+  return code;
+}
+
+extern "C" const char *fs_version(void) { return "fasts_hip 0.1 gfx950 fp64 contract=off"; }
+
+extern "C" const char *fs_last_error(const fs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int fs_create(fs_ctx **out, int device)
+{
+  if (!out) return FS_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = std::string("fs_create: no HIP device available (") + hipGetErrorString(e) + ")";
+    return FS_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) {
+    g_create_err = "fs_create: device index out of range";
+    return FS_ERR_ARG;
+  }
+  fs_ctx *c = new fs_ctx;
+  c->device = device;
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreate(&c->own_stream);
+  if (e != hipSuccess) {
+    g_create_err = std::string("fs_create: ") + hipGetErrorString(e);
+    delete c;
+    return FS_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return FS_OK;
+}
+
+extern "C" void fs_destroy(fs_ctx *ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &zn : ctx->zones) {
+    for (int r = 0; r < 3; r++) (void)hipFree(zn.dev[r]);
+    (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
+    (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev);
+  }
+  for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
+  for (auto &s : ctx->sends) (void)hipFree(s.pts_dev);
+  for (auto &p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+extern "C" int fs_set_stream(fs_ctx *ctx, void *hip_stream)
+{
+  if (!ctx) return FS_ERR_ARG;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return FS_OK;
+}
+
+extern "C" int fs_set_verif(fs_ctx *ctx, int modulo_verif)
+{
+  if (!ctx || modulo_verif <= 0) return FS_ERR_ARG;
+  ctx->modulo_verif = modulo_verif;
+  return FS_OK;
+}
+
+// Ghost range of a BC window on the whole zone, no corner overflow
+// (Fast/FastC/FastC/BC/indice_cl_sdm.for:46-99 with npass = 0)
+static bool bc_window(const int32_t *p, int idir, const int32_t *fen, FsBcWin &w)
+{
+  const int ific = p[NIJK + 3], ifick = p[NIJK + 4];
+  const int sdm[6] = {1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2]};
+  if (!(sdm[0] <= fen[1] && sdm[1] >= fen[0] && sdm[2] <= fen[3] && sdm[3] >= fen[2] && sdm[4] <= fen[5] &&
+        sdm[5] >= fen[4]))
+    return false;
+  int cl[6];
+  for (int d = 0; d < 3; d++) {
+    cl[2 * d] = fen[2 * d] > sdm[2 * d] ? fen[2 * d] : sdm[2 * d];
+    cl[2 * d + 1] = fen[2 * d + 1] < sdm[2 * d + 1] ? fen[2 * d + 1] : sdm[2 * d + 1];
+  }
+  switch (idir) {
+    case 1: cl[1] = cl[0] - 1; cl[0] = cl[0] - ific; break;
+    case 2: cl[1] = cl[0] + ific; cl[0] = cl[0] + 1; break;
+    case 3: cl[3] = cl[2] - 1; cl[2] = cl[2] - ific; break;
+    case 4: cl[3] = cl[2] + ific; cl[2] = cl[2] + 1; break;
+    case 5: cl[5] = cl[4] - 1; cl[4] = cl[4] - ifick; break;
+    default: cl[5] = cl[4] + ifick; cl[4] = cl[4] + 1; break;
+  }
+  for (int d = 0; d < 3; d++) { w.lo[d] = cl[2 * d]; w.hi[d] = cl[2 * d + 1]; }
+  return true;
+}
+
+extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const double *preal, int n_real,
+                           double *ro, double *ro_m1, double *ro_p1, const double *mtr, int n_mtr)
+{
+  if (!ctx || !pint || !preal || !ro || !ro_m1 || !ro_p1 || !mtr) return ctx ? fail(ctx, FS_ERR_ARG, "fs_zone_add: null argument") : FS_ERR_ARG;
+  if (n_int < 137 || n_real < 41) return fail(ctx, FS_ERR_ARG, "fs_zone_add: Parameter_int/real too short");
+  if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_zone_add: zones must be registered before fs_upload");
+  const int32_t *p = pint;
+  if (p[ITYPZONE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Cartesian zones (zone type 2) are implemented");
+  if (p[ITYPCP] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only the explicit scheme is implemented");
+  if (p[NEQ] != 5 || p[IFLOW] > 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Euler / NSLaminar (5 equations) are implemented");
+  if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
+  if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
+  if (p[LALE] != 0 || p[DTLOC] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local time step are not implemented");
+  if (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK]) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
+  if (p[NIJK + 3] != 2 || p[NIJK + 4] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two ghost layers in every direction are required");
+  if (n_mtr < 4) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short");
+  if ((long long)p[NIJK] * p[NIJK + 1] * p[NIJK + 2] > p[NDIMDX]) return fail(ctx, FS_ERR_ARG, "fs_zone_add: NDIMDX smaller than the zone");
+  if (p[IJKV] < 4 || p[IJKV + 1] < 4 || p[IJKV + 2] < 4) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: at least 4 interior cells per direction");
+
+  Zone zn;
+  zn.pint.assign(pint, pint + n_int);
+  zn.preal.assign(preal, preal + n_real);
+  zn.host[0] = ro; zn.host[1] = ro_m1; zn.host[2] = ro_p1;
+  FsZone &z = zn.z;
+  z.ni = p[NIJK]; z.nj = p[NIJK + 1]; z.nk = p[NIJK + 2]; z.ific = p[NIJK + 3]; z.ifick = p[NIJK + 4];
+  z.iv = p[IJKV]; z.jv = p[IJKV + 1]; z.kv = p[IJKV + 2];
+  z.nd = p[NDIMDX]; z.incj = z.ni; z.inck = (long long)z.ni * z.nj;
+  z.kflu = p[KFLUDOM]; z.iflow = p[IFLOW]; z.neq = p[NEQ]; z.rk = p[RK]; z.nssiter = p[NSSITER];
+  z.sensortype = p[SENSORTYPE];
+  // constants, same expressions as Fast/FastS/FastS/Compute/template_FluxAndBalance.for:108-156
+  const double *r = preal;
+  z.tcx = mtr[0]; z.tcy = mtr[1]; z.tcz = mtr[2];
+  z.si = std::fabs(z.tcx); z.sj = std::fabs(z.tcy); z.sk = std::fabs(z.tcz);
+  z.volinv = 0.5 / mtr[3];
+  z.gam = r[GAMMA];
+  z.rgp = r[CVINF] * (z.gam - 1.);
+  z.gam1 = z.gam / (z.gam - 1.);
+  z.gam3 = z.gam1 / r[PRANDT] * z.rgp;
+  z.psiroe = r[PSIROE];
+  z.c1 = 0.02 * r[VINF];
+  z.c2 = 0.02 / (r[VINF] * r[ROINF]);
+  z.c3 = -2.;
+  z.opt0 = (double)p[SENSORTYPE];
+  double c6 = 1. / 6.;
+  z.c4 = 5. * c6; z.c5 = 2. * c6; z.c6 = -1. * c6;
+  z.cvisq = 1. / 3;
+  z.dt = r[DTC];
+  z.coe = r[DTC] / mtr[3];  // tstb3_global.for:72-78
+  z.cv = r[CVINF]; z.cvinv = 1. / z.cv; z.cvinv2 = 0.5 * z.cvinv;  // core3ark3.for:44-46
+  {  // invist.for:49-51
+    double cmus1 = r[CS], temp01 = 1. / r[TEMP0];
+    z.cmus1 = cmus1;
+    z.coesut = r[XMUL0] * (1. + cmus1 * temp01) * std::sqrt(temp01);
+  }
+  // BC table (Fast/FastC/FastC/PyTree.py:2958-3014)
+  const int pt_bcs = p[PT_BC];
+  if (pt_bcs <= 0 || pt_bcs >= n_int) return fail(ctx, FS_ERR_ARG, "fs_zone_add: PT_BC out of range");
+  const int nb = p[pt_bcs];
+  for (int ndf = 0; ndf < nb; ndf++) {
+    const int pt = p[pt_bcs + 1 + ndf];
+    if (pt + 8 >= n_int) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC table overruns Parameter_int");
+    FsBcWin w;
+    w.type = p[pt]; w.idir = p[pt + 1];
+    if (w.type == 22) continue;  // BCOverlap: filled by the join transfer
+    if (w.type != 11 && w.type != 0) {
+      char msg[128];
+      snprintf(msg, sizeof msg, "fs_zone_add: boundary condition tag %d is not implemented", w.type);
+      return fail(ctx, FS_ERR_UNSUPPORTED, msg);
+    }
+    if (w.idir < 1 || w.idir > 6) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window is not on a zone face");
+    if (!bc_window(p, w.idir, p + pt + 2, w)) continue;
+    switch (w.idir) {  // bvbs_periodique.for: incp = IJKV(dir) * stride, towards the interior
+      case 1: w.shift = z.iv; break;
+      case 2: w.shift = -(long long)z.iv; break;
+      case 3: w.shift = (long long)z.jv * z.incj; break;
+      case 4: w.shift = -(long long)z.jv * z.incj; break;
+      case 5: w.shift = (long long)z.kv * z.inck; break;
+      default: w.shift = -(long long)z.kv * z.inck; break;
+    }
+    long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
+    if (cells > zn.bc_max_cells) zn.bc_max_cells = cells;
+    zn.bc.push_back(w);
+  }
+  ctx->zones.push_back(std::move(zn));
+  return (int)ctx->zones.size() - 1;
+}
+
+static int check_pts(fs_ctx *ctx, int zone, const int32_t *pts, int npts, const char *who)
+{
+  if (zone < 0 || zone >= (int)ctx->zones.size()) return fail(ctx, FS_ERR_ARG, std::string(who) + ": zone index out of range");
+  const FsZone &z = ctx->zones[zone].z;
+  const long long n = (long long)z.ni * z.nj * z.nk;
+  for (int i = 0; i < npts; i++)
+    if (pts[i] < 0 || pts[i] >= n) return fail(ctx, FS_ERR_ARG, std::string(who) + ": cell index outside the zone");
+  return FS_OK;
+}
+
+extern "C" int fs_join_add(fs_ctx *ctx, int rcv_zone, int donor_zone, const int32_t *rcv_pts,
+                           const int32_t *donor_pts, int npts)
+{
+  if (!ctx || !rcv_pts || npts <= 0) return ctx ? fail(ctx, FS_ERR_ARG, "fs_join_add: bad argument") : FS_ERR_ARG;
+  int rc = check_pts(ctx, rcv_zone, rcv_pts, npts, "fs_join_add");
+  if (rc) return rc;
+  Join j;
+  j.rcv_zone = rcv_zone; j.npts = npts;
+  (void)hipSetDevice(ctx->device);
+  HIPCHK(ctx, hipMalloc(&j.rcv_dev, sizeof(int) * npts));
+  HIPCHK(ctx, hipMemcpy(j.rcv_dev, rcv_pts, sizeof(int) * npts, hipMemcpyHostToDevice));
+  if (donor_zone >= 0) {
+    if (!donor_pts) return fail(ctx, FS_ERR_ARG, "fs_join_add: donor list missing");
+    rc = check_pts(ctx, donor_zone, donor_pts, npts, "fs_join_add");
+    if (rc) return rc;
+    if (ctx->zones[donor_zone].z.neq != ctx->zones[rcv_zone].z.neq) return fail(ctx, FS_ERR_ARG, "fs_join_add: zones differ in NEQ");
+    j.donor_zone = donor_zone; j.peer_tag = -1;
+    HIPCHK(ctx, hipMalloc(&j.dnr_dev, sizeof(int) * npts));
+    HIPCHK(ctx, hipMemcpy(j.dnr_dev, donor_pts, sizeof(int) * npts, hipMemcpyHostToDevice));
+  } else {
+    j.donor_zone = -1; j.peer_tag = -donor_zone - 1;
+  }
+  ctx->joins.push_back(j);
+  return FS_OK;
+}
+
+extern "C" int fs_send_add(fs_ctx *ctx, int donor_zone, int peer_tag, const int32_t *donor_pts, int npts)
+{
+  if (!ctx || !donor_pts || npts <= 0 || peer_tag < 0) return ctx ? fail(ctx, FS_ERR_ARG, "fs_send_add: bad argument") : FS_ERR_ARG;
+  int rc = check_pts(ctx, donor_zone, donor_pts, npts, "fs_send_add");
+  if (rc) return rc;
+  Send s;
+  s.donor_zone = donor_zone; s.peer_tag = peer_tag; s.npts = npts;
+  (void)hipSetDevice(ctx->device);
+  HIPCHK(ctx, hipMalloc(&s.pts_dev, sizeof(int) * npts));
+  HIPCHK(ctx, hipMemcpy(s.pts_dev, donor_pts, sizeof(int) * npts, hipMemcpyHostToDevice));
+  ctx->sends.push_back(s);
+  return FS_OK;
+}
+
+extern "C" int fs_upload(fs_ctx *ctx)
+{
+  if (!ctx) return FS_ERR_ARG;
+  if (ctx->zones.empty()) return fail(ctx, FS_ERR_STATE, "fs_upload: no zone registered");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (auto &zn : ctx->zones) {
+    const size_t nb = sizeof(double) * (size_t)zn.z.neq * (size_t)zn.z.nd;
+    if (!ctx->uploaded) {
+      for (int r = 0; r < 3; r++) HIPCHK(ctx, hipMalloc(&zn.dev[r], nb));
+      HIPCHK(ctx, hipMalloc(&zn.drodm, nb));
+      HIPCHK(ctx, hipMemsetAsync(zn.drodm, 0, nb, ctx->stream));
+      HIPCHK(ctx, hipMalloc(&zn.xmut, sizeof(double) * (size_t)zn.z.nd));
+      HIPCHK(ctx, hipMemsetAsync(zn.xmut, 0, sizeof(double) * (size_t)zn.z.nd, ctx->stream));
+      if (zn.z.kflu == 2) {
+        HIPCHK(ctx, hipMalloc(&zn.wig, sizeof(double) * 3 * (size_t)zn.z.nd));
+        HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, sizeof(double) * 3 * (size_t)zn.z.nd, ctx->stream));
+      }
+      HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 10 * (size_t)zn.z.jv * zn.z.kv));
+      HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * 10));
+      if (!zn.bc.empty()) {
+        HIPCHK(ctx, hipMalloc(&zn.bc_dev, sizeof(FsBcWin) * zn.bc.size()));
+        HIPCHK(ctx, hipMemcpy(zn.bc_dev, zn.bc.data(), sizeof(FsBcWin) * zn.bc.size(), hipMemcpyHostToDevice));
+      }
+    }
+    for (int r = 0; r < 3; r++)
+      HIPCHK(ctx, hipMemcpyAsync(zn.dev[r], zn.host[r], nb, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->uploaded = true;
+  return FS_OK;
+}
+
+extern "C" int fs_download(fs_ctx *ctx, int mask)
+{
+  if (!ctx) return FS_ERR_ARG;
+  if (!ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_download: nothing on the device yet");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int bits[3] = {FS_LEVEL_N, FS_LEVEL_M1, FS_LEVEL_P1};
+  for (auto &zn : ctx->zones) {
+    const size_t nb = sizeof(double) * (size_t)zn.z.neq * (size_t)zn.z.nd;
+    for (int r = 0; r < 3; r++)
+      if (mask & bits[r]) HIPCHK(ctx, hipMemcpyAsync(zn.host[r], zn.dev[r], nb, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FS_OK;
+}
+
+static int level_role(int level)
+{
+  return level == FS_LEVEL_N ? 0 : (level == FS_LEVEL_M1 ? 1 : (level == FS_LEVEL_P1 ? 2 : -1));
+}
+
+// stage input / output roles (Fast/FastS/FastS/Compute/gsdr3.cpp:137-145)
+static void stage_roles(int nstep, int &in, int &out)
+{
+  if (nstep % 2 == 1) { in = 0; out = 2; }
+  else { in = 2; out = 0; }
+}
+
+static void rk_coefs(int rk, int nstep, double &coefH, double &coefW)
+{
+  // init_rhs.for:31-32,58-76 ; core3ark3.for:21-24,70-80
+  coefH = 0.; coefW = 1.;
+  if (rk == 3) {
+    coefH = nstep == 2 ? -0.6830127018922193 : (nstep == 3 ? -4. / 3. : 0.);
+    coefW = nstep == 1 ? 0.5 : (nstep == 2 ? 0.9106836025229591 : 0.3660254037844387);
+  } else if (rk == 2) {
+    coefH = nstep == 2 ? -1. : 0.;
+    coefW = nstep == 1 ? 1. : 0.5;
+  }
+}
+
+static int ensure_ready(fs_ctx *ctx, const char *who)
+{
+  if (!ctx) return FS_ERR_ARG;
+  if (!ctx->uploaded) return fail(ctx, FS_ERR_STATE, std::string(who) + ": call fs_upload first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return FS_OK;
+}
+
+extern "C" int fs_stage(fs_ctx *ctx, int nitrun, int nstep)
+{
+  int rc = ensure_ready(ctx, "fs_stage");
+  if (rc) return rc;
+  for (auto &zn : ctx->zones) {
+    const FsZone &z = zn.z;
+    if (nstep < 1 || nstep > z.nssiter) return fail(ctx, FS_ERR_ARG, "fs_stage: sub-iteration out of range");
+    int in, out;
+    stage_roles(nstep, in, out);
+    double coefH, coefW;
+    rk_coefs(z.rk, nstep, coefH, coefW);
+    if (nstep == 1) {
+      if (z.iflow == 2) fsk_invist(z, zn.dev[in], zn.xmut, ctx->stream);
+      if (z.kflu == 2) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+      if (ctx->ev_used == ctx->ev.size()) {
+        hipEvent_t a, b;
+        HIPCHK(ctx, hipEventCreate(&a));
+        HIPCHK(ctx, hipEventCreate(&b));
+        ctx->ev.emplace_back(a, b);
+      }
+      e0 = ctx->ev[ctx->ev_used].first; e1 = ctx->ev[ctx->ev_used].second;
+      ctx->ev_used++;
+      HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    if (fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream))
+      return fail(ctx, FS_ERR_UNSUPPORTED, "fs_stage: no kernel for this scheme / model");
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    if (nstep == 1 && (nitrun % ctx->modulo_verif == 0 || nitrun == 1)) {
+      fsk_residual(z, zn.drodm, zn.res_part, zn.res_out, ctx->stream);
+      zn.have_res = true;
+    }
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+static int local_joins_on(fs_ctx *ctx, int role_of_zone(const void *, int), const void *arg)
+{
+  for (auto &j : ctx->joins) {
+    if (j.donor_zone < 0) continue;
+    Zone &zr = ctx->zones[j.rcv_zone], &zd = ctx->zones[j.donor_zone];
+    int rr = role_of_zone(arg, j.rcv_zone), rd = role_of_zone(arg, j.donor_zone);
+    fsk_join_copy(j.npts, zr.z.neq, zr.z.nd, zd.z.nd, j.rcv_dev, j.dnr_dev, zr.dev[rr], zd.dev[rd], ctx->stream);
+  }
+  return FS_OK;
+}
+
+static int role_from_nstep(const void *arg, int)
+{
+  int in, out;
+  stage_roles(*(const int *)arg, in, out);
+  return out;
+}
+
+static int role_fixed(const void *arg, int) { return *(const int *)arg; }
+
+extern "C" int fs_local_joins(fs_ctx *ctx, int nstep)
+{
+  int rc = ensure_ready(ctx, "fs_local_joins");
+  if (rc) return rc;
+  local_joins_on(ctx, role_from_nstep, &nstep);
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+static void bcs_on_role(fs_ctx *ctx, int role)
+{
+  for (auto &zn : ctx->zones) {
+    fsk_bc_windows(zn.z, (int)zn.bc.size(), zn.bc_dev, zn.bc_max_cells, zn.dev[role], ctx->stream);
+    fsk_bc_edges(zn.z, zn.dev[role], ctx->stream);
+  }
+}
+
+extern "C" int fs_bcs(fs_ctx *ctx, int nstep)
+{
+  int rc = ensure_ready(ctx, "fs_bcs");
+  if (rc) return rc;
+  int in, out;
+  stage_roles(nstep, in, out);
+  bcs_on_role(ctx, out);
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_rotate(fs_ctx *ctx)
+{
+  if (!ctx) return FS_ERR_ARG;
+  for (auto &zn : ctx->zones) {  // computePT.cpp:673-677
+    double *d = zn.dev[1]; zn.dev[1] = zn.dev[0]; zn.dev[0] = zn.dev[2]; zn.dev[2] = d;
+    double *h = zn.host[1]; zn.host[1] = zn.host[0]; zn.host[0] = zn.host[2]; zn.host[2] = h;
+  }
+  return FS_OK;
+}
+
+extern "C" int fs_halo_count(fs_ctx *ctx, int peer_tag, int is_send)
+{
+  if (!ctx) return FS_ERR_ARG;
+  long long n = 0;
+  if (is_send) {
+    for (auto &s : ctx->sends) if (s.peer_tag == peer_tag) n += (long long)s.npts * ctx->zones[s.donor_zone].z.neq;
+  } else {
+    for (auto &j : ctx->joins) if (j.donor_zone < 0 && j.peer_tag == peer_tag) n += (long long)j.npts * ctx->zones[j.rcv_zone].z.neq;
+  }
+  return (int)n;
+}
+
+extern "C" int fs_halo_pack(fs_ctx *ctx, int nstep, int peer_tag, double *dev_buf, int n_doubles)
+{
+  int rc = ensure_ready(ctx, "fs_halo_pack");
+  if (rc) return rc;
+  if (n_doubles != fs_halo_count(ctx, peer_tag, 1)) return fail(ctx, FS_ERR_ARG, "fs_halo_pack: buffer size mismatch");
+  int in, out;
+  if (nstep <= 0) out = level_role(-nstep); else stage_roles(nstep, in, out);
+  if (out < 0) return fail(ctx, FS_ERR_ARG, "fs_halo_pack: bad level");
+  long long off = 0;
+  for (auto &s : ctx->sends) {
+    if (s.peer_tag != peer_tag) continue;
+    Zone &zd = ctx->zones[s.donor_zone];
+    fsk_halo_pack(s.npts, zd.z.neq, zd.z.nd, s.pts_dev, zd.dev[out], dev_buf + off, ctx->stream);
+    off += (long long)s.npts * zd.z.neq;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_halo_unpack(fs_ctx *ctx, int nstep, int peer_tag, const double *dev_buf, int n_doubles)
+{
+  int rc = ensure_ready(ctx, "fs_halo_unpack");
+  if (rc) return rc;
+  if (n_doubles != fs_halo_count(ctx, peer_tag, 0)) return fail(ctx, FS_ERR_ARG, "fs_halo_unpack: buffer size mismatch");
+  int in, out;
+  if (nstep <= 0) out = level_role(-nstep); else stage_roles(nstep, in, out);
+  if (out < 0) return fail(ctx, FS_ERR_ARG, "fs_halo_unpack: bad level");
+  long long off = 0;
+  for (auto &j : ctx->joins) {
+    if (j.donor_zone >= 0 || j.peer_tag != peer_tag) continue;
+    Zone &zr = ctx->zones[j.rcv_zone];
+    fsk_halo_unpack(j.npts, zr.z.neq, zr.z.nd, j.rcv_dev, zr.dev[out], dev_buf + off, ctx->stream);
+    off += (long long)j.npts * zr.z.neq;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_compute(fs_ctx *ctx, int nitrun, int nstep_deb, int nstep_fin, int nit_c, double *t_trans)
+{
+  int rc = ensure_ready(ctx, "fs_compute");
+  if (rc) return rc;
+  if (t_trans) *t_trans = 0.;
+  const int nssiter = ctx->zones[0].z.nssiter;
+  if (nstep_deb < 1 || nstep_fin > nssiter || nstep_deb > nstep_fin || nit_c < 1)
+    return fail(ctx, FS_ERR_ARG, "fs_compute: bad sub-iteration range");
+  for (auto &j : ctx->joins)
+    if (j.donor_zone < 0) return fail(ctx, FS_ERR_STATE, "fs_compute: joins to other contexts need the split calls (fs_stage / fs_halo_* / fs_bcs)");
+  for (int it = 0; it < nit_c; it++) {
+    const int nitrun_loc = nitrun * nit_c + it;  // computePT.cpp:543
+    for (int nstep = nstep_deb; nstep <= nstep_fin; nstep++) {
+      rc = fs_stage(ctx, nitrun_loc, nstep);
+      if (rc) return rc;
+      local_joins_on(ctx, role_from_nstep, &nstep);
+      int in, out;
+      stage_roles(nstep, in, out);
+      bcs_on_role(ctx, out);
+    }
+    // the result of the last sub-iteration sits in P1 only when their number is odd
+    // (Fast/FastS/FastS/PyTree.py:233: switchPointers__(zones, case, nitmax%2+2))
+    if (nstep_fin == nssiter && nssiter % 2 == 1) fs_rotate(ctx);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_fill_ghostcells(fs_ctx *ctx, int level)
+{
+  int rc = ensure_ready(ctx, "fs_fill_ghostcells");
+  if (rc) return rc;
+  int role = level_role(level);
+  if (role < 0) return fail(ctx, FS_ERR_ARG, "fs_fill_ghostcells: bad level");
+  local_joins_on(ctx, role_fixed, &role);
+  bcs_on_role(ctx, role);
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_apply_bc(fs_ctx *ctx, int nstep, int level)
+{
+  (void)nstep;
+  int rc = ensure_ready(ctx, "fs_apply_bc");
+  if (rc) return rc;
+  int role = level_role(level);
+  if (role < 0) return fail(ctx, FS_ERR_ARG, "fs_apply_bc: bad level");
+  bcs_on_role(ctx, role);
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_residuals(fs_ctx *ctx, int zone, double *l2, double *loo, int neq)
+{
+  int rc = ensure_ready(ctx, "fs_residuals");
+  if (rc) return rc;
+  if (zone < 0 || zone >= (int)ctx->zones.size() || !l2 || !loo || neq < 5) return fail(ctx, FS_ERR_ARG, "fs_residuals: bad argument");
+  Zone &zn = ctx->zones[zone];
+  if (!zn.have_res) return fail(ctx, FS_ERR_STATE, "fs_residuals: no verification sub-iteration has run yet");
+  double out[10];
+  HIPCHK(ctx, hipMemcpyAsync(out, zn.res_out, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const double n = (double)zn.z.iv * zn.z.jv * zn.z.kv;
+  for (int e = 0; e < 5; e++) { l2[e] = std::sqrt(out[e] / n) / zn.z.dt; loo[e] = out[5 + e] / zn.z.dt; }
+  return FS_OK;
+}
+
+extern "C" int fs_sync(fs_ctx *ctx)
+{
+  if (!ctx) return FS_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FS_OK;
+}
+
+extern "C" int fs_stage_kernel_ms(fs_ctx *ctx, int reset, double *avg_ms, int *n_launch)
+{
+  if (!ctx) return FS_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.;
+  for (size_t i = 0; i < ctx->ev_used; i++) {
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[i].first, ctx->ev[i].second));
+    tot += ms;
+  }
+  if (avg_ms) *avg_ms = ctx->ev_used ? tot / (double)ctx->ev_used : 0.;
+  if (n_launch) *n_launch = (int)ctx->ev_used;
+  if (reset) { ctx->ev_used = 0; ctx->timing = true; }
+  return FS_OK;
+}
+
+extern "C" int fs_debug_fetch(fs_ctx *ctx, int zone, int which, double *host, int n_doubles)
+{
+  int rc = ensure_ready(ctx, "fs_debug_fetch");
+  if (rc) return rc;
+  if (zone < 0 || zone >= (int)ctx->zones.size() || !host) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: bad argument");
+  Zone &zn = ctx->zones[zone];
+  const double *src = which == 0 ? zn.drodm : (which == 1 ? zn.wig : zn.xmut);
+  long long n = which == 0 ? (long long)zn.z.neq * zn.z.nd : (which == 1 ? 3 * zn.z.nd : zn.z.nd);
+  if (!src) return fail(ctx, FS_ERR_STATE, "fs_debug_fetch: array not allocated for this scheme");
+  if (n_doubles != n) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: size mismatch");
+  HIPCHK(ctx, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FS_OK;
+}

@@ -1,0 +1,272 @@
+// Device-side numerics of the FastS face flux for Cartesian zones (zone type 2), gfx950.
+//
+// Every expression keeps the operand order of the reference fragment it implements and the
+// translation unit is built with -ffp-contract=off, so a face flux is bit-identical to the
+// one the reference computes: the oscillation sensor of the `senseur` scheme is a 0/1 switch
+// driven by signs of differences, and any rounding-level deviation in the state can flip it.
+//
+// Reference fragments (paths under Fast/FastS/FastS/Compute/):
+//   MUSCL o3 states        Slope/o3_slope_var.for:2-3
+//   left/right states      etat_GD.for, etat_roe_GD.for
+//   ausmpred               AUSM/3dcart/fluFaceEuler_o3_3dcart_{i,j,k}.for, Vit_ent/fluvector_3dcart_*.for
+//   senseur                SENSOR/3dcart/fluFaceEuler_o3_3dcart_{i,j,k}.for
+//   roe + Harten fix       ROE/3dcart/fluFaceEuler_o3_3dcart_*.for, Vit_ent/fludiffer_3dcart_*.for
+//   viscous flux           fluvisq_3dcart_{i,j,k}.for, mut_interface.for
+//   sensor                 SENSOR/wiggle.for, SENSOR/wiggle_{i,j,k}.for
+//   constants              template_FluxAndBalance.for:108-156
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct FsZone {
+  // geometry (cells, ghost layers included)
+  int ni, nj, nk, ific, ifick, iv, jv, kv;
+  long long nd;            // NDIMDX: stride between two variables of one time level
+  long long incj, inck;    // ni, ni*nj
+  int kflu, iflow, neq, rk, nssiter, sensortype;
+  // fluid / scheme constants
+  double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
+  double tcx, tcy, tcz, si, sj, sk, volinv;
+  double coe;              // dt/vol (constant on a Cartesian zone with a global time step)
+  double dt, cv, cvinv, cvinv2, coesut, cmus1;
+};
+
+#define FS_DEV static __device__ __forceinline__
+
+FS_DEV double fs_max(double a, double b) { return a > b ? a : b; }
+FS_DEV double fs_min(double a, double b) { return a < b ? a : b; }
+FS_DEV double fs_sign(double a, double b) { return copysign(fabs(a), b); }
+
+// Sutherland law (invist.for:49-61)
+FS_DEV double fs_sutherland(const FsZone &z, double t1) { return z.coesut * sqrt(t1) * t1 / (t1 + z.cmus1); }
+
+// sensor of one face: Q(e, offset) returns variable e at cell l + offset*inc
+template <class Q> FS_DEV double fs_wiggle(const Q &q)
+{
+  double test = 0.;
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    double a2 = q(e, -2), a1 = q(e, -1), a0 = q(e, 0), ap = q(e, 1);
+    double qm = (a1 - a2) * (a0 - a1);
+    double qp = (a0 - a1) * (ap - a0);
+    double f = fs_sign(1., qm) + fs_sign(1., qp);
+    test = e == 0 ? f : fs_min(test, f);
+  }
+  return test < -1e-12 ? 1. : 0.;
+}
+
+// Inviscid flux through the face between cell l-inc and cell l in direction DIR.
+// qm2..qp1[e] = variable e at l-2inc, l-inc, l, l+inc; wg = sensor of the face (senseur only).
+template <int KFLU, int DIR>
+FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *qm1_, const double *q0,
+                             const double *qp1_, double wg, double *flu)
+{
+  const double tc = DIR == 0 ? z.tcx : (DIR == 1 ? z.tcy : z.tcz);
+  const double s = DIR == 0 ? z.si : (DIR == 1 ? z.sj : z.sk);
+  double qm[5], qp[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    qm[e] = z.c4 * q0[e] + z.c5 * qm1_[e] + z.c6 * qp1_[e];
+    qp[e] = z.c4 * qm1_[e] + z.c6 * qm2[e] + z.c5 * q0[e];
+  }
+  constexpr int vn = 1 + DIR;
+  double flu1, flu2, flu3, flu4, flu5;
+  if (KFLU == 5) {
+    const double gam = z.gam, rgp = z.rgp, gam1 = z.gam1, psiroe = z.psiroe;
+    double r1 = qp[0], p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * qp[4] * rgp + .5 * (qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+    double r2 = qm[0], p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * qm[4] * rgp + .5 * (qm[1] * qm[1] + qm[2] * qm[2] + qm[3] * qm[3]);
+    double qp1 = sqrt(r1), qm1 = sqrt(r2);
+    double r = qp1 * qm1;
+    double r_1 = 1. / (qp1 + qm1);
+    double u = (qp1 * qp[1] + qm1 * qm[1]) * r_1;
+    double v = (qp1 * qp[2] + qm1 * qm[2]) * r_1;
+    double w = (qp1 * qp[3] + qm1 * qm[3]) * r_1;
+    double h = (qp1 * h1 + qm1 * h2) * r_1;
+    double q = .5 * (u * u + v * v + w * w);
+    double cc = sqrt((gam - 1.) * fabs(h - q));
+    double qn1 = qp[vn] * tc, qn2 = qm[vn] * tc;
+    double du = (qm[1] - qp[1]) * s, dv = (qm[2] - qp[2]) * s, dw = (qm[3] - qp[3]) * s;
+    double dp = p2 - p1, dqn = qn2 - qn1;
+    double s_1 = 1. / fs_max(s, 1.e-30);
+    double nn = tc * s_1;
+    double vel = DIR == 0 ? u : (DIR == 1 ? v : w);
+    double qn = vel * nn;
+    double f1 = qn;
+    double f4 = psiroe * (fabs(f1) + cc);
+    double f2 = .5 + fs_sign(.5, fabs(f1) - f4);
+    double f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (r2 - r1 - dp / (cc * cc)) * s;
+    double dnu = DIR == 0 ? du - nn * dqn : du;
+    double dnv = DIR == 1 ? dv - nn * dqn : dv;
+    double dnw = DIR == 2 ? dw - nn * dqn : dw;
+    flu1 = f3 * (f1);
+    flu2 = f3 * (f1 * u + r * dnu);
+    flu3 = f3 * (f1 * v + r * dnv);
+    flu4 = f3 * (f1 * w + r * dnw);
+    flu5 = f3 * (f1 * q + r * (u * du + v * dv + w * dw - qn * dqn));
+    f1 = qn + cc;
+    f2 = .5 + fs_sign(.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * (DIR == 0 ? u + nn * cc : u);
+    flu3 = flu3 + f1 * (DIR == 1 ? v + nn * cc : v);
+    flu4 = flu4 + f1 * (DIR == 2 ? w + nn * cc : w);
+    flu5 = flu5 + f1 * (h + qn * cc);
+    f1 = qn - cc;
+    f2 = .5 + fs_sign(.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp - r * cc * dqn * s_1) / (2. * cc * cc) * f3 * s;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * (DIR == 0 ? u - nn * cc : u);
+    flu3 = flu3 + f1 * (DIR == 1 ? v - nn * cc : v);
+    flu4 = flu4 + f1 * (DIR == 2 ? w - nn * cc : w);
+    flu5 = flu5 + f1 * (h - qn * cc);
+    double rou1 = r1 * qn1, rou2 = r2 * qn2, p1p2 = p1 + p2;
+    flu1 = (flu1 + rou1 + rou2) * 0.5;
+    if (DIR == 0) flu2 = (flu2 + rou1 * qp[1] + rou2 * qm[1] + tc * p1p2) * 0.5;
+    else flu2 = (flu2 + rou1 * qp[1] + rou2 * qm[1]) * 0.5;
+    if (DIR == 1) flu3 = (flu3 + rou1 * qp[2] + rou2 * qm[2] + tc * p1p2) * 0.5;
+    else flu3 = (flu3 + rou1 * qp[2] + rou2 * qm[2]) * 0.5;
+    if (DIR == 2) flu4 = (flu4 + rou1 * qp[3] + rou2 * qm[3] + tc * p1p2) * 0.5;
+    else flu4 = (flu4 + rou1 * qp[3] + rou2 * qm[3]) * 0.5;
+    flu5 = (flu5 + rou1 * h1 + rou2 * h2) * 0.5;
+  } else {
+    const double rgp = z.rgp, gam1 = z.gam1;
+    double r1 = qp[0], rou1 = r1 * qp[1], rov1 = r1 * qp[2], row1 = r1 * qp[3];
+    double p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * p1 + .5 * (rou1 * qp[1] + rov1 * qp[2] + row1 * qp[3]);
+    double r2 = qm[0], rou2 = r2 * qm[1], rov2 = r2 * qm[2], row2 = r2 * qm[3];
+    double p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * p2 + .5 * (rou2 * qm[1] + rov2 * qm[2] + row2 * qm[3]);
+    double qn1 = qp[vn] * tc, qn2 = qm[vn] * tc;
+    double u, tdu;
+    if (KFLU == 1) {
+      double cc = rgp * z.gam * q0[4];
+      double son = sqrt(qn1 * qn1 / cc);
+      double tam = z.c3 * son + s;
+      double tam1 = fs_max(0., tam) * z.c2;
+      u = 0.25 * (qn1 + qn2) - tam1 * (p2 - p1);
+      tdu = fs_max(fabs(u), z.c1 * s);
+    } else {
+      u = 0.25 * (qn1 + qn2) - z.c2 * s * (p2 - p1) * (z.opt0 * wg + 1. - z.opt0);
+      tdu = fs_max(fabs(u), z.c1 * s) * wg;
+    }
+    double p1p2 = (p1 + p2) * 0.5;
+    flu1 = u * (r1 + r2) - tdu * (r2 - r1);
+    if (DIR == 0) flu2 = u * (rou1 + rou2) - tdu * (rou2 - rou1) + tc * p1p2;
+    else flu2 = u * (rou1 + rou2) - tdu * (rou2 - rou1);
+    if (DIR == 1) flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1) + tc * p1p2;
+    else flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1);
+    if (DIR == 2) flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tc * p1p2;
+    else flu4 = u * (row1 + row2) - tdu * (row2 - row1);
+    flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+  }
+  flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
+}
+
+// Viscous part added to flu[1..4].  il = l - inc(DIR), ir = l.  The accessor gives
+//   q(e, da, db, dn): variable e (1 u, 2 v, 3 w, 4 T) at offset dn along DIR (0 = ir, -1 = il)
+//   and (da, db) along the two transverse directions in the order (i,j,k) minus DIR.
+// mul/mur = viscosity at il / ir.
+template <int DIR, class Q>
+FS_DEV void fs_flux_viscous(const FsZone &z, const Q &q, double mul, double mur, double *flu)
+{
+  const double tcx = z.tcx, tcy = z.tcy, tcz = z.tcz;
+  double xmutvol = (mur + mul) * z.volinv;
+  double xktvol = xmutvol * z.gam3;
+  double f1, f2, f3, f4, f5, f6, fv, fv5, div;
+  const double Uil = q(1, 0, 0, -1), Uir = q(1, 0, 0, 0);
+  const double Vil = q(2, 0, 0, -1), Vir = q(2, 0, 0, 0);
+  const double Wil = q(3, 0, 0, -1), Wir = q(3, 0, 0, 0);
+  const double Til = q(4, 0, 0, -1), Tir = q(4, 0, 0, 0);
+  if (DIR == 0) {  // transverse (a,b) = (j,k)
+    const double tix = tcx, tjy = .25 * tcy, tkz = .25 * tcz;
+    f1 = Uil; f2 = Uir; fv = f1 + f2;
+    f3 = fv + q(1, -1, 0, -1) + q(1, -1, 0, 0);   // l220, l020
+    f4 = fv + q(1, 1, 0, -1) + q(1, 1, 0, 0);     // l210, l010
+    f5 = fv + q(1, 0, -1, -1) + q(1, 0, -1, 0);   // l202, l002
+    f6 = fv + q(1, 0, 1, -1) + q(1, 0, 1, 0);     // l201, l001
+    double gradU_nx = (f2 - f1) * tix, gradU_ny = (f4 - f3) * tjy, gradU_nz = (f6 - f5) * tkz;
+    f1 = Vil; f2 = Vir; fv = f1 + f2;
+    f3 = fv + q(2, -1, 0, -1) + q(2, -1, 0, 0);
+    f4 = fv + q(2, 1, 0, -1) + q(2, 1, 0, 0);
+    double gradV_nx = (f2 - f1) * tix, gradV_ny = (f4 - f3) * tjy;
+    f1 = Wil; f2 = Wir; fv = f1 + f2;
+    f5 = fv + q(3, 0, -1, -1) + q(3, 0, -1, 0);
+    f6 = fv + q(3, 0, 1, -1) + q(3, 0, 1, 0);
+    double gradW_nx = (f2 - f1) * tix, gradW_nz = (f6 - f5) * tkz;
+    double gradT_nx = (Tir - Til) * tix;
+    div = (gradU_nx + gradV_ny + gradW_nz) * z.cvisq;
+    f1 = gradU_nx - div; f2 = gradU_ny + gradV_nx; f3 = gradU_nz + gradW_nx;
+    fv = -(2. * f1 * tcx) * xmutvol; fv5 = fv * (Uir + Uil); flu[1] = flu[1] + fv;
+    fv = -(f2 * tcx) * xmutvol; fv5 = fv5 + fv * (Vir + Vil); flu[2] = flu[2] + fv;
+    fv = -(f3 * tcx) * xmutvol; fv5 = fv5 + fv * (Wir + Wil); flu[3] = flu[3] + fv;
+    fv = fv5 * 0.5 - (gradT_nx * tcx) * xktvol; flu[4] = flu[4] + fv;
+  } else if (DIR == 1) {  // transverse (a,b) = (i,k)
+    const double tiy = tcy, tjz = .25 * tcz, tkx = .25 * tcx;
+    f1 = Uil; f2 = Uir; fv = f1 + f2;
+    f5 = fv + q(1, -1, 0, -1) + q(1, -1, 0, 0);   // l220, l200
+    f6 = fv + q(1, 1, 0, -1) + q(1, 1, 0, 0);     // l120, l100
+    double gradU_nx = (f6 - f5) * tkx, gradU_ny = (f2 - f1) * tiy;
+    f1 = Vil; f2 = Vir; fv = f1 + f2;
+    f3 = fv + q(2, 0, -1, -1) + q(2, 0, -1, 0);   // l022, l002
+    f4 = fv + q(2, 0, 1, -1) + q(2, 0, 1, 0);     // l021, l001
+    f5 = fv + q(2, -1, 0, -1) + q(2, -1, 0, 0);
+    f6 = fv + q(2, 1, 0, -1) + q(2, 1, 0, 0);
+    double gradV_nx = (f6 - f5) * tkx, gradV_ny = (f2 - f1) * tiy, gradV_nz = (f4 - f3) * tjz;
+    f1 = Wil; f2 = Wir; fv = f1 + f2;
+    f3 = fv + q(3, 0, -1, -1) + q(3, 0, -1, 0);
+    f4 = fv + q(3, 0, 1, -1) + q(3, 0, 1, 0);
+    double gradW_ny = (f2 - f1) * tiy, gradW_nz = (f4 - f3) * tjz;
+    double gradT_ny = (Tir - Til) * tiy;
+    div = (gradU_nx + gradV_ny + gradW_nz) * z.cvisq;
+    f2 = gradU_ny + gradV_nx; f4 = gradV_ny - div; f5 = gradV_nz + gradW_ny;
+    fv = -(f2 * tcy) * xmutvol; fv5 = fv * (Uir + Uil); flu[1] = flu[1] + fv;
+    fv = -(2. * f4 * tcy) * xmutvol; fv5 = fv5 + fv * (Vir + Vil); flu[2] = flu[2] + fv;
+    fv = -(f5 * tcy) * xmutvol; fv5 = fv5 + fv * (Wir + Wil); flu[3] = flu[3] + fv;
+    fv = fv5 * 0.5 - (gradT_ny * tcy) * xktvol; flu[4] = flu[4] + fv;
+  } else {  // transverse (a,b) = (i,j)
+    const double tiz = tcz, tky = 0.25 * tcy, tjx = 0.25 * tcx;
+    f1 = Uil; f2 = Uir; fv = f1 + f2;
+    f3 = fv + q(1, -1, 0, -1) + q(1, -1, 0, 0);   // l202, l200
+    f4 = fv + q(1, 1, 0, -1) + q(1, 1, 0, 0);     // l102, l100
+    double gradU_nx = (f4 - f3) * tjx, gradU_nz = (f2 - f1) * tiz;
+    f1 = Vil; f2 = Vir; fv = f1 + f2;
+    f5 = fv + q(2, 0, -1, -1) + q(2, 0, -1, 0);   // l022, l020
+    f6 = fv + q(2, 0, 1, -1) + q(2, 0, 1, 0);     // l012, l010
+    double gradV_ny = (f6 - f5) * tky, gradV_nz = (f2 - f1) * tiz;
+    f1 = Wil; f2 = Wir; fv = f1 + f2;
+    f3 = fv + q(3, -1, 0, -1) + q(3, -1, 0, 0);
+    f4 = fv + q(3, 1, 0, -1) + q(3, 1, 0, 0);
+    f5 = fv + q(3, 0, -1, -1) + q(3, 0, -1, 0);
+    f6 = fv + q(3, 0, 1, -1) + q(3, 0, 1, 0);
+    double gradW_nx = (f4 - f3) * tjx, gradW_ny = (f6 - f5) * tky, gradW_nz = (f2 - f1) * tiz;
+    double gradT_nz = (Tir - Til) * tiz;
+    div = (gradU_nx + gradV_ny + gradW_nz) * z.cvisq;
+    f3 = gradU_nz + gradW_nx; f5 = gradV_nz + gradW_ny; f6 = gradW_nz - div;
+    fv = -f3 * tcz * xmutvol; fv5 = fv * (Uir + Uil); flu[1] = flu[1] + fv;
+    fv = -f5 * tcz * xmutvol; fv5 = fv5 + fv * (Vir + Vil); flu[2] = flu[2] + fv;
+    fv = -2. * f6 * tcz * xmutvol; fv5 = fv5 + fv * (Wir + Wil); flu[3] = flu[3] + fv;
+    fv = fv5 * 0.5 - gradT_nz * tcz * xktvol; flu[4] = flu[4] + fv;
+  }
+}
+
+// Runge-Kutta stage update of one cell in conservative form, back to primitive variables
+// (core3ark3.for:108-154).  q = stage input, d = balance, out = stage output.
+FS_DEV void fs_rk_update(const FsZone &z, double coefW, const double *q, const double *d, double *out)
+{
+  double r_1 = coefW * z.coe;
+  double tab1 = d[0] * r_1, tab2 = d[1] * r_1, tab3 = d[2] * r_1, tab4 = d[3] * r_1, tab5 = d[4] * r_1;
+  double ro_old = q[0], u_old = q[1], v_old = q[2], w_old = q[3], t_old = q[4];
+  double ro_new = q[0] + tab1;
+  r_1 = 1. / ro_new;
+  double un = (ro_old * u_old + tab2) * r_1;
+  double vn = (ro_old * v_old + tab3) * r_1;
+  double wn = (ro_old * w_old + tab4) * r_1;
+  double roe_old = ro_old * (z.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+  out[0] = ro_new; out[1] = un; out[2] = vn; out[3] = wn;
+  out[4] = (roe_old + tab5) * r_1 * z.cvinv - z.cvinv2 * (un * un + vn * vn + wn * wn);
+}

@@ -1,0 +1,25 @@
+// Launch interface between the C ABI (fasts_capi.hip) and the kernels (fasts_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fasts_flux.h"
+
+// one BC window: ghost cells lo..hi (interior-based indices, ghosts <= 0 or > n)
+struct FsBcWin {
+  int type;          // BC tag (Fast/FastC/FastC/PyTree.py:30-82): 0 extrapolate, 11 autoperiod
+  int idir;          // 1..6 = imin,imax,jmin,jmax,kmin,kmax
+  int lo[3], hi[3];
+  long long shift;   // periodic source offset (bvbs_periodique.for: incp)
+};
+
+void fsk_invist(const FsZone &z, const double *rop, double *xmut, hipStream_t s);
+void fsk_wiggle(const FsZone &z, const double *rop, double *wig, hipStream_t s);
+int fsk_stage(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+              double *drodm, const double *xmut, const double *wig, hipStream_t s);
+void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop,
+                    hipStream_t s);
+void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);
+void fsk_join_copy(int npts, int neq, long long nd_r, long long nd_d, const int *rcv, const int *dnr,
+                   double *rop_r, const double *rop_d, hipStream_t s);
+void fsk_halo_pack(int npts, int neq, long long nd, const int *pts, const double *rop, double *buf, hipStream_t s);
+void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *rop, const double *buf, hipStream_t s);
+void fsk_residual(const FsZone &z, const double *drodm, double *part, double *out, hipStream_t s);

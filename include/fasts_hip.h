@@ -1,0 +1,157 @@
+/*
+ * fasts_hip.h -- C ABI of the MI355X (gfx950) FastS time-step library (libfasts_hip.so).
+ *
+ * This is the drop-in boundary for the structured-grid compressible Navier-Stokes time
+ * step of IvanMary69/Fast: the entry points below are what a binding of the reference's
+ * CPython extension modules `fasts` / `fastc` would call instead of its OpenMP/Fortran
+ * path.  Each declaration cites the reference interface it replaces (paths relative to the
+ * reference tree).  Plain pointers and sizes only; every function returns 0 on success or a
+ * negative error code, never exits the process; fs_last_error() gives the message.
+ *
+ * Data contract (same as the reference, Fast/FastS/FastS/Compute/computePT.cpp:225-369):
+ *   - Parameter_int  : int32 array, layout of Fast/FastS/FastS/param_solver.h:77-214 with the
+ *                      BC table appended from Parameter_int[PT_BC]
+ *                      (Fast/FastC/FastC/PyTree.py:2958-3014)
+ *   - Parameter_real : float64 array, layout of param_solver.h:225-306
+ *   - a time level   : NEQ contiguous fields of NDIMDX float64 (ghost cells included,
+ *                      i fastest), i.e. the buffer FastC._compact builds
+ *                      (Fast/FastC/FastC/PyTree.py:2256-2268)
+ *   - metrics        : [ti | tj | tk | vol] as allocated by fasts.allocate_metric
+ *                      (Fast/FastS/FastS/Metric/allocate_metric.cpp:281-284)
+ * Host arrays stay owned by the caller (the pyTree); the library keeps device copies and
+ * moves data only in fs_upload / fs_download.
+ *
+ * Threading: one host thread per context; contexts are independent (one per GPU / rank).
+ */
+#ifndef FASTS_HIP_H
+#define FASTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_ctx fs_ctx;
+
+/* error codes */
+#define FS_OK 0
+#define FS_ERR_ARG (-1)         /* bad argument / inconsistent sizes                     */
+#define FS_ERR_UNSUPPORTED (-2) /* option outside what the device path implements       */
+#define FS_ERR_HIP (-3)         /* HIP runtime error (message in fs_last_error)          */
+#define FS_ERR_STATE (-4)       /* call order violated (e.g. compute before upload)      */
+
+/* time-level selectors for fs_download / fs_fill_ghostcells / fs_apply_bc */
+#define FS_LEVEL_N 1
+#define FS_LEVEL_M1 2
+#define FS_LEVEL_P1 4
+
+/* Library version, build flags (for the "is the native path loaded" check). */
+const char *fs_version(void);
+
+/* Create / destroy a solver context bound to one HIP device.
+ * Replaces the module-level state of the reference glue (FastC.HOOK work arrays created by
+ * Fast/FastC/FastC/PyTree.py:2058-2224: drodm, coe, wiggle). */
+int fs_create(fs_ctx **ctx, int device);
+void fs_destroy(fs_ctx *ctx);
+const char *fs_last_error(const fs_ctx *ctx);
+
+/* Use an existing HIP stream (hipStream_t passed as void*) for every launch and copy of this
+ * context; NULL selects the context's own stream. */
+int fs_set_stream(fs_ctx *ctx, void *hip_stream);
+
+/* Verification period: residual norms are evaluated on sub-iteration 1 of the time steps with
+ * nitrun % modulo_verif == 0 or nitrun == 1, the rule the reference applies to its CFL /
+ * residual diagnostics (Fast/FastS/FastS/Compute/computePT.cpp:100; modulo_verif is
+ * .Solver#dtloc[1], Fast/FastC/FastC/PyTree.py:1186).  Default 200. */
+int fs_set_verif(fs_ctx *ctx, int modulo_verif);
+
+/* Register one zone.  Returns the zone index (>= 0) or an error code.
+ * Replaces the per-zone pointer gathering of K_FASTS::_computePT
+ * (Fast/FastS/FastS/Compute/computePT.cpp:225-369) and the metric list produced by
+ * fasts.allocate_metric / fastc.init_metric
+ * (Fast/FastS/FastS/Metric/allocate_metric.cpp:464-471).
+ * ro / ro_m1 / ro_p1 are the host buffers of the three time levels (Density, Density_M1,
+ * Density_P1 and the fields compacted behind them). */
+int fs_zone_add(fs_ctx *ctx, const int32_t *param_int, int n_int, const double *param_real,
+                int n_real, double *ro, double *ro_m1, double *ro_p1, const double *mtr,
+                int n_mtr);
+
+/* Match-join ghost transfer tables (one entry per join "rac"): receiver zone, donor zone and
+ * the two index lists (0-based, ghost-inclusive linear cell indices i + j*ni + k*ni*nj), i.e.
+ * the PointListDonor / PointList arrays of a 'direct' (type 0) ID join, as hand-built in
+ * Fast/FastS/test/tgvMpi.py:141-195 and consumed by K_FASTC::setInterpTransfersIntra
+ * (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:440-935).
+ * donor_zone < 0 marks a join whose donor lives in another context (another GPU): its values
+ * arrive through fs_halo_unpack, and -donor_zone-1 is the caller's peer tag. */
+int fs_join_add(fs_ctx *ctx, int rcv_zone, int donor_zone, const int32_t *rcv_pts,
+                const int32_t *donor_pts, int npts);
+
+/* Send side of an inter-context join: donor cells of local zone `donor_zone` whose values go
+ * to peer `peer_tag`.  Replaces the packing loop of K_FASTC::setInterpTransfersInter
+ * (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:944-1582). */
+int fs_send_add(fs_ctx *ctx, int donor_zone, int peer_tag, const int32_t *donor_pts, int npts);
+
+/* Host -> device copy of the three time levels of every zone; allocates device storage on
+ * first call. */
+int fs_upload(fs_ctx *ctx);
+
+/* Device -> host copy of the selected time levels (FS_LEVEL_* mask) into the buffers that
+ * currently play those roles. */
+int fs_download(fs_ctx *ctx, int levels_mask);
+
+/* Advance nit_c time steps, each running sub-iterations nstep_deb..nstep_fin
+ * (RHS -> update -> joins -> BCs -> edge/corner fix) and rotating the time levels at the end
+ * of a step.  Replaces fasts._computePT(zones, metrics, nitrun, nstep_deb, nstep_fin,
+ * layer_mode=1, nit_c, hook) (Fast/FastS/FastS/Compute/computePT.cpp:44-719) and
+ * K_FASTS::gsdr3 (Fast/FastS/FastS/Compute/gsdr3.cpp:38-461).  *t_trans receives 0 (transfer
+ * time is not separable on the device). Asynchronous: returns after enqueueing. */
+int fs_compute(fs_ctx *ctx, int nitrun, int nstep_deb, int nstep_fin, int nit_c, double *t_trans);
+
+/* Split form of one sub-iteration for callers that exchange halos between contexts:
+ *   fs_stage          RHS + update of every local zone          (gsdr3.cpp:251-269)
+ *   fs_halo_pack      gather the donor cells for peer_tag into dev_buf (device pointer,
+ *                     neq*npts doubles, variable-major)          (setInterpTransfersFast.cpp:1200-1206)
+ *   fs_halo_unpack    scatter dev_buf into the ghost cells of the joins tagged peer_tag
+ *                                                                (setInterpTransfersFast.cpp:1652-1667)
+ *   fs_local_joins    intra-context joins                        (setInterpTransfersFast.cpp:440-935)
+ *   fs_bcs            BCs + edge/corner fix on the stage output  (gsdr3.cpp:403-422, bcs.cpp:30-41)
+ *   fs_rotate         M1 <- N <- P1 <- M1                        (computePT.cpp:673-677)        */
+int fs_stage(fs_ctx *ctx, int nitrun, int nstep);
+int fs_halo_count(fs_ctx *ctx, int peer_tag, int is_send);
+int fs_halo_pack(fs_ctx *ctx, int nstep, int peer_tag, double *dev_buf, int n_doubles);
+int fs_halo_unpack(fs_ctx *ctx, int nstep, int peer_tag, const double *dev_buf, int n_doubles);
+int fs_local_joins(fs_ctx *ctx, int nstep);
+int fs_bcs(fs_ctx *ctx, int nstep);
+int fs_rotate(fs_ctx *ctx);
+
+/* Joins then BCs then edge/corner fix on one time level: replaces
+ * FastS.PyTree._fillGhostcells (Fast/FastS/FastS/PyTree.py:1153-1218) for local joins. */
+int fs_fill_ghostcells(fs_ctx *ctx, int level);
+
+/* BCs + edge/corner fix only: replaces fasts._applyBC(zones, metrics, hook, nstep, var)
+ * (Fast/FastS/FastS/BC/applyBC.cpp:37-39). */
+int fs_apply_bc(fs_ctx *ctx, int nstep, int level);
+
+/* Residual norms of the first sub-iteration of the last step of one zone, per equation:
+ * l2[e] = sqrt(sum (coe*drodm)^2 / ncell)/dt, loo[e] = max|coe*drodm|/dt
+ * (Fast/FastS/FastS/Compute/cprdu3s1_incl.for:47-71 +
+ *  Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:128-141).  Synchronises. */
+int fs_residuals(fs_ctx *ctx, int zone, double *l2, double *loo, int neq);
+
+/* Block until everything enqueued on the context's stream has finished. */
+int fs_sync(fs_ctx *ctx);
+
+/* Average device time in milliseconds of the stage kernel (RHS + update) launches since the
+ * last call with reset != 0; measured with HIP events on the launch stream.  *n_launch
+ * receives the number of launches averaged. */
+int fs_stage_kernel_ms(fs_ctx *ctx, int reset, double *avg_ms, int *n_launch);
+
+/* Copy one raw device work array of a zone to the host (tests / diagnostics):
+ * which = 0 drodm (neq*ndimdx), 1 wig (3*ndimdx), 2 xmut (ndimdx). */
+int fs_debug_fetch(fs_ctx *ctx, int zone, int which, double *host, int n_doubles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTS_HIP_H */

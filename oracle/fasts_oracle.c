@@ -1,0 +1,675 @@
+/*
+ * CPU restatement of the reference FastS explicit time step (plain C, scalar, one thread).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker used by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg; nothing under fast_amd/ links,
+ * loads or calls it.  It is pinned against the compiled reference Fortran
+ * (oracle/_ref/libfast_ref.so, built by oracle/build_ref.py) in tests/test_oracle_vs_ref.py
+ * and against the fixtures under tests/golden/ that were generated from that library.
+ *
+ * Scope: zone type 2 (Cartesian, constant step), 5 equations, slope o3, schemes
+ * ausmpred (1) / senseur (2) / roe (5), Euler or laminar Navier-Stokes, explicit RK1/2/3,
+ * BCautoperiod + BCExtrapolate ghost fill, edge/corner fix.  Array layout, loop ranges and
+ * the order of floating-point operations follow the reference routines cited at each
+ * function, so that with one cache block the results agree with the reference to rounding.
+ *
+ * Indices into Parameter_int / Parameter_real are those of
+ * Fast/FastS/FastS/param_solver.h:77-306.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NIJK 0
+#define IJKV 20
+#define ITYPZONE 25
+#define IFLOW 27
+#define ITYPCP 29
+#define KFLUDOM 33
+#define NEQ 36
+#define NDIMDX 41
+#define RK 52
+#define NSSITER 58
+#define SLOPE 64
+#define PT_BC 70
+#define SENSORTYPE 85
+
+#define DTC 0
+#define GAMMA 1
+#define CVINF 2
+#define ROINF 3
+#define VINF 5
+#define TINF 6
+#define PRANDT 10
+#define XMUL0 11
+#define TEMP0 12
+#define CS 13
+#define PSIROE 34
+
+typedef int32_t i32;
+
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+static inline double dsign(double a, double b) { return copysign(fabs(a), b); }
+
+/* 0-based linear index of cell (i,j,k), interior starting at 1
+ * (Fast/FastS/FastS/formule_param.h:4-7). */
+#define INDDM(i, j, k) ((long)((i) + ific - 1) + (long)((j) + ific - 1) * ni + (long)((k) + ifick - 1) * ninj)
+
+#define GEOM(p)                                                                      \
+  const long ni = (p)[NIJK], nj = (p)[NIJK + 1];                                     \
+  const long ninj = ni * nj;                                                         \
+  const int ific = (p)[NIJK + 3], ifick = (p)[NIJK + 4];                             \
+  const long nd = (p)[NDIMDX];                                                       \
+  (void)nj; (void)nd; (void)ifick; (void)ific; (void)ninj;
+
+/* Sutherland viscosity, Fast/FastS/FastS/Compute/invist.for:49-61 */
+void fo_invist(const i32 *p, const double *pr, const i32 *ind, const double *rop, double *xmut)
+{
+  GEOM(p)
+  const double cmus1 = pr[CS];
+  const double temp01 = 1. / pr[TEMP0];
+  const double coesut = pr[XMUL0] * (1. + cmus1 * temp01) * sqrt(temp01);
+  const double *T = rop + 4 * nd;
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        long l = INDDM(i, j, k);
+        double t1 = T[l];
+        xmut[l] = coesut * sqrt(t1) * t1 / (t1 + cmus1);
+      }
+}
+
+/* drodm = 0 at the first stage, drodm *= xi afterwards
+ * (Fast/FastS/FastS/Compute/init_rhs.for:31-32,58-129) */
+void fo_init_rhs(const i32 *p, int nitcfg, const i32 *ind, double *drodm)
+{
+  GEOM(p)
+  const double cxsi1 = -0.6830127018922193, cxsi2 = -4. / 3.;
+  double coefH = 0.;
+  int b = p[RK];
+  if (b == 3) coefH = nitcfg == 2 ? cxsi1 : (nitcfg == 3 ? cxsi2 : 0.);
+  else if (b == 2) coefH = nitcfg == 2 ? -1. : 0.;
+  int zero = (p[ITYPCP] <= 1 || nitcfg == 1);
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        long l = INDDM(i, j, k);
+        for (int e = 0; e < 5; e++) drodm[l + e * nd] = zero ? 0. : drodm[l + e * nd] * coefH;
+      }
+}
+
+/* one sensor value: 1 when some variable shows two consecutive slope sign changes
+ * (Fast/FastS/FastS/Compute/SENSOR/wiggle.for:1-31, wiggle_i.for:3-8) */
+static inline double wiggle1(const double *rop, long nd, long l, long inc)
+{
+  const double souszero = -1e-12;
+  long nm = l - inc, nm2 = l - 2 * inc, np = l + inc;
+  double test = 1e30;
+  for (int e = 0; e < 5; e++) {
+    const double *q = rop + e * nd;
+    double qm = (q[nm] - q[nm2]) * (q[l] - q[nm]);
+    double qp = (q[l] - q[nm]) * (q[np] - q[l]);
+    double f = dsign(1., qm) + dsign(1., qp);
+    test = e == 0 ? f : dmin(test, f);
+  }
+  return test < souszero ? 1. : 0.;
+}
+
+/* wiggle sensor on all faces of the range, incl. the max-side faces
+ * (Fast/FastS/FastS/Compute/SENSOR/wiggle2001.for:50-142) */
+void fo_wiggle(const i32 *p, const i32 *ind, const double *rop, double *wig)
+{
+  GEOM(p)
+  const long inci = 1, incj = ni, inck = ninj;
+  int icorr = ind[1] == p[IJKV], jcorr = ind[3] == p[IJKV + 1], kcorr = ind[5] == p[IJKV + 2];
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        long l = INDDM(i, j, k);
+        wig[l + 2 * nd] = wiggle1(rop, nd, l, inck);
+        wig[l + nd] = wiggle1(rop, nd, l, incj);
+        wig[l] = wiggle1(rop, nd, l, inci);
+      }
+  if (icorr)
+    for (int k = ind[4]; k <= ind[5]; k++)
+      for (int j = ind[2]; j <= ind[3]; j++) {
+        long l = INDDM(ind[1] + 1, j, k);
+        wig[l] = wiggle1(rop, nd, l, inci);
+      }
+  if (jcorr)
+    for (int k = ind[4]; k <= ind[5]; k++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        long l = INDDM(i, ind[3] + 1, k);
+        wig[l + nd] = wiggle1(rop, nd, l, incj);
+      }
+  if (kcorr)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        long l = INDDM(i, j, ind[5] + 1);
+        wig[l + 2 * nd] = wiggle1(rop, nd, l, inck);
+      }
+}
+
+typedef struct {
+  int kflu, iflow;
+  double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
+  double tcx, tcy, tcz, si, sj, sk, volinv;
+  long nd, inc[3];
+} fluxctx;
+
+/* Flux through the face between cell l-inc[dir] and cell l, direction dir (0 i, 1 j, 2 k).
+ * Inviscid part: MUSCL o3 (Fast/FastS/FastS/Compute/Slope/o3_slope_var.for:2-3) then
+ *   ausmpred  Fast/FastS/FastS/Compute/AUSM/3dcart/fluFaceEuler_o3_3dcart_i.for + etat_GD.for
+ *             + Vit_ent/qn_3dcart_i.for + Vit_ent/fluvector_3dcart_i.for
+ *   senseur   Fast/FastS/FastS/Compute/SENSOR/3dcart/fluFaceEuler_o3_3dcart_i.for
+ *   roe       Fast/FastS/FastS/Compute/ROE/3dcart/fluFaceEuler_o3_3dcart_i.for + etat_roe_GD.for
+ *             + Vit_ent/fludiffer_3dcart_i.for
+ * Viscous part (iflow 2): Fast/FastS/FastS/Compute/fluvisq_3dcart_{i,j,k}.for, mut_interface.for */
+static inline void face_flux(const fluxctx *c, const double *rop, const double *wig,
+                             const double *xmut, long l, int dir, double *flu)
+{
+  const long nd = c->nd, inc = c->inc[dir];
+  const long nm = l - inc, nm2 = l - 2 * inc, np = l + inc;
+  const double tc = dir == 0 ? c->tcx : (dir == 1 ? c->tcy : c->tcz);
+  const double s = dir == 0 ? c->si : (dir == 1 ? c->sj : c->sk);
+  double qm[5], qp[5];
+  for (int e = 0; e < 5; e++) {
+    const double *q = rop + e * nd;
+    qm[e] = c->c4 * q[l] + c->c5 * q[nm] + c->c6 * q[np];
+    qp[e] = c->c4 * q[nm] + c->c6 * q[nm2] + c->c5 * q[l];
+  }
+  const int vn = 1 + dir; /* normal velocity component */
+  double flu1, flu2, flu3, flu4, flu5;
+  if (c->kflu == 5) {
+    const double gam = c->gam, rgp = c->rgp, gam1 = c->gam1, psiroe = c->psiroe;
+    double r1 = qp[0], p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * qp[4] * rgp + .5 * (qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+    double r2 = qm[0], p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * qm[4] * rgp + .5 * (qm[1] * qm[1] + qm[2] * qm[2] + qm[3] * qm[3]);
+    double qp1 = sqrt(r1), qm1 = sqrt(r2);
+    double r = qp1 * qm1;
+    double r_1 = 1. / (qp1 + qm1);
+    double u = (qp1 * qp[1] + qm1 * qm[1]) * r_1;
+    double v = (qp1 * qp[2] + qm1 * qm[2]) * r_1;
+    double w = (qp1 * qp[3] + qm1 * qm[3]) * r_1;
+    double h = (qp1 * h1 + qm1 * h2) * r_1;
+    double q = .5 * (u * u + v * v + w * w);
+    double cc = sqrt((gam - 1.) * fabs(h - q));
+    double qn1 = qp[vn] * tc, qn2 = qm[vn] * tc;
+    double du = (qm[1] - qp[1]) * s, dv = (qm[2] - qp[2]) * s, dw = (qm[3] - qp[3]) * s;
+    double dp = p2 - p1, dqn = qn2 - qn1;
+    double s_1 = 1. / dmax(s, 1.e-30);
+    double nn = tc * s_1;
+    double vel[3] = {u, v, w};
+    double qn = vel[dir] * nn;
+    double f1 = qn;
+    double f4 = psiroe * (fabs(f1) + cc);
+    double f2 = .5 + dsign(.5, fabs(f1) - f4);
+    double f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (r2 - r1 - dp / (cc * cc)) * s;
+    double dd[3] = {du, dv, dw};
+    double dn[3] = {du, dv, dw};
+    dn[dir] = dd[dir] - nn * dqn;
+    flu1 = f3 * (f1);
+    flu2 = f3 * (f1 * u + r * dn[0]);
+    flu3 = f3 * (f1 * v + r * dn[1]);
+    flu4 = f3 * (f1 * w + r * dn[2]);
+    flu5 = f3 * (f1 * q + r * (u * du + v * dv + w * dw - qn * dqn));
+    f1 = qn + cc;
+    f2 = .5 + dsign(.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
+    double vp[3] = {u, v, w};
+    vp[dir] = vel[dir] + nn * cc;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * vp[0];
+    flu3 = flu3 + f1 * vp[1];
+    flu4 = flu4 + f1 * vp[2];
+    flu5 = flu5 + f1 * (h + qn * cc);
+    f1 = qn - cc;
+    f2 = .5 + dsign(.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp - r * cc * dqn * s_1) / (2. * cc * cc) * f3 * s;
+    double vm[3] = {u, v, w};
+    vm[dir] = vel[dir] - nn * cc;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * vm[0];
+    flu3 = flu3 + f1 * vm[1];
+    flu4 = flu4 + f1 * vm[2];
+    flu5 = flu5 + f1 * (h - qn * cc);
+    double rou1 = r1 * qn1, rou2 = r2 * qn2, p1p2 = p1 + p2;
+    double pt[3] = {0., 0., 0.};
+    flu1 = (flu1 + rou1 + rou2) * 0.5;
+    if (dir == 0) flu2 = (flu2 + rou1 * qp[1] + rou2 * qm[1] + tc * p1p2) * 0.5;
+    else flu2 = (flu2 + rou1 * qp[1] + rou2 * qm[1]) * 0.5;
+    if (dir == 1) flu3 = (flu3 + rou1 * qp[2] + rou2 * qm[2] + tc * p1p2) * 0.5;
+    else flu3 = (flu3 + rou1 * qp[2] + rou2 * qm[2]) * 0.5;
+    if (dir == 2) flu4 = (flu4 + rou1 * qp[3] + rou2 * qm[3] + tc * p1p2) * 0.5;
+    else flu4 = (flu4 + rou1 * qp[3] + rou2 * qm[3]) * 0.5;
+    flu5 = (flu5 + rou1 * h1 + rou2 * h2) * 0.5;
+    (void)pt;
+  } else {
+    const double rgp = c->rgp, gam1 = c->gam1;
+    double r1 = qp[0], rou1 = r1 * qp[1], rov1 = r1 * qp[2], row1 = r1 * qp[3];
+    double p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * p1 + .5 * (rou1 * qp[1] + rov1 * qp[2] + row1 * qp[3]);
+    double r2 = qm[0], rou2 = r2 * qm[1], rov2 = r2 * qm[2], row2 = r2 * qm[3];
+    double p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * p2 + .5 * (rou2 * qm[1] + rov2 * qm[2] + row2 * qm[3]);
+    double qn1 = qp[vn] * tc, qn2 = qm[vn] * tc;
+    double u, tdu;
+    if (c->kflu == 1) {
+      double cc = rgp * c->gam * rop[l + 4 * nd];
+      double son = sqrt(qn1 * qn1 / cc);
+      double tam = c->c3 * son + s;
+      double tam1 = dmax(0., tam) * c->c2;
+      u = 0.25 * (qn1 + qn2) - tam1 * (p2 - p1);
+      tdu = dmax(fabs(u), c->c1 * s);
+    } else {
+      double wg = wig[l + dir * nd];
+      u = 0.25 * (qn1 + qn2) - c->c2 * s * (p2 - p1) * (c->opt0 * wg + 1. - c->opt0);
+      tdu = dmax(fabs(u), c->c1 * s) * wg;
+    }
+    double p1p2 = (p1 + p2) * 0.5;
+    flu1 = u * (r1 + r2) - tdu * (r2 - r1);
+    if (dir == 0) flu2 = u * (rou1 + rou2) - tdu * (rou2 - rou1) + tc * p1p2;
+    else flu2 = u * (rou1 + rou2) - tdu * (rou2 - rou1);
+    if (dir == 1) flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1) + tc * p1p2;
+    else flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1);
+    if (dir == 2) flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tc * p1p2;
+    else flu4 = u * (row1 + row2) - tdu * (row2 - row1);
+    flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+  }
+
+  if (c->iflow == 2) {
+    const long inci = c->inc[0], incj = c->inc[1], inck = c->inc[2];
+    const double *U = rop + nd, *V = rop + 2 * nd, *W = rop + 3 * nd, *T = rop + 4 * nd;
+    const double tcx = c->tcx, tcy = c->tcy, tcz = c->tcz;
+    const long il = l - inc, ir = l;
+    double f1, f2, f3, f4, f5, f6, fv, fv5, div;
+    double xmutvol = (xmut[ir] + xmut[il]) * c->volinv;
+    double xktvol = xmutvol * c->gam3;
+    if (dir == 0) {
+      const long l220 = l - inci - incj, l020 = l - incj, l210 = l - inci + incj, l010 = l + incj;
+      const long l202 = l - inci - inck, l002 = l - inck, l201 = l - inci + inck, l001 = l + inck;
+      const double tix = tcx, tjy = .25 * tcy, tkz = .25 * tcz;
+      f1 = U[il]; f2 = U[ir]; fv = f1 + f2;
+      f3 = fv + U[l220] + U[l020]; f4 = fv + U[l210] + U[l010];
+      f5 = fv + U[l202] + U[l002]; f6 = fv + U[l201] + U[l001];
+      double gradU_nx = (f2 - f1) * tix, gradU_ny = (f4 - f3) * tjy, gradU_nz = (f6 - f5) * tkz;
+      f1 = V[il]; f2 = V[ir]; fv = f1 + f2;
+      f3 = fv + V[l220] + V[l020]; f4 = fv + V[l210] + V[l010];
+      double gradV_nx = (f2 - f1) * tix, gradV_ny = (f4 - f3) * tjy;
+      f1 = W[il]; f2 = W[ir]; fv = f1 + f2;
+      f5 = fv + W[l202] + W[l002]; f6 = fv + W[l201] + W[l001];
+      double gradW_nx = (f2 - f1) * tix, gradW_nz = (f6 - f5) * tkz;
+      f1 = T[il]; f2 = T[ir];
+      double gradT_nx = (f2 - f1) * tix;
+      div = (gradU_nx + gradV_ny + gradW_nz) * c->cvisq;
+      f1 = gradU_nx - div; f2 = gradU_ny + gradV_nx; f3 = gradU_nz + gradW_nx;
+      fv = -(2. * f1 * tcx) * xmutvol; fv5 = fv * (U[ir] + U[il]); flu2 = flu2 + fv;
+      fv = -(f2 * tcx) * xmutvol; fv5 = fv5 + fv * (V[ir] + V[il]); flu3 = flu3 + fv;
+      fv = -(f3 * tcx) * xmutvol; fv5 = fv5 + fv * (W[ir] + W[il]); flu4 = flu4 + fv;
+      fv = fv5 * 0.5 - (gradT_nx * tcx) * xktvol; flu5 = flu5 + fv;
+    } else if (dir == 1) {
+      const long l022 = l - incj - inck, l002 = l - inck, l021 = l - incj + inck, l001 = l + inck;
+      const long l220 = l - inci - incj, l200 = l - inci, l120 = l + inci - incj, l100 = l + inci;
+      const double tiy = tcy, tjz = .25 * tcz, tkx = .25 * tcx;
+      f1 = U[il]; f2 = U[ir]; fv = f1 + f2;
+      f5 = fv + U[l220] + U[l200]; f6 = fv + U[l120] + U[l100];
+      double gradU_nx = (f6 - f5) * tkx, gradU_ny = (f2 - f1) * tiy;
+      f1 = V[il]; f2 = V[ir]; fv = f1 + f2;
+      f3 = fv + V[l022] + V[l002]; f4 = fv + V[l021] + V[l001];
+      f5 = fv + V[l220] + V[l200]; f6 = fv + V[l120] + V[l100];
+      double gradV_nx = (f6 - f5) * tkx, gradV_ny = (f2 - f1) * tiy, gradV_nz = (f4 - f3) * tjz;
+      f1 = W[il]; f2 = W[ir]; fv = f1 + f2;
+      f3 = fv + W[l022] + W[l002]; f4 = fv + W[l021] + W[l001];
+      double gradW_ny = (f2 - f1) * tiy, gradW_nz = (f4 - f3) * tjz;
+      f1 = T[il]; f2 = T[ir];
+      double gradT_ny = (f2 - f1) * tiy;
+      div = (gradU_nx + gradV_ny + gradW_nz) * c->cvisq;
+      f2 = gradU_ny + gradV_nx; f4 = gradV_ny - div; f5 = gradV_nz + gradW_ny;
+      fv = -(f2 * tcy) * xmutvol; fv5 = fv * (U[ir] + U[il]); flu2 = flu2 + fv;
+      fv = -(2. * f4 * tcy) * xmutvol; fv5 = fv5 + fv * (V[ir] + V[il]); flu3 = flu3 + fv;
+      fv = -(f5 * tcy) * xmutvol; fv5 = fv5 + fv * (W[ir] + W[il]); flu4 = flu4 + fv;
+      fv = fv5 * 0.5 - (gradT_ny * tcy) * xktvol; flu5 = flu5 + fv;
+    } else {
+      const long l200 = l - inci, l202 = l - inci - inck, l102 = l + inci - inck, l100 = l + inci;
+      const long l022 = l - incj - inck, l020 = l - incj, l012 = l + incj - inck, l010 = l + incj;
+      const double tiz = tcz, tky = 0.25 * tcy, tjx = 0.25 * tcx;
+      f1 = U[il]; f2 = U[ir]; fv = f1 + f2;
+      f3 = fv + U[l202] + U[l200]; f4 = fv + U[l102] + U[l100];
+      double gradU_nx = (f4 - f3) * tjx, gradU_nz = (f2 - f1) * tiz;
+      f1 = V[il]; f2 = V[ir]; fv = f1 + f2;
+      f5 = fv + V[l022] + V[l020]; f6 = fv + V[l012] + V[l010];
+      double gradV_ny = (f6 - f5) * tky, gradV_nz = (f2 - f1) * tiz;
+      f1 = W[il]; f2 = W[l]; fv = f1 + f2;
+      f3 = fv + W[l202] + W[l200]; f4 = fv + W[l102] + W[l100];
+      f5 = fv + W[l022] + W[l020]; f6 = fv + W[l012] + W[l010];
+      double gradW_nx = (f4 - f3) * tjx, gradW_ny = (f6 - f5) * tky, gradW_nz = (f2 - f1) * tiz;
+      f1 = T[il]; f2 = T[ir];
+      double gradT_nz = (f2 - f1) * tiz;
+      div = (gradU_nx + gradV_ny + gradW_nz) * c->cvisq;
+      f3 = gradU_nz + gradW_nx; f5 = gradV_nz + gradW_ny; f6 = gradW_nz - div;
+      fv = -f3 * tcz * xmutvol; fv5 = fv * (U[ir] + U[il]); flu2 = flu2 + fv;
+      fv = -f5 * tcz * xmutvol; fv5 = fv5 + fv * (V[ir] + V[il]); flu3 = flu3 + fv;
+      fv = -2. * f6 * tcz * xmutvol; fv5 = fv5 + fv * (W[ir] + W[il]); flu4 = flu4 + fv;
+      fv = fv5 * 0.5 - gradT_nz * tcz * xktvol; flu5 = flu5 + fv;
+    }
+  }
+  flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
+}
+
+static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const double *ti,
+                         const double *tj, const double *tk, const double *vol)
+{
+  /* constants: Fast/FastS/FastS/Compute/template_FluxAndBalance.for:108-156 */
+  c->kflu = p[KFLUDOM]; c->iflow = p[IFLOW];
+  c->tcx = ti[0]; c->tcy = tj[0]; c->tcz = tk[0];
+  c->si = fabs(c->tcx); c->sj = fabs(c->tcy); c->sk = fabs(c->tcz);
+  c->volinv = 0.5 / vol[0];
+  double gam = pr[GAMMA];
+  c->gam = gam;
+  c->rgp = pr[CVINF] * (gam - 1.);
+  c->gam1 = gam / (gam - 1.);
+  c->gam3 = c->gam1 / pr[PRANDT] * c->rgp;
+  double roref = pr[ROINF], uref = pr[VINF];
+  c->psiroe = pr[PSIROE];
+  c->c1 = 0.02 * uref;
+  c->c2 = 0.02 / (uref * roref);
+  c->c3 = -2.;
+  c->opt0 = (double)(float)p[SENSORTYPE];
+  double c6 = 1. / 6.;
+  c->c4 = 5. * c6; c->c5 = 2. * c6; c->c6 = -1. * c6;
+  c->cvisq = 1. / 3;
+  c->nd = p[NDIMDX];
+  c->inc[0] = 1; c->inc[1] = p[NIJK]; c->inc[2] = (long)p[NIJK] * p[NIJK + 1];
+}
+
+/* Flux balance over the range ind (one cache block, no neighbouring thread): order of the
+ * face loops and of the += / -= pairs as Fast/FastS/FastS/Compute/template_FluxAndBalance.for:192-271,
+ * assemble_drodm_plus_vec1.for, flu_send_scater_vec1.for */
+void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, double *drodm,
+             const double *wig, const double *xmut, const double *ti, const double *tj,
+             const double *tk, const double *vol)
+{
+  GEOM(p)
+  fluxctx c;
+  fluxctx_init(&c, p, pr, ti, tj, tk, vol);
+  double f[5];
+  for (int k = ind[4]; k <= ind[5]; k++) {
+    for (int j = ind[2]; j <= ind[3]; j++) {
+      for (int dir = 2; dir >= 0; dir--)
+        for (int i = ind[0]; i <= ind[1]; i++) {
+          long l = INDDM(i, j, k), l0 = l - c.inc[dir];
+          face_flux(&c, rop, wig, xmut, l, dir, f);
+          for (int e = 0; e < 5; e++) {
+            drodm[l + e * nd] = drodm[l + e * nd] + f[e];
+            drodm[l0 + e * nd] = drodm[l0 + e * nd] - f[e];
+          }
+        }
+      {
+        long l = INDDM(ind[1] + 1, j, k), ls = l - 1;
+        face_flux(&c, rop, wig, xmut, l, 0, f);
+        for (int e = 0; e < 5; e++) {
+          drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
+          drodm[l + e * nd] = drodm[l + e * nd] + f[e];
+        }
+      }
+    }
+    for (int i = ind[0]; i <= ind[1]; i++) {
+      long l = INDDM(i, ind[3] + 1, k), ls = l - c.inc[1];
+      face_flux(&c, rop, wig, xmut, l, 1, f);
+      for (int e = 0; e < 5; e++) {
+        drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
+        drodm[l + e * nd] = drodm[l + e * nd] + f[e];
+      }
+    }
+  }
+  for (int j = ind[2]; j <= ind[3]; j++)
+    for (int i = ind[0]; i <= ind[1]; i++) {
+      long l = INDDM(i, j, ind[5] + 1), ls = l - c.inc[2];
+      face_flux(&c, rop, wig, xmut, l, 2, f);
+      for (int e = 0; e < 5; e++) {
+        drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
+        drodm[l + e * nd] = drodm[l + e * nd] + f[e];
+      }
+    }
+}
+
+/* Runge-Kutta stage update in conservative form, back to (rho,u,v,w,T)
+ * (Fast/FastS/FastS/Compute/core3ark3.for:21-24,70-80,108-154) */
+void fo_core3ark3(const i32 *p, const double *pr, int nitcfg, const i32 *ind, double *rop_1,
+                  const double *rop, const double *drodm, const double *coe)
+{
+  GEOM(p)
+  const double cv = pr[CVINF], cvinv = 1. / cv, cvinv2 = 0.5 * cvinv;
+  double coefW = 1.;
+  int b = p[RK];
+  if (b == 2) coefW = nitcfg == 1 ? 1. : 0.5;
+  else if (b == 3) coefW = nitcfg == 1 ? 0.5 : (nitcfg == 2 ? 0.9106836025229591 : 0.3660254037844387);
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        long l = INDDM(i, j, k);
+        double r_1 = coefW * coe[l];
+        double tab1 = drodm[l] * r_1, tab2 = drodm[l + nd] * r_1, tab3 = drodm[l + 2 * nd] * r_1;
+        double tab4 = drodm[l + 3 * nd] * r_1, tab5 = drodm[l + 4 * nd] * r_1;
+        double ro_old = rop[l], u_old = rop[l + nd], v_old = rop[l + 2 * nd];
+        double w_old = rop[l + 3 * nd], t_old = rop[l + 4 * nd];
+        double ro_new = rop[l] + tab1;
+        rop_1[l] = ro_new;
+        r_1 = 1. / ro_new;
+        double un = (ro_old * u_old + tab2) * r_1;
+        double vn = (ro_old * v_old + tab3) * r_1;
+        double wn = (ro_old * w_old + tab4) * r_1;
+        rop_1[l + nd] = un; rop_1[l + 2 * nd] = vn; rop_1[l + 3 * nd] = wn;
+        double roe_old = ro_old * (cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+        rop_1[l + 4 * nd] = (roe_old + tab5) * r_1 * cvinv - cvinv2 * (un * un + vn * vn + wn * wn);
+      }
+}
+
+/* Ghost range of a BC window, no corner overflow (npass = 0)
+ * (Fast/FastC/FastC/BC/indice_cl_sdm.for:46-99).  Returns 1 when the window is skipped. */
+int fo_indice_cl(int idir, const i32 *p, const i32 *fen, const i32 *sdm, i32 *cl)
+{
+  const int ific = p[NIJK + 3], ifick = p[NIJK + 4];
+  if (!(sdm[0] <= fen[1] && sdm[1] >= fen[0] && sdm[2] <= fen[3] && sdm[3] >= fen[2] &&
+        sdm[4] <= fen[5] && sdm[5] >= fen[4]))
+    return 1;
+  for (int d = 0; d < 3; d++) {
+    cl[2 * d] = fen[2 * d] > sdm[2 * d] ? fen[2 * d] : sdm[2 * d];
+    cl[2 * d + 1] = fen[2 * d + 1] < sdm[2 * d + 1] ? fen[2 * d + 1] : sdm[2 * d + 1];
+  }
+  switch (idir) {
+    case 1: cl[1] = cl[0] - 1; cl[0] = cl[0] - ific; break;
+    case 2: cl[1] = cl[0] + ific; cl[0] = cl[0] + 1; break;
+    case 3: cl[3] = cl[2] - 1; cl[2] = cl[2] - ific; break;
+    case 4: cl[3] = cl[2] + ific; cl[2] = cl[2] + 1; break;
+    case 5: cl[5] = cl[4] - 1; cl[4] = cl[4] - ifick; break;
+    default: cl[5] = cl[4] + ifick; cl[4] = cl[4] + 1; break;
+  }
+  return 0;
+}
+
+/* BCautoperiod: ghost = value one period inside
+ * (Fast/FastS/FastS/BC/bvbs_periodique.for:150-171, BCPeriodic_i.for, BCPeriodic.for) */
+void fo_bc_periodic(const i32 *p, int idir, const i32 *cl, double *rop)
+{
+  GEOM(p)
+  long incp;
+  switch (idir) {
+    case 1: incp = p[IJKV]; break;
+    case 2: incp = -(long)p[IJKV]; break;
+    case 3: incp = (long)p[IJKV + 1] * ni; break;
+    case 4: incp = -(long)p[IJKV + 1] * ni; break;
+    case 5: incp = (long)p[IJKV + 2] * ninj; break;
+    default: incp = -(long)p[IJKV + 2] * ninj; break;
+  }
+  for (int k = cl[4]; k <= cl[5]; k++)
+    for (int j = cl[2]; j <= cl[3]; j++)
+      for (int i = cl[0]; i <= cl[1]; i++) {
+        long l = INDDM(i, j, k);
+        for (int e = 0; e < 5; e++) rop[l + e * nd] = rop[l + incp + e * nd];
+      }
+}
+
+/* Edge ghosts = mean of the two neighbouring face ghosts, corner ghosts = mean of three
+ * (Fast/FastS/FastS/BC/correct_coins.for:23-420), whole zone range. */
+void fo_correct_coins(const i32 *p, double *rop)
+{
+  GEOM(p)
+  const int iv = p[IJKV], jv = p[IJKV + 1], kv = p[IJKV + 2];
+  const int neq = p[NEQ];
+  const int ends[3][2] = {{1, iv}, {1, jv}, {1, kv}};
+#define MIN2(a, b) ((a) < (b) ? (a) : (b))
+  for (int idir = 0; idir < 2; idir++) { /* faces imin, imax */
+    int is = idir == 0 ? -1 : 1, i0 = ends[0][idir];
+    for (int jd = 0; jd < 2; jd++) { /* bands jmin, jmax */
+      int js = jd == 0 ? -1 : 1, j0 = ends[1][jd];
+      for (int ne = 0; ne < neq; ne++)
+        for (int k = 1; k <= kv; k++)
+          for (int j = 1; j <= ific; j++)
+            for (int i = 1; i <= ific; i++) {
+              int i1 = MIN2(ific, i + 1), j1 = MIN2(ific, j + 1);
+              long l1 = INDDM(i0 + i * is, j0 + j * js, k);
+              long l11 = INDDM(i0 + i1 * is, j0, k);
+              long l12 = INDDM(i0, j0 + j1 * js, k);
+              rop[l1 + ne * nd] = (rop[l11 + ne * nd] + rop[l12 + ne * nd]) * 0.5;
+            }
+    }
+    for (int kd = 0; kd < 2; kd++) { /* bands kmin, kmax */
+      int ks = kd == 0 ? -1 : 1, k0 = ends[2][kd];
+      for (int ne = 0; ne < neq; ne++)
+        for (int k = 1; k <= ifick; k++)
+          for (int j = 1; j <= jv; j++)
+            for (int i = 1; i <= ific; i++) {
+              int k1 = MIN2(ifick, k + 1), i1 = MIN2(ific, i + 1);
+              long l1 = INDDM(i0 + i * is, j, k0 + k * ks);
+              long l11 = INDDM(i0, j, k0 + k1 * ks);
+              long l12 = INDDM(i0 + i1 * is, j, k0);
+              rop[l1 + ne * nd] = (rop[l11 + ne * nd] + rop[l12 + ne * nd]) * 0.5;
+            }
+    }
+  }
+  for (int jdir = 0; jdir < 2; jdir++) { /* faces jmin, jmax: bands kmin, kmax */
+    int js = jdir == 0 ? -1 : 1, j0 = ends[1][jdir];
+    for (int kd = 0; kd < 2; kd++) {
+      int ks = kd == 0 ? -1 : 1, k0 = ends[2][kd];
+      for (int ne = 0; ne < neq; ne++)
+        for (int k = 1; k <= ifick; k++)
+          for (int j = 1; j <= ific; j++)
+            for (int i = 1; i <= iv; i++) {
+              int k1 = MIN2(ifick, k + 1), j1 = MIN2(ific, j + 1);
+              long l1 = INDDM(i, j0 + j * js, k0 + k * ks);
+              long l11 = INDDM(i, j0, k0 + k1 * ks);
+              long l12 = INDDM(i, j0 + j1 * js, k0);
+              rop[l1 + ne * nd] = (rop[l11 + ne * nd] + rop[l12 + ne * nd]) * 0.5;
+            }
+    }
+  }
+  const double c3 = 1. / 3.;
+  for (int kd = 0; kd < 2; kd++)
+    for (int jd = 0; jd < 2; jd++)
+      for (int id = 0; id < 2; id++) {
+        int is = id == 0 ? -1 : 1, js = jd == 0 ? -1 : 1, ks = kd == 0 ? -1 : 1;
+        int i0 = ends[0][id], j0 = ends[1][jd], k0 = ends[2][kd];
+        for (int ne = 0; ne < neq; ne++)
+          for (int k = 1; k <= ifick; k++)
+            for (int j = 1; j <= ific; j++)
+              for (int i = 1; i <= ific; i++) {
+                int i1 = MIN2(ific, i + 1), j1 = MIN2(ific, j + 1), k1 = MIN2(ifick, k + 1);
+                long l = INDDM(i0 + i * is, j0 + j * js, k0 + k * ks);
+                long l11 = INDDM(i0, j0, k0 + k1 * ks);
+                long l12 = INDDM(i0 + i1 * is, j0, k0);
+                long l13 = INDDM(i0, j0 + j1 * js, k0);
+                rop[l + ne * nd] = (rop[l11 + ne * nd] + rop[l12 + ne * nd] + rop[l13 + ne * nd]) * c3;
+              }
+      }
+}
+
+/* BC dispatch over the table stored from Parameter_int[PT_BC]
+ * (Fast/FastS/FastS/BC/BCzone.cpp:193-226,560-568; table layout
+ * Fast/FastC/FastC/PyTree.py:2958-3014), then the edge/corner fix
+ * (Fast/FastS/FastS/Compute/bcs.cpp:30-41). Returns -1 on an unsupported BC tag. */
+int fo_bczone(const i32 *p, double *rop)
+{
+  const int pt_bcs = p[PT_BC], nb = p[pt_bcs];
+  i32 sdm[6] = {1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2]}, cl[6];
+  for (int ndf = 0; ndf < nb; ndf++) {
+    int pt = p[pt_bcs + 1 + ndf], type = p[pt], idir = p[pt + 1];
+    if (fo_indice_cl(idir, p, p + pt + 2, sdm, cl)) continue;
+    if (type == 11) fo_bc_periodic(p, idir, cl, rop);
+    else if (type == 22) continue;
+    else return -1;
+  }
+  fo_correct_coins(p, rop);
+  return 0;
+}
+
+/* One sub-iteration of one zone with a single cache block and no neighbouring thread:
+ * ranges of Fast/FastC/FastC/HPC_LAYER/indice_boucle_ssdom.for:108-168 (first block = last
+ * block), sequence of Fast/FastS/FastS/Compute/navier_stokes_struct.for:199-275,295-301,
+ * 310-345,467-475 and src_term.for:59-70,258-272.  rop_in is the stage input, rop_out the
+ * stage output. */
+void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in, double *rop_out,
+                double *drodm, double *coe, double *xmut, double *wig, const double *ti,
+                const double *tj, const double *tk, const double *vol)
+{
+  const int iv = p[IJKV], jv = p[IJKV + 1], kv = p[IJKV + 2];
+  const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
+  const i32 grad[6] = {0, iv + 1, 0, jv + 1, 0, kv + 1};
+  if (nitcfg == 1) {
+    if (p[IFLOW] == 2) fo_invist(p, pr, grad, rop_in, xmut);
+    double volinv = pr[DTC] / vol[0]; /* Fast/FastS/FastS/Compute/tstb3_global.for:72-78 */
+    GEOM(p)
+    for (int k = 1; k <= kv; k++)
+      for (int j = 1; j <= jv; j++)
+        for (int i = 1; i <= iv; i++) coe[INDDM(i, j, k)] = volinv;
+  }
+  fo_init_rhs(p, nitcfg, sdm, drodm);
+  if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_in, wig);
+  fo_flux(p, pr, sdm, rop_in, drodm, wig, xmut, ti, tj, tk, vol);
+  fo_core3ark3(p, pr, nitcfg, sdm, rop_out, rop_in, drodm, coe);
+}
+
+/* One explicit time step of one stand-alone zone (all BCs local): sub-iterations with the
+ * array roles of Fast/FastS/FastS/Compute/gsdr3.cpp:137-145, BCs on the stage output.
+ * On return ro_p1 holds t^{n+1}; the caller rotates the levels
+ * (Fast/FastS/FastS/Compute/computePT.cpp:673-677).  stage1_rhs (may be NULL) receives a copy
+ * of drodm after the first stage. */
+int fo_step(const i32 *p, const double *pr, double *ro, double *ro_p1, double *drodm, double *coe,
+            double *xmut, double *wig, const double *ti, const double *tj, const double *tk,
+            const double *vol, double *stage1_rhs)
+{
+  const int nssiter = p[NSSITER];
+  for (int nstep = 1; nstep <= nssiter; nstep++) {
+    double *in = (nstep % 2 == 1) ? ro : ro_p1;
+    double *out = (nstep % 2 == 1) ? ro_p1 : ro;
+    fo_subiter(p, pr, nstep, in, out, drodm, coe, xmut, wig, ti, tj, tk, vol);
+    if (nstep == 1 && stage1_rhs) memcpy(stage1_rhs, drodm, sizeof(double) * 5 * (size_t)p[NDIMDX]);
+    if (fo_bczone(p, out)) return -1;
+  }
+  return 0;
+}
+
+/* sum of squares and max abs of coe*drodm over interior cells, per equation
+ * (accumulation order of Fast/FastS/FastS/Compute/cprdu3s1_incl.for:47-71) */
+void fo_residual(const i32 *p, const double *drodm, const double *coe, double *sumsq, double *maxabs)
+{
+  GEOM(p)
+  for (int e = 0; e < 5; e++) { sumsq[e] = 0.; maxabs[e] = 0.; }
+  for (int k = 1; k <= p[IJKV + 2]; k++)
+    for (int j = 1; j <= p[IJKV + 1]; j++)
+      for (int i = 1; i <= p[IJKV]; i++) {
+        long l = INDDM(i, j, k);
+        for (int e = 0; e < 5; e++) {
+          double r = coe[l] * drodm[l + e * nd];
+          double xp = fabs(r);
+          if (xp > maxabs[e]) maxabs[e] = xp;
+          sumsq[e] = sumsq[e] + r * r;
+        }
+      }
+}

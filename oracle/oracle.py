@@ -1,0 +1,79 @@
+"""ctypes wrapper of the CPU restatement (oracle/fasts_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg as the checker; never imported by fast_amd/.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfasts_oracle.so")
+_lib = None
+
+NIJK = 0; IJKV = 20; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NDIMDX = 41; NDIMDX_MTR = 43
+NSSITER = 58; DTC = 0
+
+
+def build():
+    src = os.path.join(HERE, "fasts_oracle.c")
+    if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "libfasts_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.fo_step.restype = ctypes.c_int
+        _lib.fo_bczone.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleZone:
+    """One stand-alone zone (all boundaries local) advanced by the C restatement."""
+
+    def __init__(self, param_int, param_real, ro, mtr):
+        self.pint = np.ascontiguousarray(param_int, dtype=np.int32).copy()
+        self.preal = np.ascontiguousarray(param_real, dtype=np.float64).copy()
+        p = self.pint
+        self.neq = int(p[NEQ]); self.ndimdx = int(p[NDIMDX])
+        n = self.neq * self.ndimdx
+        self.ro = np.ascontiguousarray(ro, dtype=np.float64).reshape(-1).copy()
+        self.ro_m1 = self.ro.copy(); self.ro_p1 = self.ro.copy()
+        self.mtr = np.ascontiguousarray(mtr, dtype=np.float64).copy()
+        nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
+        self.ti = self.mtr[0:nm * nij]; self.tj = self.mtr[nm * nij:2 * nm * nij]
+        self.tk = self.mtr[2 * nm * nij:2 * nm * nij + nm * nk]
+        self.vol = self.mtr[2 * nm * nij + nm * nk:]
+        self.drodm = np.zeros(n); self.coe = np.zeros(self.ndimdx)
+        self.xmut = np.zeros(self.ndimdx); self.wig = np.zeros(3 * self.ndimdx)
+        self.stage1_rhs = np.zeros(n)
+
+    def fill_ghostcells(self):
+        if lib().fo_bczone(_p(self.pint), _p(self.ro)) != 0:
+            raise NotImplementedError("oracle: unsupported BC tag")
+
+    def step(self):
+        rc = lib().fo_step(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ro_p1), _p(self.drodm),
+                           _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj),
+                           _p(self.tk), _p(self.vol), _p(self.stage1_rhs))
+        if rc != 0:
+            raise NotImplementedError("oracle: unsupported BC tag")
+        if int(self.pint[NSSITER]) % 2 == 1:
+            self.ro_m1, self.ro, self.ro_p1 = self.ro, self.ro_p1, self.ro_m1
+
+    def residuals(self):
+        s = np.zeros(5); m = np.zeros(5)
+        lib().fo_residual(_p(self.pint), _p(self.stage1_rhs), _p(self.coe), _p(s), _p(m))
+        p = self.pint
+        n = int(p[IJKV]) * int(p[IJKV + 1]) * int(p[IJKV + 2])
+        dt = self.preal[DTC]
+        return np.sqrt(s / n) / dt, m / dt

@@ -245,8 +245,9 @@ class RefSolver:
             for nd, zn in enumerate(self.zones):
                 self._bczone(nd, zn, nstep, cl[nd])
         self.first_it = 1
-        for zn in self.zones:
-            zn.ro_m1, zn.ro, zn.ro_p1 = zn.ro, zn.ro_p1, zn.ro_m1
+        if nssiter % 2 == 1:   # Fast/FastS/FastS/PyTree.py:233 (order = nitmax%2+2)
+            for zn in self.zones:
+                zn.ro_m1, zn.ro, zn.ro_p1 = zn.ro, zn.ro_p1, zn.ro_m1
 
     def residuals(self):
         """Per zone, per equation: sqrt(sum (coe*drodm)^2 / ncell)/dt and max|coe*drodm|/dt of

@@ -1,0 +1,44 @@
+"""Shared helpers of the test-suite: build a case, prepare its solver state, wrap the oracle."""
+import numpy as np
+from fast_amd import cases, FastC, Internal
+
+
+def prepare(t):
+    """Host-side preparation without touching the GPU (what warmup does before creating the
+    device context)."""
+    FastC._buildOwnData(t, None)
+    FastC._build_omp(t)
+    dtloc = Internal.getNodeFromName2(t, '.Solver#dtloc')[1]
+    zones = Internal.getZones(t)
+    metrics = [FastC.allocate_metric_zone(z, int(dtloc[0])) for z in zones]
+    FastC._BCcompact(t)
+    FastC.fill_task_records(dtloc, zones)
+    FastC._createPrimVars(t)
+    return metrics
+
+
+def zone_arrays(z):
+    pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
+    preal = Internal.getNodeFromName2(z, 'Parameter_real')[1]
+    g = Internal.getNodeFromName1(z, 'GridCoordinates')
+    xyz = [Internal.getNodeFromName1(g, c)[1] for c in ('CoordinateX', 'CoordinateY', 'CoordinateZ')]
+    return pint, preal, xyz
+
+
+def make_case(kind, n, scheme, model=None, single_block=True, **kw):
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000} \
+        if single_block else None
+    if kind == 'tgv':
+        return cases.tgv(n, scheme, model=model or 'NSLaminar', extra_numz=extra, **kw)
+    return cases.vortex(n, scheme, extra_numz=extra, **kw)
+
+
+def rel_err(a, b, ndimdx, neq=5):
+    """max |a-b| per variable, scaled by the variable's magnitude (velocities share one scale)."""
+    a = a.reshape(neq, -1)[:, :ndimdx]; b = b.reshape(neq, -1)[:, :ndimdx]
+    d = np.abs(a - b).max(axis=1)
+    s = np.abs(b).max(axis=1)
+    vs = s[1:4].max()
+    s[1:4] = vs if vs > 0 else 1.
+    s[s == 0] = 1.
+    return d / s
