@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mcell-iter/s of the fp64 RK3 Taylor-Green step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (N = 1): Taylor-Green vortex Re = 1600, M = 0.1, one Cartesian block of 256^3 cells
+(+2 ghost layers), NSLaminar, scheme 'senseur' (the scheme of Fast/FastS/test/tgvMpi.py:272),
+explicit RK3, 6 x BCautoperiod, synthetic deterministic initial field.  One step = one full
+time step = 3 sub-iterations (flux balance + RK update + ghost fill each).  Fields are
+resident in HBM before the timed region; nothing is copied to the host inside it.
+N > 1: weak scaling, one 256^3 block per GPU of a (bx,by,bz)-split periodic box, match joins
+exchanged with RCCL send/recv (torch.distributed) between the ranks.
+
+Prints ONE JSON line (rank 0) with the whole-job throughput, the roofline of the dominant
+kernel (RK-stage kernel; HIP events on the launch stream) and a CPU baseline measured on a
+bounded sample with the compiled reference (or, when absent, the C restatement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec)
+BYTES_PER_CELL_STEP = {'senseur': 472.0, 'ausmpred': 400.0, 'roe': 400.0}
+
+
+def split_for(n):
+    return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n)
+
+
+def cpu_baseline(scheme, budget_s=12.0):
+    """Reference FastS (compiled Fortran, one thread) on a bounded sample of the same workload:
+    the same TGV case at 96^3, as many steps as fit the budget (at least 2)."""
+    from fast_amd import cases, FastC, Internal
+    from oracle import ref_harness as R
+    n = 96
+    t = cases.tgv(n, scheme)
+    FastC._buildOwnData(t, None); FastC._build_omp(t)
+    dtloc = Internal.getNodeFromName2(t, '.Solver#dtloc')[1]
+    z = Internal.getZones(t)[0]
+    metrics = FastC.allocate_metric_zone(z, int(dtloc[0]))
+    FastC._BCcompact(t); FastC._createPrimVars(t)
+    pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
+    preal = Internal.getNodeFromName2(z, 'Parameter_real')[1]
+    ro = FastC.level_buffer(z)
+    if R.available():
+        g = Internal.getNodeFromName1(z, 'GridCoordinates')
+        xyz = [Internal.getNodeFromName1(g, c)[1] for c in ('CoordinateX', 'CoordinateY', 'CoordinateZ')]
+        zn = R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], ro, metrics[0])
+        s = R.RefSolver([zn]); s.fill_ghostcells('ro')
+        step = lambda it: s.step(it)
+        kind = 'reference'
+    else:
+        from oracle import oracle as O
+        oz = O.OracleZone(pint, preal, ro, metrics[0]); oz.fill_ghostcells()
+        step = lambda it: oz.step()
+        kind = 'port'
+    step(1)
+    t0 = time.time(); it = 0
+    while True:
+        it += 1
+        step(it + 1)
+        el = time.time() - t0
+        if (el > budget_s and it >= 2) or it >= 50:
+            break
+    return {"value": n ** 3 * it / el / 1e6, "unit": "Mcell-iter/s", "cores": 1, "kind": kind,
+            "sample": "TGV %d^3 %s RK3, %d steps, one thread, default cache blocking" % (n, scheme, it)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--n', type=int, default=256, help='cells per direction per GPU block')
+    ap.add_argument('--scheme', default='senseur', choices=['senseur', 'ausmpred', 'roe'])
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus != world and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+
+    os.environ['FASTS_HIP_LAZY_SYNC'] = '1'
+    import torch
+    from fast_amd import cases, FastC, Internal
+    import fast_amd.PyTree as FastS
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    model = 'Euler' if a.scheme == 'roe' else 'NSLaminar'
+
+    if world == 1:
+        t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n)
+        (t, tc, metrics) = FastS.warmup(t, None, device=local_rank)
+        ctx = FastC.HOOK['ctx']
+        run_step = lambda it: ctx.compute(it, 1, 3, 1)
+        ncell_total = a.n ** 3
+    else:
+        import fast_amd.Mpi as FastSmpi
+        blocks = split_for(world)
+        if blocks is None:
+            raise SystemExit("bench.py: --gpus must be 1, 2, 4 or 8")
+        job = FastSmpi.tgv_job(a.n, blocks, a.scheme, model, rank, world, local_rank)
+        ctx = job.ctx
+        run_step = job.step
+        ncell_total = a.n ** 3 * world
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for it in range(1, a.warmup + 1):
+        run_step(it)
+    ctx.stage_kernel_ms(reset=True)      # start HIP-event timing of the stage kernel
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(a.warmup + 1, a.warmup + a.steps + 1):
+        run_step(it)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    k_ms, k_n = ctx.stage_kernel_ms(reset=False)
+
+    # sanity: the field must still be finite
+    ctx.download(1)
+    z0 = Internal.getZones(t)[0] if world == 1 else job.zone
+    if not np.isfinite(FastC.level_buffer(z0)).all():
+        raise SystemExit("bench.py: non-finite field after the run")
+
+    if rank == 0:
+        bpl = BYTES_PER_CELL_STEP[a.scheme] / 3.0 * a.n ** 3     # algorithmic bytes per launch
+        ach = bpl / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.
+        out = {
+            "metric": "Mcell-iter/s (fp64 RK3 TGV 256^3)",
+            "value": ncell_total * a.steps / el / 1e6,
+            "unit": "Mcell-iter/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "TGV Re=1600 M=0.1, %d^3 cells per GPU, NSLaminar, scheme=%s, RK3, periodic"
+                                   % (a.n, a.scheme) if model != 'Euler' else
+                                   "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
+                       "blocks": list(split_for(world) or (1, 1, 1)), "ghost_layers": 2},
+            "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n},
+        }
+        if not a.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.scheme)
+            except Exception as e:   # the baseline is informative; never lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Mcell-iter/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %s" % e}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -49,7 +49,9 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
     """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
     whole box; blocks = (bi,bj,bk) split.  Returns t."""
     L1 = 2. * math.pi
-    nb = [n // blocks[d] for d in range(3)]
+    nn = (n, n, n) if isinstance(n, int) else tuple(n)
+    nb = [nn[d] // blocks[d] for d in range(3)]
+    n = max(nn)
     zones = []
     for kb in range(blocks[2]):
         for jb in range(blocks[1]):

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +52,7 @@ struct fs_ctx {
   std::vector<Join> joins;
   std::vector<Send> sends;
   bool uploaded = false;
+  bool plain_stage = false;   // FASTS_HIP_STAGE=plain: untiled stage kernel (debugging aid)
   int modulo_verif = 200;
   std::string err;
   // stage-kernel timing
@@ -104,6 +106,8 @@ extern "C" int fs_create(fs_ctx **out, int device)
     return FS_ERR_HIP;
   }
   c->stream = c->own_stream;
+  const char *ev = getenv("FASTS_HIP_STAGE");
+  c->plain_stage = ev && strcmp(ev, "plain") == 0;
   *out = c;
   return FS_OK;
 }
@@ -395,7 +399,7 @@ extern "C" int fs_stage(fs_ctx *ctx, int nitrun, int nstep)
     rk_coefs(z.rk, nstep, coefH, coefW);
     if (nstep == 1) {
       if (z.iflow == 2) fsk_invist(z, zn.dev[in], zn.xmut, ctx->stream);
-      if (z.kflu == 2) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
+      if (z.kflu == 2 && ctx->plain_stage) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
@@ -409,7 +413,10 @@ extern "C" int fs_stage(fs_ctx *ctx, int nitrun, int nstep)
       ctx->ev_used++;
       HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     }
-    if (fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream))
+    const int krc = ctx->plain_stage
+        ? fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream)
+        : fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
+    if (krc)
       return fail(ctx, FS_ERR_UNSUPPORTED, "fs_stage: no kernel for this scheme / model");
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     if (nstep == 1 && (nitrun % ctx->modulo_verif == 0 || nitrun == 1)) {

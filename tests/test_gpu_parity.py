@@ -16,6 +16,9 @@ CASES = [
     ('tgv', 12, 'ausmpred', 'Euler', 6),
     ('tgv', 12, 'roe', 'NSLaminar', 6),
     ('vortex', 16, 'roe', None, 12),
+    ('tgv', (72, 10, 37), 'senseur', 'NSLaminar', 4),     # several i-tiles, ragged j and k chunks
+    ('tgv', (130, 9, 6), 'ausmpred', 'NSLaminar', 3),
+    ('tgv', (64, 8, 33), 'senseur', 'NSLaminar', 3),      # tile edge passes on the zone boundary
 ]
 
 
