@@ -97,8 +97,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # one rank per GPU over RCCL; FASTS_DIST_BACKEND=gloo (messages staged through the host)
+        # lets several ranks share one GPU for rehearsals on a single-GPU machine
+        backend = os.environ.get('FASTS_DIST_BACKEND', 'nccl')
+        if backend != 'nccl':
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     model = 'Euler' if a.scheme == 'roe' else 'NSLaminar'
 
     if world == 1:
@@ -134,7 +142,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([el], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     k_ms, k_n = ctx.stage_kernel_ms(reset=False)

@@ -181,9 +181,9 @@ def _buildOwnData(t, Padding=None):
         temps = float(Internal.getValue(first))
 
     o = Internal.createUniqueChild(t, '.Solver#ownData', 'UserDefinedData_t')
-    if MX_OMP_SIZE_INT == -1:
-        ntask = len(zones) * 2
-        size_task = (6 + 7 * OMP_NUM_THREADS) * ntask
+    ntask = len(zones) * 2
+    size_task = (6 + 7 * OMP_NUM_THREADS) * ntask
+    if MX_OMP_SIZE_INT < 1 + nssiter * (2 + size_task):   # grows with the tree at hand
         MX_OMP_SIZE_INT = 1 + nssiter * (2 + size_task)
     size_omp = MX_OMP_SIZE_INT
     dtdim = 12 + 1

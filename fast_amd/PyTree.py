@@ -70,12 +70,8 @@ def joins_from_tc(t, tc):
     return out
 
 
-def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_graph=None, Padding=None,
-           verbose=0, device=0):
-    """Perform necessary operations for the solver to run (same signature as the reference plus
-    the HIP device index)."""
-    if infos_ale is not None or Adjoint or tmy is not None:
-        raise ValueError("fast_amd.warmup: ALE, adjoint and running statistics are not supported")
+def _warmup_host(t, tc, Padding=None):
+    """Host part of warmup: solver data, metrics, BC table, three compacted time levels."""
     FastC._reorder(t, tc)
     FastC._buildOwnData(t, Padding)
     own = Internal.getNodeFromName1(t, '.Solver#ownData')
@@ -86,7 +82,11 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     FastC._BCcompact(t)
     FastC.fill_task_records(dtloc, zones)
     FastC.FIRST_IT = FastC._createPrimVars(t)
+    return zones, metrics, dtloc
 
+
+def _new_context(zones, metrics, dtloc, device):
+    """Device context with every zone of t registered; returns (ctx, {zone name: index})."""
     if FastC.HOOK is not None and FastC.HOOK.get('ctx') is not None:
         FastC.HOOK['ctx'].close()
     ctx = _capi.Context(device)
@@ -99,15 +99,32 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
         ctx.zone_add(pint, preal, FastC.level_buffer(z, ''), FastC.level_buffer(z, '_M1'),
                      FastC.level_buffer(z, '_P1'), m[0])
         names[z[0]] = nd
-    for (rn, dn, rpts, dpts) in joins_from_tc(t, tc):
-        if rn not in names or dn not in names:
-            raise ValueError("warmup: join %s <- %s refers to a zone that is not in t" % (rn, dn))
-        ctx.join_add(names[rn], names[dn], rpts, dpts)
-    ctx.upload()
+    return ctx, names
+
+
+def _set_hook(ctx, dtloc, names, mpi=0):
     FastC.HOOK = {'ctx': ctx, 'dtloc': dtloc, 'FIRST_IT': FastC.FIRST_IT, 'param_int_tc': None,
-                  'param_real_tc': None, 'mpi': 0, 'zone_index': names,
+                  'param_real_tc': None, 'mpi': mpi, 'zone_index': names,
                   'MX_SSZONE': FastC.MX_SSZONE, 'MX_SYNCHRO': FastC.MX_SYNCHRO,
                   'MX_OMP_SIZE_INT': FastC.MX_OMP_SIZE_INT, 'lssiter_loc': 0, 'neq_max': 5}
+    return FastC.HOOK
+
+
+def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_graph=None, Padding=None,
+           verbose=0, device=0):
+    """Perform necessary operations for the solver to run (same signature as the reference plus
+    the HIP device index)."""
+    if infos_ale is not None or Adjoint or tmy is not None:
+        raise ValueError("fast_amd.warmup: ALE, adjoint and running statistics are not supported")
+    zones, metrics, dtloc = _warmup_host(t, tc, Padding)
+    ctx, names = _new_context(zones, metrics, dtloc, device)
+    for (rn, dn, rpts, dpts) in joins_from_tc(t, tc):
+        if rn not in names or dn not in names:
+            raise ValueError("warmup: join %s <- %s refers to a zone that is not in t "
+                             "(zones on other ranks need fast_amd.Mpi.warmup)" % (rn, dn))
+        ctx.join_add(names[rn], names[dn], rpts, dpts)
+    ctx.upload()
+    _set_hook(ctx, dtloc, names)
     # ghost cells of the initial field: joins, BCs, edges (Fast/FastS/FastS/PyTree.py:520-527)
     ctx.fill_ghostcells(_capi.FS_LEVEL_N)
     ctx.download(_capi.FS_LEVEL_N)

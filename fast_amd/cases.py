@@ -45,9 +45,11 @@ def tgv_fields(t, state, L0=1.):
 
 
 def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
-        temporal_scheme='explicit', modulo_verif=50, extra_numz=None):
+        temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None):
     """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
-    whole box; blocks = (bi,bj,bk) split.  Returns t."""
+    whole box; blocks = (bi,bj,bk) split; only = block numbers to instantiate (the blocks of one
+    rank; block b = ib + jb*bi + kb*bi*bj is named 'cart<b>').  Split directions carry no BC:
+    their ghost cells are filled by match joins (fast_amd.connect).  Returns t."""
     L1 = 2. * math.pi
     nn = (n, n, n) if isinstance(n, int) else tuple(n)
     nb = [nn[d] // blocks[d] for d in range(3)]
@@ -59,7 +61,10 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
                 org = [-0.5 * L1 + ib * L1 / blocks[0], -0.5 * L1 + jb * L1 / blocks[1],
                        -0.5 * L1 + kb * L1 / blocks[2]]
                 ln = [L1 / blocks[0], L1 / blocks[1], L1 / blocks[2]]
-                name = 'cart%d' % (ib + jb * blocks[0] + kb * blocks[0] * blocks[1])
+                b = ib + jb * blocks[0] + kb * blocks[0] * blocks[1]
+                if only is not None and b not in only:
+                    continue
+                name = 'cart%d' % b
                 z = _box(nb, ln, org, name)
                 faces = []
                 if blocks[0] == 1: faces += ['imin', 'imax']

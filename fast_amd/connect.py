@@ -1,0 +1,144 @@
+"""Match-join ("raccord") tables between the blocks of a split periodic box.
+
+The reference's TGV script builds these tables by hand for a cubic block and a 1 x 2 x 2
+split (Fast/FastS/test/tgvMpi.py:80-195): for every face of a block that touches another
+block, the two ghost layers of the receiver take the values of the two interior layers of
+the donor next to the shared face.  Indices are 0-based, ghost-inclusive and linear
+(i + j*ni + k*ni*nj), and the tables live in the connectivity tree under the DONOR zone as a
+ZoneSubRegion_t 'ID_<receiver>' with PointList (donor cells) / PointListDonor (receiver cells),
+which is the storage K_FASTC::setInterpTransfers consumes
+(Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:440-935).
+
+Here the same tables are produced for any (bi,bj,bk) split and any block size; the loop nest
+order of the reference script is kept (i fastest inside a j-k sweep for i-faces, and so on) so
+that a 1 x 2 x 2 split of a cubic box gives the script's arrays element for element.
+"""
+import numpy
+from . import Internal
+
+FACES = ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')
+
+
+def face_points(face, nv, ghost=2):
+    """(receiver_pts, donor_pts) of one face of a block with nv = (iv,jv,kv) interior cells whose
+    neighbour across that face has the same interior size along the face normal.
+    Receiver cells are the ghost layers of `face`; donor cells are the interior layers of the
+    neighbour that coincide with them (tgvMpi.py:149-192)."""
+    iv, jv, kv = nv
+    ni = iv + 2 * ghost; nj = jv + 2 * ghost
+    ninj = ni * nj
+    d = FACES.index(face) // 2
+    hi = FACES.index(face) % 2
+    n = nv[d]
+    # interior-based index (1..n interior): ghost layers are -1,0 (min) and n+1,n+2 (max)
+    g = numpy.arange(-1, 1) if not hi else numpy.arange(n + 1, n + 3)
+    gd = g + n if not hi else g - n          # coinciding interior cells of the neighbour
+    ri = numpy.arange(1, iv + 1); rj = numpy.arange(1, jv + 1); rk = numpy.arange(1, kv + 1)
+
+    def lin(i, j, k):
+        return ((i + ghost - 1) + (j + ghost - 1) * ni + (k + ghost - 1) * ninj).astype(numpy.int32).ravel()
+
+    if d == 0:      # loops k, j, i(ghost)
+        K, J, I = numpy.meshgrid(rk, rj, g, indexing='ij')
+        _, _, Id = numpy.meshgrid(rk, rj, gd, indexing='ij')
+        return lin(I, J, K), lin(Id, J, K)
+    if d == 1:      # loops j(ghost), k, i
+        J, K, I = numpy.meshgrid(g, rk, ri, indexing='ij')
+        Jd, _, _ = numpy.meshgrid(gd, rk, ri, indexing='ij')
+        return lin(I, J, K), lin(I, Jd, K)
+    K, J, I = numpy.meshgrid(g, rj, ri, indexing='ij')   # loops k(ghost), j, i
+    Kd, _, _ = numpy.meshgrid(gd, rj, ri, indexing='ij')
+    return lin(I, J, K), lin(I, J, Kd)
+
+
+def block_index(pos, blocks):
+    return pos[0] + pos[1] * blocks[0] + pos[2] * blocks[0] * blocks[1]
+
+
+def block_pos(b, blocks):
+    i = b % blocks[0]
+    j = (b // blocks[0]) % blocks[1]
+    k = b // (blocks[0] * blocks[1])
+    return (i, j, k)
+
+
+def split_faces(blocks):
+    """Faces that are joins (the direction is split) rather than periodic BCs."""
+    out = []
+    for d in range(3):
+        if blocks[d] > 1:
+            out += [FACES[2 * d], FACES[2 * d + 1]]
+    return out
+
+
+def periodic_block_joins(blocks, nv):
+    """All joins of a periodic box split in blocks = (bi,bj,bk) equal blocks of nv interior
+    cells: list of (receiver_block, donor_block, receiver_pts, donor_pts), ordered by donor
+    block then face, the order in which a donor-side connectivity tree is walked."""
+    out = []
+    nb = blocks[0] * blocks[1] * blocks[2]
+    for bd in range(nb):
+        pos = block_pos(bd, blocks)
+        for face in split_faces(blocks):
+            d = FACES.index(face) // 2
+            hi = FACES.index(face) % 2
+            # `face` names the RECEIVER's face (the script's convention): its ghost layers there
+            # are filled by the block sitting across that face, so seen from the donor the
+            # receiver is the neighbour on the opposite side
+            npos = list(pos)
+            npos[d] = (pos[d] + (-1 if hi else 1)) % blocks[d]
+            br = block_index(npos, blocks)
+            rpts, dpts = face_points(face, nv)
+            out.append((br, bd, rpts, dpts))
+    return out
+
+
+def add_joins_to_tc(tc, joins, zone_names, local=None):
+    """Store joins in the connectivity tree the way the reference expects them
+    (tgvMpi.py:132-195): one ZoneSubRegion_t per (donor, receiver) pair, several faces
+    concatenated.  `local` restricts to donor zones present in tc."""
+    by_pair = {}
+    for (br, bd, rpts, dpts) in joins:
+        by_pair.setdefault((bd, br), []).append((rpts, dpts))
+    zones = {z[0]: z for z in Internal.getZones(tc)}
+    for (bd, br), lst in by_pair.items():
+        dn = zone_names[bd]; rn = zone_names[br]
+        if dn not in zones:
+            if local is None:
+                raise ValueError("add_joins_to_tc: donor zone %s is not in tc" % dn)
+            continue
+        z = zones[dn]
+        rp = numpy.concatenate([a for a, _ in lst]).astype(Internal.E_NpyInt)
+        dp = numpy.concatenate([b for _, b in lst]).astype(Internal.E_NpyInt)
+        sr = Internal.createUniqueChild(z, 'ID_' + rn, 'ZoneSubRegion_t', rn)
+        Internal.createUniqueChild(sr, 'ZoneRole', 'DataArray_t', 'Donor')
+        Internal.createUniqueChild(sr, 'GridLocation', 'GridLocation_t', 'CellCenter')
+        Internal.createUniqueChild(sr, 'InterpolantsDonor', 'DataArray_t', numpy.ones(rp.size))
+        Internal.createUniqueChild(sr, 'InterpolantsType', 'DataArray_t',
+                                   numpy.ones(rp.size, dtype=Internal.E_NpyInt))
+        Internal.createUniqueChild(sr, 'PointListDonor', 'DataArray_t', rp)
+        Internal.createUniqueChild(sr, 'PointList', 'DataArray_t', dp)
+    return tc
+
+
+def graph_of(blocks, zone_names, owner):
+    """The 'graph' dictionary the reference's Mpi entry points take (tgvMpi.py:198-256):
+    graphID[rank] = {peer_rank: [zone names on the peer that receive from rank]}, procDict[zone]
+    = owning rank."""
+    nb = len(zone_names)
+    procDict = {zone_names[b]: owner[b] for b in range(nb)}
+    nranks = max(owner) + 1
+    graphID = {r: {} for r in range(nranks)}
+    for bd in range(nb):
+        pos = block_pos(bd, blocks)
+        for face in split_faces(blocks):
+            d = FACES.index(face) // 2
+            hi = FACES.index(face) % 2
+            npos = list(pos); npos[d] = (pos[d] + (-1 if hi else 1)) % blocks[d]
+            br = block_index(npos, blocks)
+            if owner[br] != owner[bd]:
+                lst = graphID[owner[bd]].setdefault(owner[br], [])
+                if zone_names[br] not in lst:
+                    lst.append(zone_names[br])
+    procList = [[zone_names[b] for b in range(nb) if owner[b] == r] for r in range(nranks)]
+    return {'graphID': graphID, 'graphIBCD': {}, 'procDict': procDict, 'procList': procList}

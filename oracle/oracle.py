@@ -77,3 +77,58 @@ class OracleZone:
         n = int(p[IJKV]) * int(p[IJKV + 1]) * int(p[IJKV + 2])
         dt = self.preal[DTC]
         return np.sqrt(s / n) / dt, m / dt
+
+    # -- split form of a time step, for multi-zone jobs -----------------------------------
+    def roles(self, nstep):
+        """(input, output) arrays of sub-iteration nstep (Fast/FastS/FastS/Compute/gsdr3.cpp:137-145)."""
+        return (self.ro, self.ro_p1) if nstep % 2 == 1 else (self.ro_p1, self.ro)
+
+    def stage(self, nstep):
+        rin, rout = self.roles(nstep)
+        lib().fo_subiter(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), _p(rin), _p(rout),
+                         _p(self.drodm), _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti),
+                         _p(self.tj), _p(self.tk), _p(self.vol))
+        if nstep == 1:
+            self.stage1_rhs[:] = self.drodm
+
+    def bcs(self, nstep):
+        if lib().fo_bczone(_p(self.pint), _p(self.roles(nstep)[1])) != 0:
+            raise NotImplementedError("oracle: unsupported BC tag")
+
+    def rotate(self):
+        if int(self.pint[NSSITER]) % 2 == 1:
+            self.ro_m1, self.ro, self.ro_p1 = self.ro, self.ro_p1, self.ro_m1
+
+
+class OracleSolver:
+    """Several zones coupled by match joins: per sub-iteration, every zone is advanced, then the
+    ghost cells of the joins are copied (receiver[rcv_pts] = donor[donor_pts] for every variable,
+    Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:440-935, 'direct' type), then BCs and the
+    edge/corner fix (order of Fast/FastS/FastS/Compute/gsdr3.cpp:251-269,343-349,403-422).
+    joins = [(rcv_zone_index, rcv_pts, donor_zone_index, donor_pts)]."""
+
+    def __init__(self, zones, joins=None):
+        self.zones = zones
+        self.joins = joins or []
+
+    def transfers(self, arrays):
+        for (zr, ridx, zd, didx) in self.joins:
+            nr = self.zones[zr].ndimdx; ndd = self.zones[zd].ndimdx
+            for v in range(self.zones[zr].neq):
+                arrays[zr][v * nr + ridx] = arrays[zd][v * ndd + didx]
+
+    def fill_ghostcells(self):
+        self.transfers([z.ro for z in self.zones])
+        for z in self.zones:
+            z.fill_ghostcells()
+
+    def step(self):
+        nssiter = int(self.zones[0].pint[NSSITER])
+        for nstep in range(1, nssiter + 1):
+            for z in self.zones:
+                z.stage(nstep)
+            self.transfers([z.roles(nstep)[1] for z in self.zones])
+            for z in self.zones:
+                z.bcs(nstep)
+        for z in self.zones:
+            z.rotate()

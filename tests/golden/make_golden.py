@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors of tests/golden/*.npz from the COMPILED REFERENCE
+(oracle/_ref/libfast_ref.so, built by oracle/build_ref.py from the Fortran sources where they
+lie in the reference tree) driven by oracle/ref_harness.py.
+
+    python tests/golden/make_golden.py
+
+Each file holds the inputs (Parameter_int, Parameter_real, metrics, initial field without
+ghost fill, join tables) and the reference's outputs (field after 1, 3 and `nit` time steps and
+the per-step residual norms of the first sub-iteration).  Cases marked 'single' run the
+reference with one cache block per zone (cache_blocking_I/J/K larger than the zone), the
+configuration in which its floating-point operation order is reproducible by a plain loop nest;
+'default' keeps the reference's default cache blocking (2048,2,7), whose results differ from
+'single' in the last bits (or, for the sensor scheme, by sensor flips).
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np
+from fast_amd import cases, connect, FastC, Internal
+from oracle import ref_harness as R
+from common import prepare, zone_arrays
+
+SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+
+# name: (kind, n, scheme, model, blocks, cache, nit)
+CASES = {
+    'tgv12_senseur_lamin':      ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'single', 100),
+    'tgv12_ausmpred_lamin':     ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'single', 100),
+    'tgv12_roe_lamin':          ('tgv', 12, 'roe', 'NSLaminar', (1, 1, 1), 'single', 10),
+    'tgv10_senseur_euler':      ('tgv', 10, 'senseur', 'Euler', (1, 1, 1), 'single', 10),
+    'vortex12_roe_euler':       ('vortex', 12, 'roe', None, (1, 1, 1), 'single', 100),
+    'tgv_ragged_senseur_lamin': ('tgv', (13, 6, 9), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 5),
+    'tgv_2x2_senseur_lamin':    ('tgv', (8, 12, 20), 'senseur', 'NSLaminar', (1, 2, 2), 'single', 10),
+    'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
+    'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
+}
+
+
+def build(kind, n, scheme, model, blocks, cache):
+    extra = SINGLE if cache == 'single' else None
+    if kind == 'tgv':
+        return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra)
+    return cases.vortex(n, scheme, extra_numz=extra)
+
+
+def main():
+    if not R.available():
+        raise SystemExit("make_golden: oracle/_ref/libfast_ref.so is missing (python oracle/build_ref.py)")
+    for name, (kind, n, scheme, model, blocks, cache, nit) in CASES.items():
+        t = build(kind, n, scheme, model, blocks, cache)
+        metrics = prepare(t)
+        zones = Internal.getZones(t)
+        nb = len(zones)
+        out = {'nzone': np.int32(nb), 'nit': np.int32(nit)}
+        rz = []
+        for b, (z, m) in enumerate(zip(zones, metrics)):
+            pint, preal, xyz = zone_arrays(z)
+            ro0 = FastC.level_buffer(z).copy()
+            rz.append(R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], ro0, m[0]))
+            # metrics from the reference's own cp_tijk / cp_vol
+            out['mtr%d' % b] = R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2])
+            out['pint%d' % b] = np.asarray(pint, dtype=np.int32)
+            out['preal%d' % b] = np.asarray(preal, dtype=np.float64)
+            out['ro0_%d' % b] = ro0
+        joins = []
+        if nb > 1:
+            if isinstance(n, int):
+                n = (n, n, n)
+            nv = tuple(n[d] // blocks[d] for d in range(3))
+            joins = [(br, r, bd, d) for br, bd, r, d in connect.periodic_block_joins(blocks, nv)]
+            out['njoin'] = np.int32(len(joins))
+            for q, (br, r, bd, d) in enumerate(joins):
+                out['join%d_zones' % q] = np.array([br, bd], dtype=np.int32)
+                out['join%d_rcv' % q] = r
+                out['join%d_dnr' % q] = d
+        s = R.RefSolver(rz, joins)
+        s.fill_ghostcells('ro')
+        for b in range(nb):
+            out['ghost_%d' % b] = rz[b].ro.copy()
+        res = np.zeros((nit, nb, 2, 5))
+        for it in range(1, nit + 1):
+            s.step(it)
+            for b, (l2, loo) in enumerate(s.residuals()):
+                res[it - 1, b, 0] = l2; res[it - 1, b, 1] = loo
+            if it in (1, 3, nit):
+                for b in range(nb):
+                    out['ro_it%d_%d' % (it, b)] = rz[b].ro.copy()
+        out['residuals'] = res
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **out)
+        print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024.))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,62 @@
+"""One rank of the multi-rank GPU test (started by test_gpu_mpi.py): the product path
+fast_amd.Mpi (warmup / _compute over torch.distributed) with every rank on GPU 0 and the
+messages staged through the host by the gloo backend.  Each rank compares its block with a
+serial run of the whole job by the CPU restatement.
+
+    python mpi_gpu_worker.py <bi> <bj> <bk> <n> <nsteps>
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from fast_amd import cases, connect, FastC, Internal
+import fast_amd.Mpi as FastSmpi
+from oracle import oracle as O
+from common import prepare, zone_arrays
+
+SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+
+
+def main():
+    blocks = tuple(int(a) for a in sys.argv[1:4])
+    n = int(sys.argv[4]); nsteps = int(sys.argv[5])
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    job = FastSmpi.tgv_job(n, blocks, 'senseur', 'NSLaminar', rank, world, 0)
+    for it in range(1, nsteps + 1):
+        FastSmpi._compute(job.t, job.metrics, it, job.tc, job.graph)
+    got = FastC.level_buffer(Internal.getZones(job.t)[0])
+
+    nn = tuple(n * b for b in blocks)
+    tt = cases.tgv(nn, 'senseur', blocks=blocks, time_step=0.003 * 32. / max(nn))
+    mm = prepare(tt)
+    zs = []
+    for zz, m in zip(Internal.getZones(tt), mm):
+        p, pr, _ = zone_arrays(zz)
+        zs.append(O.OracleZone(p, pr, FastC.level_buffer(zz), m[0]))
+    s = O.OracleSolver(zs, [(br, r, bd, d) for br, bd, r, d in connect.periodic_block_joins(blocks, (n, n, n))])
+    s.fill_ghostcells()
+    for it in range(nsteps):
+        s.step()
+    ok = np.array_equal(got, zs[rank].ro)
+    if not ok:
+        print("rank %d: max abs diff %g" % (rank, np.abs(got - zs[rank].ro).max()), flush=True)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("MPI_GPU_WORKER_RESULT %d" % int(flag.item()), flush=True)
+    FastC.HOOK['ctx'].close()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,14 @@
+"""Multi-rank product path on one GPU: 2 ranks share GPU 0, messages over gloo (staged through
+pinned host memory).  On a multi-GPU node the same code runs one rank per GPU over RCCL."""
+import pytest
+
+from test_mpi_gloo import _run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("blocks,n", [((1, 1, 2), 12), ((2, 1, 1), 10)])
+def test_two_ranks_one_gpu(blocks, n):
+    rcs, outs = _run(2, list(blocks) + [n, 3], timeout=300, worker='mpi_gpu_worker.py')
+    assert rcs == [0, 0], "\n".join(outs)
+    assert "MPI_GPU_WORKER_RESULT 1" in outs[0]

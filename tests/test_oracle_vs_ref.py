@@ -1,0 +1,90 @@
+"""CPU restatement and host model against the compiled reference itself (oracle/_ref), on
+cases beyond the committed golden vectors.  Skipped where the reference library is absent."""
+import numpy as np
+import pytest
+
+from fast_amd import cases, connect, FastC, Internal
+from oracle import oracle as O
+from oracle import ref_harness as R
+from common import prepare, zone_arrays, make_case
+
+pytestmark = [pytest.mark.ref,
+              pytest.mark.skipif(not R.available(), reason="compiled reference not built")]
+
+
+def _pair(t, blocks=None, nv=None):
+    metrics = prepare(t)
+    zones = Internal.getZones(t)
+    oz, rz = [], []
+    for z, m in zip(zones, metrics):
+        pint, preal, xyz = zone_arrays(z)
+        oz.append(O.OracleZone(pint, preal, FastC.level_buffer(z), m[0]))
+        rz.append(R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], FastC.level_buffer(z), m[0]))
+    joins = []
+    if blocks is not None:
+        joins = [(br, r, bd, d) for br, bd, r, d in connect.periodic_block_joins(blocks, nv)]
+    return O.OracleSolver(oz, joins), R.RefSolver(rz, joins)
+
+
+@pytest.mark.parametrize("kind,n,scheme,model,nit", [
+    ('tgv', 14, 'senseur', 'NSLaminar', 6),
+    ('tgv', (9, 7, 5), 'ausmpred', 'NSLaminar', 4),
+    ('tgv', (6, 11, 8), 'roe', 'NSLaminar', 4),
+    ('tgv', 9, 'ausmpred', 'Euler', 4),
+    ('vortex', 10, 'roe', None, 6),
+])
+def test_single_zone_bit_exact(kind, n, scheme, model, nit):
+    so, sr = _pair(make_case(kind, n, scheme, model))
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    for it in range(1, nit + 1):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+        np.testing.assert_allclose(so.zones[0].residuals()[0], sr.residuals()[0][0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("blocks,nn", [((2, 1, 1), (12, 6, 6)), ((1, 1, 3), (6, 6, 15)), ((2, 2, 2), (8, 8, 8))])
+def test_match_joins_bit_exact(blocks, nn):
+    nv = tuple(nn[d] // blocks[d] for d in range(3))
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    t = cases.tgv(nn, 'senseur', blocks=blocks, extra_numz=extra)
+    so, sr = _pair(t, blocks, nv)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for it in range(1, 4):
+        so.step(); sr.step(it)
+        for a, b in zip(so.zones, sr.zones):
+            assert np.array_equal(a.ro, b.ro), "step %d" % it
+
+
+def test_split_box_equals_single_block_to_rounding():
+    """An inviscid periodic box split in blocks and joined gives the single-block solution up to
+    rounding.  (With viscous terms the two differ at O(1e-10): the cross derivatives next to a
+    block edge read edge ghost cells, which are averages of face ghosts in a block but true
+    periodic images along the interior of a single block.)"""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    t1 = cases.tgv(8, 'ausmpred', model='Euler', extra_numz=extra)
+    s1, _ = _pair(t1)
+    t2 = cases.tgv(8, 'ausmpred', model='Euler', blocks=(1, 1, 2), extra_numz=extra)
+    s2, _ = _pair(t2, (1, 1, 2), (8, 8, 4))
+    s1.fill_ghostcells(); s2.fill_ghostcells()
+    for it in range(5):
+        s1.step(); s2.step()
+    a = s1.zones[0].ro.reshape(5, -1)[:, :12 * 12 * 12].reshape(5, 12, 12, 12)[:, 2:-2, 2:-2, 2:-2]
+    lo = s2.zones[0].ro.reshape(5, -1)[:, :8 * 12 * 12].reshape(5, 8, 12, 12)[:, 2:-2, 2:-2, 2:-2]
+    hi = s2.zones[1].ro.reshape(5, -1)[:, :8 * 12 * 12].reshape(5, 8, 12, 12)[:, 2:-2, 2:-2, 2:-2]
+    b = np.concatenate([lo, hi], axis=1)
+    assert np.abs(a - b).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [(8, 8, 8), (5, 9, 7)])
+def test_host_metrics_equal_reference(n):
+    """ti,tj,tk,vol built on the host equal the reference's cp_tijk / cp_vol bit for bit, and the
+    zone classification equals nature_geom_dom."""
+    t = cases.tgv(n, 'senseur')
+    metrics = prepare(t)
+    z = Internal.getZones(t)[0]
+    pint, preal, xyz = zone_arrays(z)
+    assert np.array_equal(metrics[0][0], R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2]))
+    typ, nijk_mtr, ndimdx_mtr, neq_ij, neq_k = R.ref_nature_geom_dom(xyz[0], xyz[1], xyz[2], 2, 2)
+    assert typ == int(pint[25]) == 2
+    assert ndimdx_mtr == int(pint[43]) and neq_ij == int(pint[37]) and neq_k == int(pint[38])
