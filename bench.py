@@ -78,7 +78,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--n', type=int, default=256, help='cells per direction per GPU block')
+    ap.add_argument('--cells', dest='n', type=int, default=256, help='cells per direction per GPU block')
     ap.add_argument('--scheme', default='senseur', choices=['senseur', 'ausmpred', 'roe'])
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     a = ap.parse_args()

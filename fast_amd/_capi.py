@@ -35,6 +35,13 @@ def lib():
             raise FastsHipError(
                 "fast_amd: native library %s is missing; build it with "
                 "`make -C fast_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm ships its own copy of the HIP runtime.  When both live in one process the
+        # copy loaded first must be torch's, or torch finds no GPU afterwards; the library then
+        # binds to that same runtime (same soname).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.fs_version.restype = ctypes.c_char_p
         L.fs_last_error.restype = ctypes.c_char_p

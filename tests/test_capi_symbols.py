@@ -23,7 +23,7 @@ def test_header_declares_the_binding_symbols():
 
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_capi.LIB_PATH), "build with make -C fast_amd/csrc"
-    L = ctypes.CDLL(_capi.LIB_PATH)
+    L = _capi.lib()
     for name in declared_symbols():
         assert hasattr(L, name), name
     L.fs_version.restype = ctypes.c_char_p

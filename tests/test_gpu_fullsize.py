@@ -1,7 +1,8 @@
 """Full-size checks (256^3, the benchmark configuration): one complete time step against the CPU
 restatement, and size-independent properties of the scheme on a periodic Cartesian box --
-translation invariance (bit-exact: every cell runs the same arithmetic wherever the tile and
-chunk boundaries fall) and conservation of mass, momentum and total energy."""
+translation invariance of the inviscid scheme (bit-exact: every cell runs the same arithmetic
+wherever the tile and chunk boundaries fall; the viscous cross derivatives are excluded because
+next to the box boundary they read edge ghost cells, which the reference fills with averages) and conservation of mass, momentum and total energy."""
 import numpy as np
 import pytest
 
@@ -33,14 +34,15 @@ def test_one_full_size_step_bit_exact_vs_oracle():
     FastS._compute(t, metrics, 1, None)
     oz.step()
     got = FastC.level_buffer(z)
-    assert np.array_equal(got, oz.ro), "max abs diff %g" % np.abs(got - oz.ro).max()
+    same = np.array_equal(got, oz.ro)
+    assert same, "max abs diff %g" % np.abs(got - oz.ro).max()
 
 
 @pytest.mark.parametrize("scheme", ["senseur", "ausmpred"])
 def test_translation_invariance_full_size(scheme):
     shift = (11, 5, 37)          # cells along k, j, i: moves every tile and chunk boundary
     nit = 2
-    t = cases.tgv(N, scheme)
+    t = cases.tgv(N, scheme, model='Euler')
     (t, tc, metrics) = FastS.warmup(t, None)
     z = Internal.getZones(t)[0]
     start = _interior(z).copy()
@@ -48,7 +50,7 @@ def test_translation_invariance_full_size(scheme):
         FastS._compute(t, metrics, it, None)
     ref = np.roll(_interior(z), shift, axis=(1, 2, 3))
 
-    t2 = cases.tgv(N, scheme)
+    t2 = cases.tgv(N, scheme, model='Euler')
     (t2, tc2, metrics2) = FastS.warmup(t2, None)
     z2 = Internal.getZones(t2)[0]
     _interior(z2)[...] = np.roll(start, shift, axis=(1, 2, 3))
@@ -57,7 +59,8 @@ def test_translation_invariance_full_size(scheme):
     for it in range(1, nit + 1):
         FastS._compute(t2, metrics2, it, None)
     got = _interior(z2)
-    assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
+    same = np.array_equal(got, ref)
+    assert same, "max abs diff %g" % np.abs(got - ref).max()
 
 
 def test_conservation_full_size():
