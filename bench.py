@@ -172,7 +172,7 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n},
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.scheme)
             except Exception as e:   # the baseline is informative; never lose the GPU number

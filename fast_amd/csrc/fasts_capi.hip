@@ -320,8 +320,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
       HIPCHK(ctx, hipMalloc(&zn.xmut, sizeof(double) * (size_t)zn.z.nd));
       HIPCHK(ctx, hipMemsetAsync(zn.xmut, 0, sizeof(double) * (size_t)zn.z.nd, ctx->stream));
       if (zn.z.kflu == 2) {
-        HIPCHK(ctx, hipMalloc(&zn.wig, sizeof(double) * 3 * (size_t)zn.z.nd));
-        HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, sizeof(double) * 3 * (size_t)zn.z.nd, ctx->stream));
+        // face sensors: 0/1 values, one byte each in the tiled kernel, doubles in the plain one
+        const size_t nw = (ctx->plain_stage ? sizeof(double) : 1) * 3 * (size_t)zn.z.nd;
+        HIPCHK(ctx, hipMalloc(&zn.wig, nw));
+        HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, nw, ctx->stream));
       }
       HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 10 * (size_t)zn.z.jv * zn.z.kv));
       HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * 10));
@@ -415,7 +417,7 @@ extern "C" int fs_stage(fs_ctx *ctx, int nitrun, int nstep)
     }
     const int krc = ctx->plain_stage
         ? fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream)
-        : fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
+        : fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, (unsigned char *)zn.wig, ctx->stream);
     if (krc)
       return fail(ctx, FS_ERR_UNSUPPORTED, "fs_stage: no kernel for this scheme / model");
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
@@ -638,6 +640,13 @@ extern "C" int fs_debug_fetch(fs_ctx *ctx, int zone, int which, double *host, in
   long long n = which == 0 ? (long long)zn.z.neq * zn.z.nd : (which == 1 ? 3 * zn.z.nd : zn.z.nd);
   if (!src) return fail(ctx, FS_ERR_STATE, "fs_debug_fetch: array not allocated for this scheme");
   if (n_doubles != n) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: size mismatch");
+  if (which == 1 && !ctx->plain_stage) {  // byte sensors: widen on the host
+    std::vector<unsigned char> b((size_t)n);
+    HIPCHK(ctx, hipMemcpyAsync(b.data(), src, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (long long i = 0; i < n; i++) host[i] = (double)b[(size_t)i];
+    return FS_OK;
+  }
   HIPCHK(ctx, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FS_OK;

@@ -93,7 +93,7 @@ template <int KFLU, int IFLOW, bool FIRST>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int ntile_j, int nblk,
              const double *__restrict__ rop, double *__restrict__ rop_out, double *__restrict__ drodm,
-             const double *__restrict__ xmut, double *__restrict__ wig)
+             const double *__restrict__ xmut, unsigned char *__restrict__ wig)
 {
   __shared__ Smem sm;
   // blocks that share an XCD (same blockIdx % 8) get consecutive tiles, so halo rows of
@@ -125,6 +125,15 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
   };
   auto PW_ = [&](double *a, int e, int kk) -> double * {
     return a + ((long long)e * nd + (long long)(kk + z.ifick - 1) * inck);
+  };
+  // face sensors are 0 or 1: kept as one byte per cell and direction
+  auto ldw = [&](int d, int kk, unsigned boff) -> double {
+    const unsigned char *b = wig + ((long long)d * nd + (long long)(kk + z.ifick - 1) * inck);
+    return (double)b[boff >> 3];
+  };
+  auto stw = [&](int d, int kk, unsigned boff, double w) {
+    unsigned char *b = wig + ((long long)d * nd + (long long)(kk + z.ifick - 1) * inck);
+    b[boff >> 3] = (unsigned char)(w != 0.);
   };
   // staging map.  The 256 tile cells of a plane are written to LDS by their own lanes from
   // registers; the 288 halo cells (rows -2,-1,TJ,TJ+1 over the full width, then columns
@@ -195,9 +204,9 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
   // sensor values of the faces of the next plane are fetched one step ahead (stages 2 and 3)
   double wgi_n = 0., wgj_n = 0., wgk_n = 0.;
   if (KFLU == 2 && !FIRST) {
-    wgk_n = ldg(P(wig, 2, k0), ob);
-    wgi_n = ldg(P(wig, 0, k0), ob);
-    wgj_n = ldg(P(wig, 1, k0), ob);
+    wgk_n = ldw(2, k0, ob);
+    wgi_n = ldw(0, k0, ob);
+    wgj_n = ldw(1, k0, ob);
   }
   __syncthreads();
 
@@ -209,7 +218,7 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
     if (KFLU == 2 && FIRST) {
       auto qs = [&](int e, int o) -> double { return o == -2 ? m2[e] : (o == -1 ? m1[e] : (o == 0 ? p0[e] : p1[e])); };
       wg = fs_wiggle(qs);
-      if (cell_ok) stg(PW_(wig, 2, kk + 1), ob, wg);   // the face belongs to cell kk+1
+      if (cell_ok) stw(2, kk + 1, ob, wg);   // the face belongs to cell kk+1
     }
     fs_flux_inviscid<KFLU, 2>(z, m2, m1, p0, p1, wg, flu);
     if (IFLOW == 2) {
@@ -252,9 +261,9 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
     const double wgi = wgi_n, wgj = wgj_n;
     double wgk = 0.;
     if (KFLU == 2 && !FIRST) {
-      wgk = ldg(P(wig, 2, k + 1), ob);
-      wgi_n = ldg(P(wig, 0, k + 1), ob);
-      wgj_n = ldg(P(wig, 1, k + 1), ob);
+      wgk = ldw(2, k + 1, ob);
+      wgi_n = ldw(0, k + 1, ob);
+      wgj_n = ldw(1, k + 1, ob);
     }
     // sensors of the tile-edge faces handled by this wave in this step
     const int duty = (k - k0) & 3;
@@ -262,8 +271,8 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
     const bool duty_i = row == ((duty + 2) & 3) && edge_i;
     double wge_j = 0., wge_i = 0.;
     if (KFLU == 2 && !FIRST) {
-      if (duty_j) wge_j = ldg(P(wig, 1, k), ob_je);
-      if (duty_i) wge_i = ldg(P(wig, 0, k), ob_ie);
+      if (duty_j) wge_j = ldw(1, k, ob_je);
+      if (duty_i) wge_i = ldw(0, k, ob_ie);
     }
     // plane k+2 of (u,v,w) goes to the free ring slot as soon as the j-face is done; plane k+1 of
     // (rho,T,mu) is requested before the k-face and replaces plane k after the faces are done
@@ -281,7 +290,7 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
     double fkp[5], fjm[5] = {0., 0., 0., 0., 0.}, fim[5] = {0., 0., 0., 0., 0.}, fip[5], fjp[5];
     if (fj_ok) {
       double w = face_ij<KFLU, IFLOW, 1, FIRST>(z, sm, k, ct, wgj, fjm);
-      if (KFLU == 2 && FIRST) stg(PW_(wig, 1, k), ob, w);
+      if (KFLU == 2 && FIRST) stw(1, k, ob, w);
 #pragma unroll
       for (int e = 0; e < 5; e++) sm.fj[e][row][lane] = fjm[e];
     }
@@ -298,21 +307,21 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
     }
     if (fi_ok) {
       double w = face_ij<KFLU, IFLOW, 0, FIRST>(z, sm, k, ct, wgi, fim);
-      if (KFLU == 2 && FIRST) stg(PW_(wig, 0, k), ob, w);
+      if (KFLU == 2 && FIRST) stw(0, k, ob, w);
     }
     // far-edge faces of the tile (row j0+TJ+1 and column i0+TI+1 of the zone): one masked pass
     // each, rotated over the waves
     if (duty_j) {
       double fe[5];
       double w = face_ij<KFLU, IFLOW, 1, FIRST>(z, sm, k, lidx(lane, TJ), wge_j, fe);
-      if (KFLU == 2 && FIRST) stg(PW_(wig, 1, k), ob_je, w);
+      if (KFLU == 2 && FIRST) stw(1, k, ob_je, w);
 #pragma unroll
       for (int e = 0; e < 5; e++) sm.fj[e][TJ][lane] = fe[e];
     }
     if (duty_i) {
       double fe[5];
       double w = face_ij<KFLU, IFLOW, 0, FIRST>(z, sm, k, lidx(TI, lane), wge_i, fe);
-      if (KFLU == 2 && FIRST) stg(PW_(wig, 0, k), ob_ie, w);
+      if (KFLU == 2 && FIRST) stw(0, k, ob_ie, w);
 #pragma unroll
       for (int e = 0; e < 5; e++) sm.fi_extra[e][lane] = fe[e];
     }
@@ -388,7 +397,7 @@ k_stage_tile(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int 
 
 template <int KFLU, int IFLOW>
 void launch(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-            double *drodm, const double *xmut, double *wig, hipStream_t s)
+            double *drodm, const double *xmut, unsigned char *wig, hipStream_t s)
 {
   // the face i = iv+1 is evaluated by lane iv - i0 of the last tile, or by its edge pass
   const int nti = (z.iv + TI - 1) / TI;
@@ -408,7 +417,7 @@ void launch(const FsZone &z, double coefH, double coefW, int first, const double
 }  // namespace
 
 int fsk_stage_tiled(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                    double *drodm, const double *xmut, double *wig, hipStream_t s)
+                    double *drodm, const double *xmut, unsigned char *wig, hipStream_t s)
 {
   // one k-plane must stay below 4 GiB / 8 so that in-plane byte offsets fit 32 bits
   if ((long long)z.ni * z.nj >= (1ll << 28)) return -2;
