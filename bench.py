@@ -154,6 +154,13 @@ def main():
         raise SystemExit("bench.py: non-finite field after the run")
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes of this same command (collected in runs of their
+        # own by profiles/run_profiles.sh; counters cannot be read inside a timed run)
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic_%s_%d.json' % (a.scheme, a.n))
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                traffic = json.load(fh).get('traffic_bytes_per_launch')
         bpl = BYTES_PER_CELL_STEP[a.scheme] / 3.0 * a.n ** 3     # algorithmic bytes per launch
         ach = bpl / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.
         out = {
@@ -169,7 +176,7 @@ def main():
                                    "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
                        "blocks": list(split_for(world) or (1, 1, 1)), "ghost_layers": 2},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n},
         }
         if not a.no_cpu and world == 1:

@@ -8,7 +8,7 @@ import os
 import numpy
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libfasts_hip.so")
+LIB_PATH = os.environ.get("FASTS_HIP_LIB", os.path.join(HERE, "csrc", "libfasts_hip.so"))
 
 FS_LEVEL_N, FS_LEVEL_M1, FS_LEVEL_P1 = 1, 2, 4
 

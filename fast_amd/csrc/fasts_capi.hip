@@ -53,6 +53,7 @@ struct fs_ctx {
   std::vector<Send> sends;
   bool uploaded = false;
   bool plain_stage = false;   // FASTS_HIP_STAGE=plain: untiled stage kernel (debugging aid)
+  bool dma_stage = true;      // default: LDS-DMA staged kernel; FASTS_HIP_STAGE=tile64 selects the register-staged one
   int modulo_verif = 200;
   std::string err;
   // stage-kernel timing
@@ -108,6 +109,7 @@ extern "C" int fs_create(fs_ctx **out, int device)
   c->stream = c->own_stream;
   const char *ev = getenv("FASTS_HIP_STAGE");
   c->plain_stage = ev && strcmp(ev, "plain") == 0;
+  c->dma_stage = !(ev && strcmp(ev, "tile64") == 0);
   *out = c;
   return FS_OK;
 }
@@ -417,7 +419,9 @@ extern "C" int fs_stage(fs_ctx *ctx, int nitrun, int nstep)
     }
     const int krc = ctx->plain_stage
         ? fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream)
-        : fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, (unsigned char *)zn.wig, ctx->stream);
+        : (ctx->dma_stage
+               ? fsk_stage_dma(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, (unsigned char *)zn.wig, ctx->stream)
+               : fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, (unsigned char *)zn.wig, ctx->stream));
     if (krc)
       return fail(ctx, FS_ERR_UNSUPPORTED, "fs_stage: no kernel for this scheme / model");
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));

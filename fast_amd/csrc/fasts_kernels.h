@@ -18,6 +18,9 @@ int fsk_stage(const FsZone &z, double coefH, double coefW, int first, const doub
 // tiled stage kernel (fasts_stage.hip); at the first stage it also evaluates and stores the sensor
 int fsk_stage_tiled(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                     double *drodm, const double *xmut, unsigned char *wig, hipStream_t s);
+// same contract, planes staged by LDS-DMA (fasts_stage_dma.hip)
+int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                  double *drodm, const double *xmut, unsigned char *wig, hipStream_t s);
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop,
                     hipStream_t s);
 void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);

@@ -19,4 +19,5 @@ for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ
   timeout -s KILL 180 rocprofv3 --pmc $PASS --output-format csv -d $OUT/${TAG}_pmc_$NAME -o ${TAG} -- $BENCH --steps 3 --warmup 1 > $OUT/${TAG}_pmc_$NAME.log 2>&1
   python3 $REPO/profiles/summarise.py pmc $OUT/${TAG}_pmc_$NAME $OUT/${TAG}_pmc_$NAME.csv
 done
+python3 $REPO/profiles/summarise.py traffic $OUT/${TAG}_pmc_FETCH_SIZE.csv $OUT/${TAG}_pmc_WRITE_SIZE.csv $OUT/${TAG}_traffic.json
 echo done

@@ -59,5 +59,32 @@ def pmc(d, out):
             w.writerow([k, c, n, '%.6g' % (tot / n), '%.6g' % tot] + list(meta[k]))
 
 
+def traffic(fetch_csv, write_csv, out, kernel='k_stage_'):
+    """HBM bytes per launch of the dominant kernel from the two PMC passes.  FETCH_SIZE and
+    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so it is
+    doubled (checked on k_invist, whose read volume is known: 2 x 74.9 MiB reported = 258^3 doubles
+    rounded up to 128-byte lines per row)."""
+    import json
+    tot = {'fetch': [0, 0.0], 'write': [0, 0.0]}
+    per = {}
+    for key, f in (('fetch', fetch_csv), ('write', write_csv)):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if kernel not in r['kernel']:
+                    continue
+                n = int(r['launches']); b = float(r['total']) * 1024.0 * (2.0 if key == 'fetch' else 1.0)
+                tot[key][0] += n; tot[key][1] += b
+                per.setdefault(r['kernel'], {})[key + '_bytes_per_launch'] = b / n
+    res = {'kernel': kernel, 'launches': tot['fetch'][0],
+           'fetch_bytes_per_launch': tot['fetch'][1] / max(tot['fetch'][0], 1),
+           'write_bytes_per_launch': tot['write'][1] / max(tot['write'][0], 1),
+           'per_variant': per,
+           'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py; '
+                     'KiB -> bytes; FETCH_SIZE x2 (gfx950)'}
+    res['traffic_bytes_per_launch'] = res['fetch_bytes_per_launch'] + res['write_bytes_per_launch']
+    with open(out, 'w') as fh:
+        json.dump(res, fh, indent=1)
+
+
 if __name__ == '__main__':
-    {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {'stats': stats, 'pmc': pmc, 'traffic': traffic}[sys.argv[1]](*sys.argv[2:])
