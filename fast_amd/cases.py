@@ -45,7 +45,7 @@ def tgv_fields(t, state, L0=1.):
 
 
 def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
-        temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None):
+        temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None, bcs=None):
     """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
     whole box; blocks = (bi,bj,bk) split; only = block numbers to instantiate (the blocks of one
     rank; block b = ib + jb*bi + kb*bi*bj is named 'cart<b>').  Split directions carry no BC:
@@ -70,6 +70,10 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
                 if blocks[0] == 1: faces += ['imin', 'imax']
                 if blocks[1] == 1: faces += ['jmin', 'jmax']
                 if blocks[2] == 1: faces += ['kmin', 'kmax']
+                if bcs:
+                    for f in [f for f in faces if f in bcs]:
+                        C.addBC2Zone(z, bcs[f].lower() + ' ' + f, bcs[f], f)
+                    faces = [f for f in faces if f not in bcs]
                 _periodic_faces(z, faces)
                 zones.append(z)
     t = C.newPyTree(['Base'] + zones)

@@ -16,7 +16,8 @@ namespace {
 enum { NIJK = 0, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
        NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
        SLOPE = 64, PT_BC = 70, SENSORTYPE = 85 };
-enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
+enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
+       VXINF = 19, VYINF = 20, VZINF = 21,
        PSIROE = 34 };
 
 struct Zone {
@@ -235,13 +236,28 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     FsBcWin w;
     w.type = p[pt]; w.idir = p[pt + 1];
     if (w.type == 22) continue;  // BCOverlap: filled by the join transfer
-    if (w.type != 11 && w.type != 0) {
+    // dispatch of Fast/FastS/FastS/BC/BCzone.cpp:262-283,451-461,513-523,578-586
+    const int tag = w.type;
+    if (tag == 11 || tag == 0 || tag == 1) w.type = tag;
+    else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
+    else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
+    else {
       char msg[128];
-      snprintf(msg, sizeof msg, "fs_zone_add: boundary condition tag %d is not implemented", w.type);
+      snprintf(msg, sizeof msg, "fs_zone_add: boundary condition tag %d is not implemented", tag);
       return fail(ctx, FS_ERR_UNSUPPORTED, msg);
     }
+    if ((w.type == FS_BC_WALL_SLIP || w.type == FS_BC_WALL_NOSLIP) && p[KFLUDOM] == 5)
+      return fail(ctx, FS_ERR_UNSUPPORTED,
+                  "fs_zone_add: the wall-face flux correction of the roe scheme (bfl3) is not implemented; "
+                  "use ausmpred or senseur with wall boundaries");
+    if (p[pt + 8] != 0 && tag != 11)
+      return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: boundary conditions carrying their own data are not implemented");
     if (w.idir < 1 || w.idir > 6) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window is not on a zone face");
     if (!bc_window(p, w.idir, p + pt + 2, w)) continue;
+    // reference state of BCzone.cpp:26-38 and the face metric along the normal
+    w.st[0] = r[ROINF]; w.st[1] = r[VXINF] * r[ROINF]; w.st[2] = r[VYINF] * r[ROINF]; w.st[3] = r[VZINF] * r[ROINF];
+    w.st[4] = r[PINF] / (r[GAMMA] - 1.) + 0.5 * (r[VXINF] * w.st[1] + r[VYINF] * w.st[2] + r[VZINF] * w.st[3]);
+    w.tcn = w.idir <= 2 ? mtr[0] : (w.idir <= 4 ? mtr[1] : mtr[2]);
     switch (w.idir) {  // bvbs_periodique.for: incp = IJKV(dir) * stride, towards the interior
       case 1: w.shift = z.iv; break;
       case 2: w.shift = -(long long)z.iv; break;

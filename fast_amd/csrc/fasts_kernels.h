@@ -4,11 +4,17 @@
 #include "fasts_flux.h"
 
 // one BC window: ghost cells lo..hi (interior-based indices, ghosts <= 0 or > n)
+// device-side BC kinds: the tags of Fast/FastC/FastC/PyTree.py:30-82 after the dispatch of BCzone.cpp
+// (tag 4 is a slip wall for Euler and a no-slip wall otherwise)
+enum { FS_BC_EXTRAPOLATE = 0, FS_BC_FARFIELD = 1, FS_BC_WALL_SLIP = 3, FS_BC_WALL_NOSLIP = 6, FS_BC_PERIODIC = 11 };
+
 struct FsBcWin {
-  int type;          // BC tag (Fast/FastC/FastC/PyTree.py:30-82): 0 extrapolate, 11 autoperiod
+  int type;          // FS_BC_*
   int idir;          // 1..6 = imin,imax,jmin,jmax,kmin,kmax
-  int lo[3], hi[3];
+  int lo[3], hi[3];  // ghost cells of the window (interior-based indices)
   long long shift;   // periodic source offset (bvbs_periodique.for: incp)
+  double st[5];      // conservative reference state (BCzone.cpp:26-38)
+  double tcn;        // face metric along the normal (ti, tj or tk of the Cartesian zone)
 };
 
 void fsk_invist(const FsZone &z, const double *rop, double *xmut, hipStream_t s);

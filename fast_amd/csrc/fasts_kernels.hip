@@ -127,31 +127,141 @@ __global__ void __launch_bounds__(256) k_stage_ref(FsZone z, double coefH, doubl
 // ------------------------------------------------------------------------------------------
 // ghost fill: BC windows, then edges and corners
 // ------------------------------------------------------------------------------------------
-// One block-row per window; window w fills cells [lo..hi] in each direction from
-// rop(l + shift) (BCautoperiod, bvbs_periodique.for:150-171) or from the nearest interior cell
-// (BCExtrapolate order 0).
+// Characteristic far-field state in ghost cell l from the interior cell l1 and the reference state
+// (Fast/FastS/FastS/BC/BCFarfield.for, non_reflection.for:1-153; fixed mesh: qen = 0).
+// tc = face metric scaled by snorm (only the normal component is non zero on a Cartesian zone).
+FS_DEV void fs_bc_farfield_first(const FsZone &z, const double *st, double tcx, double tcy, double tcz,
+                                 double *rop, long long l, long long l1)
+{
+  const long long nd = z.nd;
+  const double gam1 = z.gam - 1., gam1_1 = 1. / gam1, cvinv = 1. / z.cv;
+  const double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
+  double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+  double roi = rop[l1], rui = rop[l1 + nd] * roi, rvi = rop[l1 + 2 * nd] * roi, rwi = rop[l1 + 3 * nd] * roi;
+  double eti = rop[l1 + 4 * nd] * z.cv * roi + .5 * (rui * rui + rvi * rvi + rwi * rwi) / roi;
+  const double qen = 0.;
+  double qref1 = .5 * (roe + roi), qref2 = .5 * (rue + rui), qref3 = .5 * (rve + rvi);
+  double qref4 = .5 * (rwe + rwi), qref5 = .5 * (ete + eti);
+  double r = qref1, ri = 1. / r, u = qref2 * ri, v = qref3 * ri, w = qref4 * ri;
+  double pp = gam1 * (qref5 - .5 * r * (u * u + v * v + w * w));
+  double c = sqrt(z.gam * pp * ri), ci = 1. / c, s_1 = 1. / sn;
+  double qn = tcx * u + tcy * v + tcz * w - qen;
+  double tnx, tny;
+  if (sn == 0.) { tnx = 1.; tny = 0.; } else { tnx = tcx / sn; tny = tcy / sn; }
+  double eigv1 = qn, eigv4 = qn + sn * c, eigv5 = qn - sn * c;
+  double qvar1 = roe, qvar2 = rue, qvar3 = rve, qvar4 = rwe, qvar5 = ete;
+  double svar1 = qvar1, svar2 = (qvar2 - u * qvar1) * ri, svar3 = (qvar3 - v * qvar1) * ri;
+  double svar4 = (qvar4 - w * qvar1) * ri;
+  double svar5 = gam1 * (.5 * (u * u + v * v + w * w) * qvar1 - u * qvar2 - v * qvar3 - w * qvar4 + qvar5);
+  double rvar1 = svar1 - ci * ci * svar5;
+  double rvar2 = tcz * s_1 * (tnx * svar2 + tny * svar3) - svar4;
+  double rvar3 = -tny * svar2 + tnx * svar3;
+  double rvar4 = .5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+  double rvar5 = -.5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+  const double roext = rvar1, ruext = rvar2, rvext = rvar3, rwext = rvar4, etext = rvar5;
+  qvar1 = roi; qvar2 = rui; qvar3 = rvi; qvar4 = rwi; qvar5 = eti;
+  svar1 = qvar1; svar2 = (qvar2 - u * qvar1) * ri; svar3 = (qvar3 - v * qvar1) * ri;
+  svar4 = (qvar4 - w * qvar1) * ri;
+  svar5 = gam1 * (.5 * (u * u + v * v + w * w) * qvar1 - u * qvar2 - v * qvar3 - w * qvar4 + qvar5);
+  rvar1 = svar1 - ci * ci * svar5;
+  rvar2 = tcz * s_1 * (tnx * svar2 + tny * svar3) - svar4;
+  rvar3 = -tny * svar2 + tnx * svar3;
+  rvar4 = .5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+  rvar5 = -.5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+  if (eigv1 < 0.) { rvar1 = roext; rvar2 = ruext; rvar3 = rvext; }
+  if (eigv4 < 0.) rvar4 = rwext;
+  if (eigv5 < 0.) rvar5 = etext;
+  svar1 = rvar1 + r * ci * (rvar4 + rvar5);
+  svar2 = tcz * s_1 * tnx * rvar2 - tny * rvar3 + tcx * s_1 * (rvar4 - rvar5);
+  svar3 = tcz * s_1 * tny * rvar2 + tnx * rvar3 + tcy * s_1 * (rvar4 - rvar5);
+  svar4 = -rvar2 + tcz * s_1 * (rvar4 - rvar5);
+  svar5 = r * c * (rvar4 + rvar5);
+  qvar5 = .5 * (u * u + v * v + w * w) * svar1 + r * (u * svar2 + v * svar3 + w * svar4) + gam1_1 * svar5;
+  double roinv = 1. / svar1;
+  u = u + r * svar2 * roinv; v = v + r * svar3 * roinv; w = w + r * svar4 * roinv;
+  rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
+  rop[l + 4 * nd] = (qvar5 * roinv - .5 * (u * u + v * v + w * w)) * cvinv;
+}
+
+// One block-row per window, one thread per face cell of the window; the thread walks the ghost
+// ranks outwards (rank 2 of the far field reads rank 1).
+//   BCautoperiod       ghost = rop(l + shift)                     bvbs_periodique.for:150-171
+//   BCExtrapolate      ghost = first interior cell                 BCExtrapolate.for (c1 = 1)
+//   no-slip wall       mirror cell, velocity reversed              BCWallViscous_i.for (c_ale = 0)
+//   slip wall          mirror cell, velocity reflected             FastC/BC/BCWallInviscid.for
+//   far field          characteristic state, then extrapolation    BCFarfield.for, BC_nextrank.for
 __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const FsBcWin *__restrict__ wins,
                                                     double *__restrict__ rop)
 {
   const FsBcWin w = wins[blockIdx.y];
-  const int n0 = w.hi[0] - w.lo[0] + 1, n1 = w.hi[1] - w.lo[1] + 1, n2 = w.hi[2] - w.lo[2] + 1;
-  const long long n = (long long)n0 * n1 * n2;
+  const int d = (w.idir - 1) >> 1, sgn = (w.idir & 1) ? 1 : -1;
+  const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;          // transverse directions, fastest first
+  const int na = w.hi[da] - w.lo[da] + 1, nb = w.hi[db] - w.lo[db] + 1, nr = w.hi[d] - w.lo[d] + 1;
+  const int first = sgn > 0 ? 1 : (d == 0 ? z.iv : (d == 1 ? z.jv : z.kv));
+  const long long stride = d == 0 ? 1 : (d == 1 ? z.incj : z.inck);
+  const long long inc = sgn * stride;                          // from a ghost cell towards the interior
+  const long long nd = z.nd;
+  const long long n = (long long)na * nb;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-    int i = w.lo[0] + (int)(t % n0);
-    int j = w.lo[1] + (int)((t / n0) % n1);
-    int k = w.lo[2] + (int)(t / ((long long)n0 * n1));
-    long long l = fs_inddm(z, i, j, k), ls;
-    if (w.type == 11) ls = l + w.shift;
-    else {  // order-0 extrapolation: first interior cell along the face normal
-      int ii = i, jj = j, kk = k;
-      switch (w.idir) {
-        case 1: ii = 1; break; case 2: ii = z.iv; break;
-        case 3: jj = 1; break; case 4: jj = z.jv; break;
-        case 5: kk = 1; break; default: kk = z.kv; break;
+    int q[3];
+    q[da] = w.lo[da] + (int)(t % na);
+    q[db] = w.lo[db] + (int)(t / na);
+    q[d] = first;
+    const long long l1 = fs_inddm(z, q[0], q[1], q[2]);        // first interior cell
+    if (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE) {
+      for (int r = 1; r <= nr; r++) {
+        const long long l = l1 - r * inc;
+        const long long ls = w.type == FS_BC_PERIODIC ? l + w.shift : l1;
+        for (int e = 0; e < 5; e++) rop[e * nd + l] = rop[e * nd + ls];
       }
-      ls = fs_inddm(z, ii, jj, kk);
+    } else if (w.type == FS_BC_WALL_NOSLIP) {
+      for (int r = 1; r <= nr; r++) {
+        const long long l = l1 - r * inc, lm = l1 + (r - 1) * inc;
+        rop[l] = rop[lm];
+        rop[l + nd] = 0. - rop[lm + nd];
+        rop[l + 2 * nd] = 0. - rop[lm + 2 * nd];
+        rop[l + 3 * nd] = 0. - rop[lm + 3 * nd];
+        rop[l + 4 * nd] = rop[lm + 4 * nd];
+      }
+    } else if (w.type == FS_BC_WALL_SLIP) {
+      // shape_tab_mtr.for:32-52: only the metric component along the face normal is kept
+      double tc[3] = {w.tcn * 0., w.tcn * 0., w.tcn * 0.};
+      tc[d] = w.tcn * 1.;
+      for (int r = 1; r <= nr; r++) {
+        const long long l = l1 - r * inc, lm = l1 + (r - 1) * inc;
+        double tcx = tc[0], tcy = tc[1], tcz = tc[2];
+        double surf = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+        surf = fs_max(surf, 1e-30);
+        const double s_1 = 1. / surf;
+        tcx = tcx * s_1; tcy = tcy * s_1; tcz = tcz * s_1;
+        const double u = rop[lm + nd] - 0., v = rop[lm + 2 * nd] - 0., ww = rop[lm + 3 * nd] - 0.;
+        const double qn = (u * tcx + v * tcy + ww * tcz);
+        const double ut = u - qn * tcx, vt = v - qn * tcy, wt = ww - qn * tcz;
+        const double ua = 2. * ut - u, va = 2. * vt - v, wa = 2. * wt - ww;
+        rop[l] = rop[lm];
+        rop[l + nd] = 0. + ua;
+        rop[l + 2 * nd] = 0. + va;
+        rop[l + 3 * nd] = 0. + wa;
+        rop[l + 4 * nd] = rop[lm + 4 * nd];
+      }
+    } else {  // FS_BC_FARFIELD
+      const double snorm = (w.idir & 1) ? -1. : 1.;
+      double tc[3] = {w.tcn * 0. * snorm, w.tcn * 0. * snorm, w.tcn * 0. * snorm};
+      tc[d] = w.tcn * 1. * snorm;
+      fs_bc_farfield_first(z, w.st, tc[0], tc[1], tc[2], rop, l1 - inc, l1);
+      const double c4 = 5. / 6., c5 = 2. / 6., c6 = -1. / 6.;
+      const double c0 = 1. / c6, c1 = -(c4 + c5) * c0, c2 = -c6 * c0, c3 = (2. - c5 - c4) * c0;
+      for (int r = 2; r <= nr; r++) {   // BC_nextrank.for
+        const long long l = l1 - r * inc, l0 = l + inc, l1b = l + 2 * inc, l2 = l + 3 * inc;
+        const double ro = rop[l0] * c3 + rop[l1b] * c1 + rop[l2] * c2;
+        rop[l] = ro;
+        if (fabs(ro / rop[l0] - 1.) >= 0.7) {
+          for (int e = 0; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd];
+        } else {
+          for (int e = 1; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd] * c3 + rop[l1b + e * nd] * c1 + rop[l2 + e * nd] * c2;
+        }
+      }
     }
-    for (int e = 0; e < z.neq; e++) rop[e * z.nd + l] = rop[e * z.nd + ls];
   }
 }
 

@@ -9,7 +9,8 @@
  *
  * Scope: zone type 2 (Cartesian, constant step), 5 equations, slope o3, schemes
  * ausmpred (1) / senseur (2) / roe (5), Euler or laminar Navier-Stokes, explicit RK1/2/3,
- * BCautoperiod + BCExtrapolate ghost fill, edge/corner fix.  Array layout, loop ranges and
+ * ghost fill for BCautoperiod, BCExtrapolate, BCFarfield, slip and adiabatic no-slip walls,
+ * edge/corner fix.  Array layout, loop ranges and
  * the order of floating-point operations follow the reference routines cited at each
  * function, so that with one cache block the results agree with the reference to rounding.
  *
@@ -516,6 +517,209 @@ void fo_bc_periodic(const i32 *p, int idir, const i32 *cl, double *rop)
       }
 }
 
+/* Geometry of a ghost window for the BCs that look along the face normal: for every face cell
+ * (a,b) the ghost cells g_1, g_2 (rank 1 next to the face) and the interior cells in_1, in_2, ...
+ * inc = stride pointing from a ghost cell towards the interior (inci/incj/inck of the
+ * reference loops, e.g. Fast/FastS/FastS/BC/bvbs_farfield.for:150-153,198-201). */
+typedef struct {
+  int d;        /* normal direction 0,1,2 */
+  int first;    /* index of the first interior cell along d (1 or iv/jv/kv) */
+  int sgn;      /* +1 on a min face, -1 on a max face: ghost rank r sits at first - sgn*r */
+  int nr;       /* number of ghost ranks in the window */
+} fo_face;
+
+static fo_face fo_face_of(const i32 *p, int idir)
+{
+  fo_face f;
+  f.d = (idir - 1) / 2;
+  f.sgn = (idir % 2 == 1) ? 1 : -1;
+  f.first = f.sgn > 0 ? 1 : p[IJKV + f.d];
+  f.nr = f.d == 2 ? p[NIJK + 4] : p[NIJK + 3];
+  return f;
+}
+
+/* BCExtrapolate: every ghost rank = first interior cell
+ * (Fast/FastS/FastS/BC/bvbs_extrapolate.for, BCExtrapolate_i.for, BCExtrapolate.for with
+ * c1 = 1, vmax = -1e30 from BCExtrapolate_init.for) */
+void fo_bc_extrapolate(const i32 *p, int idir, const i32 *cl, double *rop)
+{
+  GEOM(p)
+  const fo_face f = fo_face_of(p, idir);
+  const double vmax = -1.e30, c1 = 1.;
+  for (int k = cl[4]; k <= cl[5]; k++)
+    for (int j = cl[2]; j <= cl[3]; j++)
+      for (int i = cl[0]; i <= cl[1]; i++) {
+        int q[3] = {i, j, k};
+        q[f.d] = f.first;
+        long l = INDDM(i, j, k), l1 = INDDM(q[0], q[1], q[2]);
+        for (int e = 0; e < 5; e++) rop[l + e * nd] = dmax(vmax, rop[l1 + e * nd]) * c1;
+      }
+}
+
+/* Adiabatic no-slip wall on a fixed mesh: ghost rank r mirrors interior rank r with the
+ * velocity reversed (Fast/FastS/FastS/BC/bvbs_wall_viscous_adia.for:118-160,
+ * BCWallViscous_i.for with c_ale = 0: rop(l,2) = 2*ventx*c_ale - u). */
+void fo_bc_wall_viscous(const i32 *p, int idir, const i32 *cl, double *rop)
+{
+  GEOM(p)
+  const fo_face f = fo_face_of(p, idir);
+  const int ref = 2 * f.first - f.sgn;   /* iref = 2*ind_loop(2)+1 (min) or 2*ind_loop(1)-1 (max) */
+  for (int k = cl[4]; k <= cl[5]; k++)
+    for (int j = cl[2]; j <= cl[3]; j++)
+      for (int i = cl[0]; i <= cl[1]; i++) {
+        int q[3] = {i, j, k};
+        q[f.d] = ref - q[f.d];
+        long l = INDDM(i, j, k), lm = INDDM(q[0], q[1], q[2]);
+        rop[l] = rop[lm];
+        rop[l + nd] = 0. - rop[lm + nd];
+        rop[l + 2 * nd] = 0. - rop[lm + 2 * nd];
+        rop[l + 3 * nd] = 0. - rop[lm + 3 * nd];
+        rop[l + 4 * nd] = rop[lm + 4 * nd];
+      }
+}
+
+/* Face normal (unit, then scaled quantities) of a Cartesian zone for the BC routines: only the
+ * component along the face normal is non zero (Fast/FastC/FastC/Compute/shape_tab_mtr.for:32-52,
+ * neq_mtr = 1). */
+static void fo_bc_metric(int idir, const double *ti, const double *tj, const double *tk, double *tc)
+{
+  tc[0] = tc[1] = tc[2] = 0.;
+  if (idir <= 2) { tc[0] = ti[0] * 1.; tc[1] = ti[0] * 0.; tc[2] = ti[0] * 0.; }
+  else if (idir <= 4) { tc[0] = tj[0] * 0.; tc[1] = tj[0] * 1.; tc[2] = tj[0] * 0.; }
+  else { tc[0] = tk[0] * 0.; tc[1] = tk[0] * 0.; tc[2] = tk[0] * 1.; }
+}
+
+/* Slip wall: the velocity of the mirror cell is reflected about the face
+ * (Fast/FastS/FastS/BC/bvbs_wall_inviscid.for, BCWallInviscid_i.for,
+ * Fast/FastC/FastC/BC/BCWallInviscid.for:1-49 with c_ale = 0) */
+void fo_bc_wall_inviscid(const i32 *p, int idir, const i32 *cl, double *rop, const double *ti,
+                         const double *tj, const double *tk)
+{
+  GEOM(p)
+  const fo_face f = fo_face_of(p, idir);
+  const int ref = 2 * f.first - f.sgn;
+  double tc[3];
+  fo_bc_metric(idir, ti, tj, tk, tc);
+  for (int k = cl[4]; k <= cl[5]; k++)
+    for (int j = cl[2]; j <= cl[3]; j++)
+      for (int i = cl[0]; i <= cl[1]; i++) {
+        int q[3] = {i, j, k};
+        q[f.d] = ref - q[f.d];
+        long l = INDDM(i, j, k), lm = INDDM(q[0], q[1], q[2]);
+        double tcx = tc[0], tcy = tc[1], tcz = tc[2];
+        double surf = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+        surf = dmax(surf, 1e-30);
+        double s_1 = 1. / surf;
+        tcx = tcx * s_1; tcy = tcy * s_1; tcz = tcz * s_1;
+        double u = rop[lm + nd] - 0., v = rop[lm + 2 * nd] - 0., w = rop[lm + 3 * nd] - 0.;
+        double qn = (u * tcx + v * tcy + w * tcz);
+        double ut = u - qn * tcx, vt = v - qn * tcy, wt = w - qn * tcz;
+        double ua = 2. * ut - u, va = 2. * vt - v, wa = 2. * wt - w;
+        rop[l] = rop[lm];
+        rop[l + nd] = 0. + ua;
+        rop[l + 2 * nd] = 0. + va;
+        rop[l + 3 * nd] = 0. + wa;
+        rop[l + 4 * nd] = rop[lm + 4 * nd];
+      }
+}
+
+/* Far field: characteristic (non-reflecting) state in the first ghost rank from the first interior
+ * cell and the reference state, parabolic extrapolation with a positivity guard in the next ranks
+ * (Fast/FastS/FastS/BC/bvbs_farfield.for:118-196, BCFarfield_i.for, BCFarfield.for,
+ * non_reflection.for:1-153, BC_nextrank_i.for, BC_nextrank.for; c_ale = 0). */
+#define VXINF 19
+#define VYINF 20
+#define VZINF 21
+#define PINF 4
+void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
+                    const double *tj, const double *tk)
+{
+  GEOM(p)
+  const fo_face f = fo_face_of(p, idir);
+  const long strides[3] = {1, ni, ninj};
+  const long inc = f.sgn * strides[f.d];
+  const double snorm = (idir % 2 == 0) ? 1. : -1.;
+  const double gam1 = pr[GAMMA] - 1., gam1_1 = 1. / gam1, cvinv = 1. / pr[CVINF];
+  const double c4 = 5. / 6., c5 = 2. / 6., c6 = -1. / 6.;
+  const double c0 = 1. / c6, c1 = -(c4 + c5) * c0, c2 = -c6 * c0, c3 = (2. - c5 - c4) * c0;
+  /* default state of BCzone.cpp:26-38 */
+  double st[5];
+  st[0] = pr[ROINF]; st[1] = pr[VXINF] * pr[ROINF]; st[2] = pr[VYINF] * pr[ROINF]; st[3] = pr[VZINF] * pr[ROINF];
+  st[4] = pr[PINF] / (pr[GAMMA] - 1.) + 0.5 * (pr[VXINF] * st[1] + pr[VYINF] * st[2] + pr[VZINF] * st[3]);
+  const double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
+  double tc[3];
+  fo_bc_metric(idir, ti, tj, tk, tc);
+  /* transverse window */
+  int lo[3] = {cl[0], cl[2], cl[4]}, hi[3] = {cl[1], cl[3], cl[5]};
+  lo[f.d] = hi[f.d] = f.first;
+  for (int k = lo[2]; k <= hi[2]; k++)
+    for (int j = lo[1]; j <= hi[1]; j++)
+      for (int i = lo[0]; i <= hi[0]; i++) {
+        const long l1 = INDDM(i, j, k);      /* first interior cell */
+        long l = l1 - inc;                   /* first ghost rank */
+        {
+          double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
+          double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+          double roi = rop[l1], rui = rop[l1 + nd] * roi, rvi = rop[l1 + 2 * nd] * roi, rwi = rop[l1 + 3 * nd] * roi;
+          double eti = rop[l1 + 4 * nd] * pr[CVINF] * roi + .5 * (rui * rui + rvi * rvi + rwi * rwi) / roi;
+          double qen = (0. * tcx + 0. * tcy + 0. * tcz * 0.) * 0.;
+          double qref1 = .5 * (roe + roi), qref2 = .5 * (rue + rui), qref3 = .5 * (rve + rvi);
+          double qref4 = .5 * (rwe + rwi), qref5 = .5 * (ete + eti);
+          double r = qref1, ri = 1. / r, u = qref2 * ri, v = qref3 * ri, w = qref4 * ri;
+          double pp = gam1 * (qref5 - .5 * r * (u * u + v * v + w * w));
+          double c = sqrt(pr[GAMMA] * pp * ri), ci = 1. / c, s_1 = 1. / sn;
+          double qn = tcx * u + tcy * v + tcz * w - qen;
+          double tnx, tny;
+          if (sn == 0.) { tnx = 1.; tny = 0.; } else { tnx = tcx / sn; tny = tcy / sn; }
+          double eigv1 = qn, eigv2 = qn, eigv3 = qn, eigv4 = qn + sn * c, eigv5 = qn - sn * c;
+          double qvar1 = roe, qvar2 = rue, qvar3 = rve, qvar4 = rwe, qvar5 = ete;
+          double svar1 = qvar1, svar2 = (qvar2 - u * qvar1) * ri, svar3 = (qvar3 - v * qvar1) * ri;
+          double svar4 = (qvar4 - w * qvar1) * ri;
+          double svar5 = gam1 * (.5 * (u * u + v * v + w * w) * qvar1 - u * qvar2 - v * qvar3 - w * qvar4 + qvar5);
+          double rvar1 = svar1 - ci * ci * svar5;
+          double rvar2 = tcz * s_1 * (tnx * svar2 + tny * svar3) - svar4;
+          double rvar3 = -tny * svar2 + tnx * svar3;
+          double rvar4 = .5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+          double rvar5 = -.5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+          const double roext = rvar1, ruext = rvar2, rvext = rvar3, rwext = rvar4, etext = rvar5;
+          qvar1 = roi; qvar2 = rui; qvar3 = rvi; qvar4 = rwi; qvar5 = eti;
+          svar1 = qvar1; svar2 = (qvar2 - u * qvar1) * ri; svar3 = (qvar3 - v * qvar1) * ri;
+          svar4 = (qvar4 - w * qvar1) * ri;
+          svar5 = gam1 * (.5 * (u * u + v * v + w * w) * qvar1 - u * qvar2 - v * qvar3 - w * qvar4 + qvar5);
+          rvar1 = svar1 - ci * ci * svar5;
+          rvar2 = tcz * s_1 * (tnx * svar2 + tny * svar3) - svar4;
+          rvar3 = -tny * svar2 + tnx * svar3;
+          rvar4 = .5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+          rvar5 = -.5 * s_1 * (tcx * svar2 + tcy * svar3 + tcz * svar4) + .5 * ri * ci * svar5;
+          if (eigv1 < 0.) rvar1 = roext;
+          if (eigv2 < 0.) rvar2 = ruext;
+          if (eigv3 < 0.) rvar3 = rvext;
+          if (eigv4 < 0.) rvar4 = rwext;
+          if (eigv5 < 0.) rvar5 = etext;
+          svar1 = rvar1 + r * ci * (rvar4 + rvar5);
+          svar2 = tcz * s_1 * tnx * rvar2 - tny * rvar3 + tcx * s_1 * (rvar4 - rvar5);
+          svar3 = tcz * s_1 * tny * rvar2 + tnx * rvar3 + tcy * s_1 * (rvar4 - rvar5);
+          svar4 = -rvar2 + tcz * s_1 * (rvar4 - rvar5);
+          svar5 = r * c * (rvar4 + rvar5);
+          qvar5 = .5 * (u * u + v * v + w * w) * svar1 + r * (u * svar2 + v * svar3 + w * svar4) + gam1_1 * svar5;
+          double roinv = 1. / svar1;
+          u = u + r * svar2 * roinv; v = v + r * svar3 * roinv; w = w + r * svar4 * roinv;
+          rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
+          rop[l + 4 * nd] = (qvar5 * roinv - .5 * (u * u + v * v + w * w)) * cvinv;
+        }
+        for (int r = 2; r <= f.nr; r++) {   /* next ranks, outwards */
+          l = l1 - r * inc;
+          const long l0 = l + inc, l1b = l + 2 * inc, l2 = l + 3 * inc;
+          rop[l] = rop[l0] * c3 + rop[l1b] * c1 + rop[l2] * c2;
+          if (fabs(rop[l] / rop[l0] - 1.) >= 0.7) {
+            for (int e = 0; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd];
+          } else {
+            for (int e = 1; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd] * c3 + rop[l1b + e * nd] * c1 + rop[l2 + e * nd] * c2;
+          }
+        }
+      }
+}
+
 /* Edge ghosts = mean of the two neighbouring face ghosts, corner ghosts = mean of three
  * (Fast/FastS/FastS/BC/correct_coins.for:23-420), whole zone range. */
 void fo_correct_coins(const i32 *p, double *rop)
@@ -594,7 +798,7 @@ void fo_correct_coins(const i32 *p, double *rop)
  * (Fast/FastS/FastS/BC/BCzone.cpp:193-226,560-568; table layout
  * Fast/FastC/FastC/PyTree.py:2958-3014), then the edge/corner fix
  * (Fast/FastS/FastS/Compute/bcs.cpp:30-41). Returns -1 on an unsupported BC tag. */
-int fo_bczone(const i32 *p, double *rop)
+int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, const double *tj, const double *tk)
 {
   const int pt_bcs = p[PT_BC], nb = p[pt_bcs];
   i32 sdm[6] = {1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2]}, cl[6];
@@ -603,6 +807,12 @@ int fo_bczone(const i32 *p, double *rop)
     if (fo_indice_cl(idir, p, p + pt + 2, sdm, cl)) continue;
     if (type == 11) fo_bc_periodic(p, idir, cl, rop);
     else if (type == 22) continue;
+    else if (type == 0) fo_bc_extrapolate(p, idir, cl, rop);
+    else if (type == 1) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
+    else if (p[KFLUDOM] == 5 && type >= 3 && type <= 6)
+      return -1; /* roe + walls: the wall-face flux correction (BC/bfl3.for) is not restated */
+    else if (type == 3 || (type == 4 && p[IFLOW] == 1) || type == 5) fo_bc_wall_inviscid(p, idir, cl, rop, ti, tj, tk);
+    else if ((type == 6 || type == 4) && p[IFLOW] > 1) fo_bc_wall_viscous(p, idir, cl, rop);
     else return -1;
   }
   fo_correct_coins(p, rop);
@@ -650,7 +860,7 @@ int fo_step(const i32 *p, const double *pr, double *ro, double *ro_p1, double *d
     double *out = (nstep % 2 == 1) ? ro_p1 : ro;
     fo_subiter(p, pr, nstep, in, out, drodm, coe, xmut, wig, ti, tj, tk, vol);
     if (nstep == 1 && stage1_rhs) memcpy(stage1_rhs, drodm, sizeof(double) * 5 * (size_t)p[NDIMDX]);
-    if (fo_bczone(p, out)) return -1;
+    if (fo_bczone(p, pr, out, ti, tj, tk)) return -1;
   }
   return 0;
 }

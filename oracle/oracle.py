@@ -58,7 +58,7 @@ class OracleZone:
         self.stage1_rhs = np.zeros(n)
 
     def fill_ghostcells(self):
-        if lib().fo_bczone(_p(self.pint), _p(self.ro)) != 0:
+        if lib().fo_bczone(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ti), _p(self.tj), _p(self.tk)) != 0:
             raise NotImplementedError("oracle: unsupported BC tag")
 
     def step(self):
@@ -92,7 +92,8 @@ class OracleZone:
             self.stage1_rhs[:] = self.drodm
 
     def bcs(self, nstep):
-        if lib().fo_bczone(_p(self.pint), _p(self.roles(nstep)[1])) != 0:
+        if lib().fo_bczone(_p(self.pint), _p(self.preal), _p(self.roles(nstep)[1]), _p(self.ti), _p(self.tj),
+                           _p(self.tk)) != 0:
             raise NotImplementedError("oracle: unsupported BC tag")
 
     def rotate(self):

@@ -207,6 +207,19 @@ class RefSolver:
                                     _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
             elif btype == 22:
                 pass   # BCOverlap: ghost cells come from the join transfer
+            elif btype in (1, 3, 4, 5, 6):
+                # dispatch of Fast/FastS/FastS/BC/BCzone.cpp:279-283,451-461,513-523 (these use ind_CL)
+                if btype == 1:
+                    fn = L.bvbs_farfield_
+                elif btype == 3 or (btype == 4 and p[IFLOW] == 1) or btype == 5:
+                    fn = L.bvbs_wall_inviscid_
+                elif p[IFLOW] > 1:
+                    fn = L.bvbs_wall_viscous_adia_
+                else:
+                    raise NotImplementedError("ref_harness: BC tag %d with IFLOW %d" % (btype, p[IFLOW]))
+                fn(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl),
+                   _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+                   _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
             else:
                 raise NotImplementedError("ref_harness: BC tag %d" % btype)
         L.correct_coins_(_i(nd), _p(p), _p(zn.ind_dm), _p(rop))

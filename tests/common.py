@@ -3,6 +3,9 @@ import numpy as np
 from fast_amd import cases, FastC, Internal
 
 
+SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+
+
 def prepare(t):
     """Host-side preparation without touching the GPU (what warmup does before creating the
     device context)."""

@@ -37,23 +37,31 @@ CASES = {
     'vortex12_roe_euler':       ('vortex', 12, 'roe', None, (1, 1, 1), 'single', 100),
     'tgv_ragged_senseur_lamin': ('tgv', (13, 6, 9), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 5),
     'tgv_2x2_senseur_lamin':    ('tgv', (8, 12, 20), 'senseur', 'NSLaminar', (1, 2, 2), 'single', 10),
+    'channel_senseur_lamin':    ('tgv', (12, 10, 8), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 20,
+                                 {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}),
+    'box_farfield_ausmpred':    ('tgv', (9, 8, 10), 'ausmpred', 'NSLaminar', (1, 1, 1), 'single', 20,
+                                 {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')}),
+    'box_mixed_bc_euler':       ('tgv', (8, 9, 7), 'ausmpred', 'Euler', (1, 1, 1), 'single', 10,
+                                 {'imin': 'BCExtrapolate', 'imax': 'BCFarfield', 'jmin': 'BCWall',
+                                  'jmax': 'BCSymmetryPlane', 'kmin': 'BCWallInviscid'}),
     'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
     'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
 }
 
 
-def build(kind, n, scheme, model, blocks, cache):
+def build(kind, n, scheme, model, blocks, cache, bcs=None):
     extra = SINGLE if cache == 'single' else None
     if kind == 'tgv':
-        return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra)
+        return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra, bcs=bcs)
     return cases.vortex(n, scheme, extra_numz=extra)
 
 
 def main():
     if not R.available():
         raise SystemExit("make_golden: oracle/_ref/libfast_ref.so is missing (python oracle/build_ref.py)")
-    for name, (kind, n, scheme, model, blocks, cache, nit) in CASES.items():
-        t = build(kind, n, scheme, model, blocks, cache)
+    for name, spec in CASES.items():
+        (kind, n, scheme, model, blocks, cache, nit) = spec[:7]
+        t = build(kind, n, scheme, model, blocks, cache, spec[7] if len(spec) > 7 else None)
         metrics = prepare(t)
         zones = Internal.getZones(t)
         nb = len(zones)

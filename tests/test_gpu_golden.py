@@ -22,15 +22,23 @@ CASES = {
     'vortex12_roe_euler':       ('vortex', 12, 'roe', None, (1, 1, 1)),
     'tgv_ragged_senseur_lamin': ('tgv', (13, 6, 9), 'senseur', 'NSLaminar', (1, 1, 1)),
     'tgv_2x2_senseur_lamin':    ('tgv', (8, 12, 20), 'senseur', 'NSLaminar', (1, 2, 2)),
+    'channel_senseur_lamin':    ('tgv', (12, 10, 8), 'senseur', 'NSLaminar', (1, 1, 1),
+                                 {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}),
+    'box_farfield_ausmpred':    ('tgv', (9, 8, 10), 'ausmpred', 'NSLaminar', (1, 1, 1),
+                                 {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')}),
+    'box_mixed_bc_euler':       ('tgv', (8, 9, 7), 'ausmpred', 'Euler', (1, 1, 1),
+                                 {'imin': 'BCExtrapolate', 'imax': 'BCFarfield', 'jmin': 'BCWall',
+                                  'jmax': 'BCSymmetryPlane', 'kmin': 'BCWallInviscid'}),
 }
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_gpu_equals_reference_golden(name):
-    kind, n, scheme, model, blocks = CASES[name]
+    kind, n, scheme, model, blocks = CASES[name][:5]
+    bcs = CASES[name][5] if len(CASES[name]) > 5 else None
     g = np.load(os.path.join(HERE, 'golden', name + '.npz'))
     if kind == 'tgv':
-        t = cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=SINGLE, modulo_verif=1)
+        t = cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=SINGLE, modulo_verif=1, bcs=bcs)
     else:
         t = cases.vortex(n, scheme, extra_numz=SINGLE)
         FastC._setNum2Base(t, {'temporal_scheme': 'explicit', 'modulo_verif': 1})

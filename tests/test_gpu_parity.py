@@ -39,3 +39,45 @@ def test_bit_exact_vs_oracle(kind, n, scheme, model, nit):
         assert np.array_equal(got, oz.ro), \
             "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
     l2, loo = FastS.display_temporal_criteria(t, metrics, 1, format='none')[z[0]]
+
+
+FAR = {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')}
+BC_CASES = [
+    ('NSLaminar', 'senseur', (70, 9, 12), {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}),
+    ('NSLaminar', 'ausmpred', (12, 10, 9), {'imin': 'BCWall', 'imax': 'BCWall', 'kmin': 'BCWallViscous'}),
+    ('Euler', 'senseur', (10, 12, 9), {'jmin': 'BCWall', 'kmax': 'BCWallInviscid', 'imin': 'BCSymmetryPlane'}),
+    ('NSLaminar', 'senseur', (9, 8, 10), FAR),
+    ('Euler', 'roe', (8, 9, 7), {'imin': 'BCExtrapolate', 'imax': 'BCFarfield', 'kmin': 'BCExtrapolate'}),
+]
+
+
+@pytest.mark.parametrize("model,scheme,n,bcs", BC_CASES)
+def test_boundary_conditions_bit_exact(model, scheme, n, bcs):
+    from fast_amd import cases
+    from common import SINGLE
+    t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, bcs=bcs)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()                                     # idempotent on a correctly filled field
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)      # ghost fill of the initial field
+    for it in range(1, 7):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        same = np.array_equal(got, oz.ro)
+        assert same, "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+
+
+def test_unsupported_options_are_refused():
+    from fast_amd import cases
+    t = cases.tgv(8, 'roe', model='Euler', bcs={'jmin': 'BCWall'})
+    with pytest.raises(_capi.FastsHipError, match="wall-face flux correction"):
+        FastS.warmup(t, None)
+    t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCInflow'})
+    with pytest.raises(_capi.FastsHipError, match="tag 13"):
+        FastS.warmup(t, None)
+    t = cases.tgv(8, 'senseur', temporal_scheme='implicit')
+    with pytest.raises(_capi.FastsHipError, match="explicit"):
+        FastS.warmup(t, None)
