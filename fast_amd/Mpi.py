@@ -127,7 +127,7 @@ class HaloExchange:
             if self.sync is not None:
                 self.sync()
             for p in peers:
-                self.hs[p].copy_(self.sbuf[p])
+                self.hs[p].copy_(self.sbuf[p])      # stream-ordered after the pack kernels, blocking
         wire_s = self.hs if self.staged else self.sbuf
         wire_r = self.hr if self.staged else self.rbuf
         for p in peers:
@@ -162,8 +162,15 @@ def register_plan(ctx, plan, names):
 
 def _exchange(ctx, halo, nstep):
     """nstep >= 1: on the output level of that sub-iteration; nstep <= 0: on time level -nstep."""
-    halo.run(lambda p, b: ctx.halo_pack(nstep, p, b.data_ptr(), b.numel()),
-             lambda p, b: ctx.halo_unpack(nstep, p, b.data_ptr(), b.numel()))
+    import torch
+    pack = lambda p, b: ctx.halo_pack(nstep, p, b.data_ptr(), b.numel())
+    unpack = lambda p, b: ctx.halo_unpack(nstep, p, b.data_ptr(), b.numel())
+    stream = getattr(halo, 'stream', None)
+    if stream is None:
+        halo.run(pack, unpack)
+    else:
+        with torch.cuda.stream(stream):
+            halo.run(pack, unpack)
 
 
 def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_graph=None, Padding=None,
@@ -179,26 +186,51 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     zones, metrics, dtloc = FastS._warmup_host(t, tc, Padding)
     torch.cuda.set_device(device)
     ctx, names = FastS._new_context(zones, metrics, dtloc, device)
-    # kernels and RCCL messages are ordered on one stream: torch's current stream of this device
-    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    # kernels and RCCL messages are ordered on ONE explicit (non-default) torch stream: the library
+    # launches on it (fs_set_stream) and the messages are posted while it is torch's current stream,
+    # so RCCL's event hand-shake orders them after the pack kernels and before the unpack kernels
+    # A second stream carries pack -> messages -> unpack so that they overlap the tiles of a stage that
+    # do not feed a message (fs_stage_part); events order the two streams.
+    main = torch.cuda.Stream(device=device)
+    comm = torch.cuda.Stream(device=device)
+    ctx.set_stream(main.cuda_stream)
+    ctx.set_comm_stream(comm.cuda_stream)
     plan = HaloPlan(FastS.joins_from_tc(t, tc), procDict, r, n)
     register_plan(ctx, plan, names)
     ctx.upload()
     hook = FastS._set_hook(ctx, dtloc, names, mpi=1)
-    halo = HaloExchange(plan, torch.device('cuda', device), sync=ctx.sync)
+    with torch.cuda.stream(comm):
+        halo = HaloExchange(plan, torch.device('cuda', device))
+    halo.stream = comm
+    halo.main = main
+    halo.overlap = os.environ.get('FASTS_HIP_OVERLAP', '1') != '0'
     hook['halo'] = halo
     # ghost cells of the initial field
+    comm.wait_stream(main)
     _exchange(ctx, halo, -_capi.FS_LEVEL_N)
+    main.wait_stream(comm)
     ctx.fill_ghostcells(_capi.FS_LEVEL_N)
     ctx.download(_capi.FS_LEVEL_N)
     return (t, tc, metrics)
 
 
 def _steps(ctx, halo, nitrun, nitmax, nit=1):
+    main, comm = getattr(halo, 'main', None), getattr(halo, 'stream', None)
     for it in range(nit):
         for nstep in range(1, nitmax + 1):
-            ctx.stage(nitrun * nit + it, nstep)
+            n = nitrun * nit + it
+            if main is not None and getattr(halo, 'overlap', False):
+                ctx.stage_part(n, nstep, 0)          # tiles that feed the messages
+                donors_ready = main.record_event()
+                ctx.stage_part(n, nstep, 1)          # everything else, overlapped with the messages
+                comm.wait_event(donors_ready)
+            else:
+                ctx.stage(n, nstep)
+                if main is not None:
+                    comm.wait_stream(main)
             _exchange(ctx, halo, nstep)
+            if main is not None:
+                main.wait_stream(comm)
             ctx.local_joins(nstep)
             ctx.bcs(nstep)
         if nitmax % 2 == 1:

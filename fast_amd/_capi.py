@@ -15,7 +15,7 @@ FS_LEVEL_N, FS_LEVEL_M1, FS_LEVEL_P1 = 1, 2, 4
 SYMBOLS = [
     "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif",
     "fs_zone_add", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
-    "fs_stage", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
+    "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
 ]
@@ -134,6 +134,13 @@ class Context:
 
     def stage(self, nitrun, nstep):
         self._chk(lib().fs_stage(self._h, ctypes.c_int(nitrun), ctypes.c_int(nstep)), "fs_stage")
+
+    def stage_part(self, nitrun, nstep, part):
+        self._chk(lib().fs_stage_part(self._h, ctypes.c_int(nitrun), ctypes.c_int(nstep), ctypes.c_int(part)),
+                  "fs_stage_part")
+
+    def set_comm_stream(self, stream_ptr):
+        self._chk(lib().fs_set_comm_stream(self._h, ctypes.c_void_p(stream_ptr)), "fs_set_comm_stream")
 
     def halo_count(self, peer_tag, is_send):
         return self._chk(lib().fs_halo_count(self._h, ctypes.c_int(peer_tag), ctypes.c_int(int(is_send))),

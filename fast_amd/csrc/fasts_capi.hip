@@ -32,6 +32,10 @@ struct Zone {
   std::vector<FsBcWin> bc;
   long long bc_max_cells = 0;
   bool have_res = false;
+  // stage-kernel tiles that hold donor cells of joins to other contexts ("shell") and the others
+  int *shell_dev = nullptr, *inner_dev = nullptr;
+  int n_shell = 0, n_inner = 0;
+  hipEvent_t ev_part = nullptr;   // start of a split stage (timing)
 };
 
 struct Join {
@@ -42,6 +46,7 @@ struct Join {
 struct Send {
   int donor_zone, peer_tag, npts;
   int *pts_dev = nullptr;
+  std::vector<int32_t> pts_host;
 };
 
 }  // namespace
@@ -49,6 +54,7 @@ struct Send {
 struct fs_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t comm_stream = nullptr;   // halo pack / unpack launch here when set (fs_set_comm_stream)
   std::vector<Zone> zones;
   std::vector<Join> joins;
   std::vector<Send> sends;
@@ -124,6 +130,8 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     for (int r = 0; r < 3; r++) (void)hipFree(zn.dev[r]);
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev);
+    (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev);
+    if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
   }
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
   for (auto &s : ctx->sends) (void)hipFree(s.pts_dev);
@@ -320,9 +328,12 @@ extern "C" int fs_send_add(fs_ctx *ctx, int donor_zone, int peer_tag, const int3
   (void)hipSetDevice(ctx->device);
   HIPCHK(ctx, hipMalloc(&s.pts_dev, sizeof(int) * npts));
   HIPCHK(ctx, hipMemcpy(s.pts_dev, donor_pts, sizeof(int) * npts, hipMemcpyHostToDevice));
+  s.pts_host.assign(donor_pts, donor_pts + npts);
   ctx->sends.push_back(s);
   return FS_OK;
 }
+
+static int build_shell_lists(fs_ctx *ctx);
 
 extern "C" int fs_upload(fs_ctx *ctx)
 {
@@ -354,6 +365,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
       HIPCHK(ctx, hipMemcpyAsync(zn.dev[r], zn.host[r], nb, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (!ctx->uploaded && ctx->dma_stage && !ctx->plain_stage) {
+    int rc = build_shell_lists(ctx);
+    if (rc) return rc;
+  }
   ctx->uploaded = true;
   return FS_OK;
 }
@@ -406,47 +421,125 @@ static int ensure_ready(fs_ctx *ctx, const char *who)
   return FS_OK;
 }
 
-extern "C" int fs_stage(fs_ctx *ctx, int nitrun, int nstep)
+// Tiles of the stage kernel that contain donor cells of joins to other contexts: their results are
+// what the halo messages carry, so they can be computed (and sent) first.
+static int build_shell_lists(fs_ctx *ctx)
 {
-  int rc = ensure_ready(ctx, "fs_stage");
+  for (size_t nz = 0; nz < ctx->zones.size(); nz++) {
+    Zone &zn = ctx->zones[nz];
+    const FsZone &z = zn.z;
+    const FsTiling t = fsk_stage_dma_tiling(z);
+    const int nblk = t.nti * t.ntj * t.ntk;
+    std::vector<char> mark((size_t)nblk, 0);
+    bool any = false;
+    for (auto &s : ctx->sends) {
+      if (s.donor_zone != (int)nz) continue;
+      any = true;
+      for (int n = 0; n < s.npts; n++) {
+        const long long l = s.pts_host[n];
+        const int i = (int)(l % z.ni) - z.ific + 1, j = (int)((l / z.ni) % z.nj) - z.ific + 1;
+        const int k = (int)(l / ((long long)z.ni * z.nj)) - z.ifick + 1;
+        if (i < 1 || i > z.iv || j < 1 || j > z.jv || k < 1 || k > z.kv) continue;   // ghost donors: not computed
+        const int bi = (i - 1) / t.ti, bj = (j - 1) / t.tj, bk = (k - 1) / t.kchunk;
+        mark[(size_t)bi + (size_t)t.nti * (bj + (size_t)t.ntj * bk)] = 1;
+      }
+    }
+    if (!any) continue;
+    std::vector<int> shell, inner;
+    for (int b = 0; b < nblk; b++) (mark[b] ? shell : inner).push_back(b);
+    zn.n_shell = (int)shell.size(); zn.n_inner = (int)inner.size();
+    if (zn.n_shell) {
+      HIPCHK(ctx, hipMalloc(&zn.shell_dev, sizeof(int) * shell.size()));
+      HIPCHK(ctx, hipMemcpy(zn.shell_dev, shell.data(), sizeof(int) * shell.size(), hipMemcpyHostToDevice));
+    }
+    if (zn.n_inner) {
+      HIPCHK(ctx, hipMalloc(&zn.inner_dev, sizeof(int) * inner.size()));
+      HIPCHK(ctx, hipMemcpy(zn.inner_dev, inner.data(), sizeof(int) * inner.size(), hipMemcpyHostToDevice));
+    }
+  }
+  return FS_OK;
+}
+
+// part < 0: the whole stage.  part 0: viscosity + the shell tiles.  part 1: the remaining tiles
+// (+ residual norms).  Zones without joins to other contexts run entirely in part 1.
+static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *who)
+{
+  int rc = ensure_ready(ctx, who);
   if (rc) return rc;
+  if (part >= 0 && !(ctx->dma_stage && !ctx->plain_stage))
+    return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": split stages need the default stage kernel");
   for (auto &zn : ctx->zones) {
     const FsZone &z = zn.z;
-    if (nstep < 1 || nstep > z.nssiter) return fail(ctx, FS_ERR_ARG, "fs_stage: sub-iteration out of range");
+    if (nstep < 1 || nstep > z.nssiter) return fail(ctx, FS_ERR_ARG, std::string(who) + ": sub-iteration out of range");
     int in, out;
     stage_roles(nstep, in, out);
     double coefH, coefW;
     rk_coefs(z.rk, nstep, coefH, coefW);
-    if (nstep == 1) {
+    const bool split = part >= 0 && zn.n_shell > 0;
+    const bool opens = part <= 0 || !split;      // this call starts the stage of this zone
+    const bool closes = part != 0;               // this call ends it (part 0 of an unsplit zone does nothing)
+    if (part == 0 && !split) continue;
+    if (opens && nstep == 1) {
       if (z.iflow == 2) fsk_invist(z, zn.dev[in], zn.xmut, ctx->stream);
       if (z.kflu == 2 && ctx->plain_stage) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
+    if (ctx->timing && opens) {
+      if (!zn.ev_part) HIPCHK(ctx, hipEventCreate(&zn.ev_part));
+      HIPCHK(ctx, hipEventRecord(zn.ev_part, ctx->stream));
+    }
+    int krc = 0;
+    if (ctx->plain_stage)
+      krc = fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
+    else if (!ctx->dma_stage)
+      krc = fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
+                            (unsigned char *)zn.wig, ctx->stream);
+    else {
+      const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
+      const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
+      if (!split || nlist > 0)
+        krc = fsk_stage_dma(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
+                            (unsigned char *)zn.wig, blist, nlist, ctx->stream);
+    }
+    if (krc)
+      return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": no kernel for this scheme / model");
+    if (!closes) continue;
+    if (ctx->timing) {   // one timed interval per stage, from its first launch to its last
       if (ctx->ev_used == ctx->ev.size()) {
         hipEvent_t a, b;
         HIPCHK(ctx, hipEventCreate(&a));
         HIPCHK(ctx, hipEventCreate(&b));
         ctx->ev.emplace_back(a, b);
       }
-      e0 = ctx->ev[ctx->ev_used].first; e1 = ctx->ev[ctx->ev_used].second;
+      std::swap(ctx->ev[ctx->ev_used].first, zn.ev_part);
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used].second, ctx->stream));
       ctx->ev_used++;
-      HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     }
-    const int krc = ctx->plain_stage
-        ? fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream)
-        : (ctx->dma_stage
-               ? fsk_stage_dma(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, (unsigned char *)zn.wig, ctx->stream)
-               : fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, (unsigned char *)zn.wig, ctx->stream));
-    if (krc)
-      return fail(ctx, FS_ERR_UNSUPPORTED, "fs_stage: no kernel for this scheme / model");
-    if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     if (nstep == 1 && (nitrun % ctx->modulo_verif == 0 || nitrun == 1)) {
       fsk_residual(z, zn.drodm, zn.res_part, zn.res_out, ctx->stream);
       zn.have_res = true;
     }
   }
   HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_stage_part(fs_ctx *ctx, int nitrun, int nstep, int part)
+{
+  if (part != 0 && part != 1) return ctx ? fail(ctx, FS_ERR_ARG, "fs_stage_part: part must be 0 or 1") : FS_ERR_ARG;
+  return stage_impl(ctx, nitrun, nstep, part, "fs_stage_part");
+}
+
+extern "C" int fs_set_comm_stream(fs_ctx *ctx, void *hip_stream)
+{
+  if (!ctx) return FS_ERR_ARG;
+  ctx->comm_stream = (hipStream_t)hip_stream;
+  return FS_OK;
+}
+
+extern "C" int fs_stage(fs_ctx *ctx, int nitrun, int nstep)
+{
+  int rc = stage_impl(ctx, nitrun, nstep, -1, "fs_stage");
+  if (rc) return rc;
   return FS_OK;
 }
 
@@ -532,7 +625,8 @@ extern "C" int fs_halo_pack(fs_ctx *ctx, int nstep, int peer_tag, double *dev_bu
   for (auto &s : ctx->sends) {
     if (s.peer_tag != peer_tag) continue;
     Zone &zd = ctx->zones[s.donor_zone];
-    fsk_halo_pack(s.npts, zd.z.neq, zd.z.nd, s.pts_dev, zd.dev[out], dev_buf + off, ctx->stream);
+    fsk_halo_pack(s.npts, zd.z.neq, zd.z.nd, s.pts_dev, zd.dev[out], dev_buf + off,
+                  ctx->comm_stream ? ctx->comm_stream : ctx->stream);
     off += (long long)s.npts * zd.z.neq;
   }
   HIPCHK(ctx, hipGetLastError());
@@ -551,7 +645,8 @@ extern "C" int fs_halo_unpack(fs_ctx *ctx, int nstep, int peer_tag, const double
   for (auto &j : ctx->joins) {
     if (j.donor_zone >= 0 || j.peer_tag != peer_tag) continue;
     Zone &zr = ctx->zones[j.rcv_zone];
-    fsk_halo_unpack(j.npts, zr.z.neq, zr.z.nd, j.rcv_dev, zr.dev[out], dev_buf + off, ctx->stream);
+    fsk_halo_unpack(j.npts, zr.z.neq, zr.z.nd, j.rcv_dev, zr.dev[out], dev_buf + off,
+                    ctx->comm_stream ? ctx->comm_stream : ctx->stream);
     off += (long long)j.npts * zr.z.neq;
   }
   HIPCHK(ctx, hipGetLastError());

@@ -24,9 +24,13 @@ int fsk_stage(const FsZone &z, double coefH, double coefW, int first, const doub
 // tiled stage kernel (fasts_stage.hip); at the first stage it also evaluates and stores the sensor
 int fsk_stage_tiled(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                     double *drodm, const double *xmut, unsigned char *wig, hipStream_t s);
-// same contract, planes staged by LDS-DMA (fasts_stage_dma.hip)
+// same contract, planes staged by LDS-DMA (fasts_stage_dma.hip).  The zone is cut in nti x ntj x ntk
+// tiles of ti x tj x kchunk cells, numbered bi + nti*(bj + ntj*bk); blist (device, nlist entries)
+// restricts a launch to a subset of the tiles, NULL launches all of them.
+struct FsTiling { int nti, ntj, ntk, kchunk, ti, tj; };
+FsTiling fsk_stage_dma_tiling(const FsZone &z);
 int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                  double *drodm, const double *xmut, unsigned char *wig, hipStream_t s);
+                  double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, hipStream_t s);
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop,
                     hipStream_t s);
 void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);

@@ -110,7 +110,7 @@ template <int KFLU, int IFLOW, bool FIRST, bool WIDE>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int ntile_j, int nblk,
             const double *__restrict__ rop, double *__restrict__ rop_out, double *__restrict__ drodm,
-            const double *__restrict__ xmut, unsigned char *__restrict__ wig)
+            const double *__restrict__ xmut, unsigned char *__restrict__ wig, const int *__restrict__ blist)
 {
   __shared__ Smem sm;
   // blocks that share an XCD (same blockIdx % 8) get consecutive tiles, so halo rows of
@@ -120,6 +120,7 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
     const int q8 = nblk / 8, r8 = nblk % 8, x = bid % 8;
     bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + bid / 8;
   }
+  if (blist) bid = blist[bid];   // a subset of the tiles (tile number = bi + nti*(bj + ntj*bk))
   const int bi = bid % ntile_i;
   const int bj = (bid / ntile_i) % ntile_j;
   const int bk = bid / (ntile_i * ntile_j);
@@ -379,22 +380,17 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
 
 template <int KFLU, int IFLOW>
 void launch(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-            double *drodm, const double *xmut, unsigned char *wig, hipStream_t s)
+            double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, hipStream_t s)
 {
-  // the face i = iv+1 is evaluated by lane iv - i0 of the last tile, or by its edge pass
-  const int nti = (z.iv + TI - 1) / TI;
-  const int ntj = (z.jv + TJ - 1) / TJ;
-  int kchunk = 32;
-  if (const char *ev = getenv("FASTS_HIP_KCHUNK")) kchunk = atoi(ev) > 0 ? atoi(ev) : kchunk;   // tuning aid
-  if (z.kv < kchunk) kchunk = z.kv;
-  const int ntk = (z.kv + kchunk - 1) / kchunk;
-  const int nblk = nti * ntj * ntk;
+  const FsTiling t = fsk_stage_dma_tiling(z);
+  const int nblk = blist ? nlist : t.nti * t.ntj * t.ntk;
+  if (nblk <= 0) return;
   // 16-byte DMA needs pairs of cells that are 16-byte aligned in every row and plane
   const bool wide = z.ni % 2 == 0 && z.nd % 2 == 0 && z.ific % 2 == 0 && ((uintptr_t)rop % 16 == 0) &&
                     (xmut == nullptr || (uintptr_t)xmut % 16 == 0);
 #define FS_LAUNCH(FIRST_, WIDE_)                                                                       \
   hipLaunchKernelGGL((k_stage_dma<KFLU, IFLOW, FIRST_, WIDE_>), dim3(nblk), dim3(NTHREADS), 0, s, z, coefH, coefW, \
-                     kchunk, nti, ntj, nblk, rop, rop_out, drodm, xmut, wig)
+                     t.kchunk, t.nti, t.ntj, nblk, rop, rop_out, drodm, xmut, wig, blist)
   if (first) { if (wide) FS_LAUNCH(true, true); else FS_LAUNCH(true, false); }
   else       { if (wide) FS_LAUNCH(false, true); else FS_LAUNCH(false, false); }
 #undef FS_LAUNCH
@@ -409,14 +405,28 @@ extern "C" int fs_stamp_fetch(long long *host)
 }
 #endif
 
+FsTiling fsk_stage_dma_tiling(const FsZone &z)
+{
+  FsTiling t;
+  t.ti = TI; t.tj = TJ;
+  // the face i = iv+1 is evaluated by lane iv - i0 of the last tile, or by its edge pass
+  t.nti = (z.iv + TI - 1) / TI;
+  t.ntj = (z.jv + TJ - 1) / TJ;
+  t.kchunk = 32;
+  if (const char *ev = getenv("FASTS_HIP_KCHUNK")) t.kchunk = atoi(ev) > 0 ? atoi(ev) : t.kchunk;   // tuning aid
+  if (z.kv < t.kchunk) t.kchunk = z.kv;
+  t.ntk = (z.kv + t.kchunk - 1) / t.kchunk;
+  return t;
+}
+
 int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                  double *drodm, const double *xmut, unsigned char *wig, hipStream_t s)
+                  double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, hipStream_t s)
 {
   // one k-plane must stay below 4 GiB / 8 so that in-plane byte offsets fit 32 bits
   if ((long long)z.ni * z.nj >= (1ll << 28)) return -2;
 #define FS_CASE(K, F)                                                                       \
   if (z.kflu == K && z.iflow == F) {                                                        \
-    launch<K, F>(z, coefH, coefW, first, rop, rop_out, drodm, xmut, wig, s);                \
+    launch<K, F>(z, coefH, coefW, first, rop, rop_out, drodm, xmut, wig, blist, nlist, s);  \
     return 0;                                                                               \
   }
   FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)

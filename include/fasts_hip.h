@@ -118,6 +118,15 @@ int fs_compute(fs_ctx *ctx, int nitrun, int nstep_deb, int nstep_fin, int nit_c,
  *   fs_bcs            BCs + edge/corner fix on the stage output  (gsdr3.cpp:403-422, bcs.cpp:30-41)
  *   fs_rotate         M1 <- N <- P1 <- M1                        (computePT.cpp:673-677)        */
 int fs_stage(fs_ctx *ctx, int nitrun, int nstep);
+/* fs_stage in two launches, so that halo messages overlap the bulk of the computation (the
+ * reference runs its transfers after the whole RHS + update, Fast/FastS/FastS/Compute/gsdr3.cpp:251-349,
+ * transfert_multiblock.cpp:11-45; the results are the same): part 0 = the tiles holding donor cells
+ * of joins to other contexts, part 1 = everything else.  After part 0 the donor cells of this
+ * sub-iteration are final and fs_halo_pack may run on another stream. */
+int fs_stage_part(fs_ctx *ctx, int nitrun, int nstep, int part);
+/* Stream (hipStream_t as void*) on which fs_halo_pack / fs_halo_unpack launch; NULL = the context's
+ * stream.  The caller orders the two streams with events. */
+int fs_set_comm_stream(fs_ctx *ctx, void *hip_stream);
 int fs_halo_count(fs_ctx *ctx, int peer_tag, int is_send);
 int fs_halo_pack(fs_ctx *ctx, int nstep, int peer_tag, double *dev_buf, int n_doubles);
 int fs_halo_unpack(fs_ctx *ctx, int nstep, int peer_tag, const double *dev_buf, int n_doubles);

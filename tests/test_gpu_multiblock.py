@@ -75,8 +75,9 @@ def _two_plans(blocks, nv, names):
     return [FastSmpi.HaloPlan(joins_of(r), procDict, r, 2, all_gather_object=gather_for(r)) for r in range(2)]
 
 
-@pytest.mark.parametrize("blocks,nn", [((1, 1, 2), (10, 8, 12)), ((2, 1, 1), (140, 6, 5))])
-def test_two_contexts_exchange_through_the_split_calls(blocks, nn):
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("blocks,nn", [((1, 1, 2), (10, 8, 140)), ((2, 1, 1), (140, 6, 5)), ((1, 2, 1), (40, 36, 9))])
+def test_two_contexts_exchange_through_the_split_calls(blocks, nn, split):
     import torch
     s = _oracle_job(nn, blocks, 'senseur', 'NSLaminar')
     nv = tuple(nn[d] // blocks[d] for d in range(3))
@@ -115,7 +116,11 @@ def test_two_contexts_exchange_through_the_split_calls(blocks, nn):
     for it in range(1, 4):
         for nstep in (1, 2, 3):
             for c in ctxs:
-                c.stage(it, nstep)
+                if split:      # donor tiles first, the rest afterwards: same result
+                    c.stage_part(it, nstep, 0)
+                    c.stage_part(it, nstep, 1)
+                else:
+                    c.stage(it, nstep)
             exchange(nstep)
             for c in ctxs:
                 c.local_joins(nstep); c.bcs(nstep)
