@@ -467,6 +467,79 @@ def cart_metrics(x, y, z, ific, ifick):
     return ti, tj, tk, vol
 
 
+def general_metrics(x, y, z):
+    """ti, tj, tk (surface vectors of the i-, j-, k-min face of every cell, two-triangle average)
+    and vol of a curvilinear zone, ghost cells included, with the operand order of
+    Fast/FastC/FastC/Metric/cp_tijk.for:60-123 and cp_vol.for:55-93.  Arrays are dimensioned on the
+    nodes (ni,nj,nk) like the reference's (index = i + j*ni + k*ni*nj, NDIMDX_MTR = ni*nj*nk);
+    entries without a face or cell behind them stay 0.  Returns the flat buffer
+    [ti(:,1..3) | tj(:,1..3) | tk(:,1..3) | vol]."""
+    ni, nj, nk = x.shape
+    n = ni * nj * nk
+    X = [numpy.asarray(a, dtype=numpy.float64) for a in (x, y, z)]
+
+    def N(a, di, dj, dk, si, sj, sk):
+        """node a(i+di, j+dj, k+dk) for i in si etc."""
+        return a[si.start + di:si.stop + di, sj.start + dj:sj.stop + dj, sk.start + dk:sk.stop + dk]
+
+    def cross(p1, p0, p3, q0, c):
+        # component c of (p1-p0) x (p3-q0) written as in the reference:
+        #   tix = (y1-y0)*(z3-z0) - (z1-z0)*(y3-y0)
+        a, b = (c + 1) % 3, (c + 2) % 3
+        return (p1[a] - p0[a]) * (p3[b] - q0[b]) - (p1[b] - p0[b]) * (p3[a] - q0[a])
+
+    T = [numpy.zeros((3, ni, nj, nk)) for _ in range(3)]
+    full = slice(0, ni), slice(0, nj), slice(0, nk)
+    # I faces: nodes l0=(i,j,k) l1=(i,j+1,k) l2=(i,j,k+1) l3=(i,j+1,k+1); all i, cells in j,k
+    si, sj, sk = slice(0, ni), slice(0, nj - 1), slice(0, nk - 1)
+    l0 = [N(a, 0, 0, 0, si, sj, sk) for a in X]; l1 = [N(a, 0, 1, 0, si, sj, sk) for a in X]
+    l2 = [N(a, 0, 0, 1, si, sj, sk) for a in X]; l3 = [N(a, 0, 1, 1, si, sj, sk) for a in X]
+    for c in range(3):
+        t10 = cross(l1, l0, l3, l0, c)          # (l1-l0) x (l3-l0)
+        t11 = cross(l2, l3, l0, l2, c)          # (l2-l3) x (l0-l2)
+        T[0][c][si, sj, sk] = .5 * (t10 + t11)
+    # J faces: l0, l2=(i,j,k+1), l4=(i+1,j,k), l6=(i+1,j,k+1)
+    si, sj, sk = slice(0, ni - 1), slice(0, nj), slice(0, nk - 1)
+    l0 = [N(a, 0, 0, 0, si, sj, sk) for a in X]; l2 = [N(a, 0, 0, 1, si, sj, sk) for a in X]
+    l4 = [N(a, 1, 0, 0, si, sj, sk) for a in X]; l6 = [N(a, 1, 0, 1, si, sj, sk) for a in X]
+    for c in range(3):
+        t10 = cross(l0, l4, l2, l0, c)          # (l0-l4) x (l2-l0)
+        t11 = cross(l6, l2, l4, l6, c)          # (l6-l2) x (l4-l6)
+        T[1][c][si, sj, sk] = .5 * (t10 + t11)
+    # K faces: l0, l1=(i,j+1,k), l4, l5=(i+1,j+1,k)
+    si, sj, sk = slice(0, ni - 1), slice(0, nj - 1), slice(0, nk)
+    l0 = [N(a, 0, 0, 0, si, sj, sk) for a in X]; l1 = [N(a, 0, 1, 0, si, sj, sk) for a in X]
+    l4 = [N(a, 1, 0, 0, si, sj, sk) for a in X]; l5 = [N(a, 1, 1, 0, si, sj, sk) for a in X]
+    for c in range(3):
+        t10 = cross(l4, l0, l5, l4, c)          # (l4-l0) x (l5-l4)
+        t11 = cross(l1, l5, l0, l1, c)          # (l1-l5) x (l0-l1)
+        T[2][c][si, sj, sk] = .5 * (t10 + t11)
+    # volumes (cp_vol.for:55-93)
+    si, sj, sk = slice(0, ni - 1), slice(0, nj - 1), slice(0, nk - 1)
+    P = {m: [N(a, (m >> 2) & 1, m & 1, (m >> 1) & 1, si, sj, sk) for a in X] for m in range(8)}
+    # node numbering of the reference: l1 = +j, l2 = +k, l3 = +j+k, l4 = +i, l5 = +i+j, l6 = +i+k, l7 = all
+    tiL = [T[0][c][si, sj, sk] for c in range(3)]; tiP = [T[0][c][1:ni, 0:nj - 1, 0:nk - 1] for c in range(3)]
+    tjL = [T[1][c][si, sj, sk] for c in range(3)]; tjP = [T[1][c][0:ni - 1, 1:nj, 0:nk - 1] for c in range(3)]
+    tkL = [T[2][c][si, sj, sk] for c in range(3)]; tkP = [T[2][c][0:ni - 1, 0:nj - 1, 1:nk] for c in range(3)]
+    acc = []
+    for c in range(3):
+        q = {m: P[m][c] for m in range(8)}
+        acc.append(.25 * ((q[4] + q[5] + q[7] + q[6]) * tiP[c]
+                          - (q[0] + q[1] + q[3] + q[2]) * tiL[c]
+                          + (q[1] + q[3] + q[5] + q[7]) * tjP[c]
+                          - (q[0] + q[2] + q[4] + q[6]) * tjL[c]
+                          + (q[2] + q[3] + q[6] + q[7]) * tkP[c]
+                          - (q[0] + q[1] + q[4] + q[5]) * tkL[c]))
+    vol = numpy.zeros((ni, nj, nk))
+    vol[si, sj, sk] = numpy.maximum((acc[0] + acc[1] + acc[2]) / 3., 1.e-30)
+    out = numpy.zeros(10 * n)
+    for d in range(3):
+        for c in range(3):
+            out[(3 * d + c) * n:(3 * d + c + 1) * n] = T[d][c].reshape(-1, order='F')
+    out[9 * n:] = vol.reshape(-1, order='F')
+    return out
+
+
 def allocate_metric_zone(z, nssiter):
     """Fill the size/type entries of Parameter_int and return the per-zone ``metrics`` list
     ``[mtr, mtr0, vent, mtr_df, rdm, ind_dm, it_lu_ssdom, degen]``
@@ -549,9 +622,11 @@ def allocate_metric_zone(z, nssiter):
     mtr = numpy.zeros(ndimdx_mtr * neq_mtr, numpy.float64)
     if typ == 2:
         mtr[0:4] = cart_metrics(x, y, zz, ific, ifick)
+    elif typ == 0:
+        mtr[:] = general_metrics(x, y, zz)
     else:
-        raise ValueError("fast_amd: zone %s is not Cartesian with constant step (zone type %d); "
-                         "only zone type 2 is implemented on the device." % (z[0], typ))
+        raise ValueError("fast_amd: zone %s is k-homogeneous or two-dimensional (zone type %d); only "
+                         "Cartesian (2) and curvilinear (0) zones are implemented on the device." % (z[0], typ))
     degen = numpy.zeros(1, Internal.E_NpyInt)
     return [mtr, mtr, None, mtr, rdm, ind_dm, it_lu_ssdom, degen]
 

@@ -22,6 +22,20 @@ def _box(n, length, origin, name):
     return C.cart(o, h, (n[0] + 5, n[1] + 5, n[2] + 5), name=name)
 
 
+def _perturb(z, amp, L=2. * math.pi):
+    """Smooth node displacement of period L in every direction (amp in units of the local mesh
+    step): the zone stops being Cartesian and is classified curvilinear (zone type 0), while the
+    ghost nodes stay periodic images of interior nodes up to round-off."""
+    g = Internal.getNodeFromName1(z, Internal.__GridCoordinates__)
+    xs = [Internal.getNodeFromName1(g, n)[1] for n in ('CoordinateX', 'CoordinateY', 'CoordinateZ')]
+    h = [xs[0][1, 0, 0] - xs[0][0, 0, 0], xs[1][0, 1, 0] - xs[1][0, 0, 0], xs[2][0, 0, 1] - xs[2][0, 0, 0]]
+    w = 2. * math.pi / L
+    x, y, zc = [a.copy() for a in xs]
+    xs[0][...] = x + amp * h[0] * numpy.sin(w * y + 0.3) * numpy.cos(w * zc) * numpy.cos(w * x)
+    xs[1][...] = y + amp * h[1] * numpy.sin(w * zc + 0.7) * numpy.cos(w * x) * numpy.cos(w * y)
+    xs[2][...] = zc + amp * h[2] * numpy.sin(w * x + 1.1) * numpy.cos(w * y) * numpy.cos(w * zc)
+
+
 def _periodic_faces(z, faces=('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')):
     for f in faces:
         C.addBC2Zone(z, 'period ' + f, 'BCautoperiod', f)
@@ -45,11 +59,13 @@ def tgv_fields(t, state, L0=1.):
 
 
 def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
-        temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None, bcs=None):
+        temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None, bcs=None,
+        perturb=0.):
     """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
     whole box; blocks = (bi,bj,bk) split; only = block numbers to instantiate (the blocks of one
     rank; block b = ib + jb*bi + kb*bi*bj is named 'cart<b>').  Split directions carry no BC:
-    their ghost cells are filled by match joins (fast_amd.connect).  Returns t."""
+    their ghost cells are filled by match joins (fast_amd.connect).  perturb > 0 displaces the nodes
+    smoothly (see _perturb) so that the zones are curvilinear.  Returns t."""
     L1 = 2. * math.pi
     nn = (n, n, n) if isinstance(n, int) else tuple(n)
     nb = [nn[d] // blocks[d] for d in range(3)]
@@ -66,6 +82,8 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
                     continue
                 name = 'cart%d' % b
                 z = _box(nb, ln, org, name)
+                if perturb:
+                    _perturb(z, perturb, L1)
                 faces = []
                 if blocks[0] == 1: faces += ['imin', 'imax']
                 if blocks[1] == 1: faces += ['jmin', 'jmax']

@@ -158,7 +158,18 @@ typedef struct {
   double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
   double tcx, tcy, tcz, si, sj, sk, volinv;
   long nd, inc[3];
+  /* curvilinear zones (zone type 0): metric arrays ti,tj,tk(NDIMDX_MTR,3), vol(NDIMDX_MTR) */
+  int ityp;
+  const double *t[3], *vol;
+  long ndm, minc[3];
 } fluxctx;
+
+#define NIJK_MTR 5
+#define NDIMDX_MTR 43
+/* 0-based metric index (Fast/FastC/FastC/formule_mtr_param.h) */
+#define INDMTR(p, i, j, k)                                                                        \
+  ((long)((i) + (p)[NIJK_MTR + 3] - 1) * (p)[NIJK_MTR] + (long)((j) + (p)[NIJK_MTR + 3] - 1) * (p)[NIJK_MTR + 1] + \
+   (long)((k) + (p)[NIJK_MTR + 4] - 1) * (p)[NIJK_MTR + 2])
 
 /* Flux through the face between cell l-inc[dir] and cell l, direction dir (0 i, 1 j, 2 k).
  * Inviscid part: MUSCL o3 (Fast/FastS/FastS/Compute/Slope/o3_slope_var.for:2-3) then
@@ -363,9 +374,171 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
   flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
 }
 
+/* Same face flux on a curvilinear zone (zone type 0): lt = metric index of cell l.
+ *   normal, surface       Normale/normale_3dfull_{i,j,k}.for
+ *   normal velocity       Vit_ent/qn_3dfull_i.for
+ *   ausmpred / senseur    AUSM|SENSOR/3dfull/fluFaceEuler_o3_3dfull_i.for, Vit_ent/fluvector_3dfull_i.for
+ *   roe                   ROE/3dfull/fluFaceEuler_o3_3dfull_i.for, Vit_ent/fludiffer_3dfull_i.for
+ *   viscous               fluvisq_3dfull_{i,j,k}.for, mut_interface.for
+ * The three directions of the viscous fragment are one pattern: with a = dir+1, b = dir+2 (cyclic),
+ * the cross sums f3..f6 take the neighbours along a then b and the metrics of those directions. */
+static inline void face_flux_full(const fluxctx *c, const double *rop, const double *wig,
+                                  const double *xmut, long l, long lt, int dir, double *flu)
+{
+  const long nd = c->nd, inc = c->inc[dir], ndm = c->ndm;
+  const long nm = l - inc, nm2 = l - 2 * inc, np = l + inc;
+  const double *Tn = c->t[dir];
+  const double tcx = Tn[lt], tcy = Tn[lt + ndm], tcz = Tn[lt + 2 * ndm];
+  const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+  double qm[5], qp[5];
+  for (int e = 0; e < 5; e++) {
+    const double *q = rop + e * nd;
+    qm[e] = c->c4 * q[l] + c->c5 * q[nm] + c->c6 * q[np];
+    qp[e] = c->c4 * q[nm] + c->c6 * q[nm2] + c->c5 * q[l];
+  }
+  double flu1, flu2, flu3, flu4, flu5;
+  if (c->kflu == 5) {
+    const double gam = c->gam, rgp = c->rgp, gam1 = c->gam1, psiroe = c->psiroe;
+    double r1 = qp[0], p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * qp[4] * rgp + .5 * (qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+    double r2 = qm[0], p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * qm[4] * rgp + .5 * (qm[1] * qm[1] + qm[2] * qm[2] + qm[3] * qm[3]);
+    double qp1 = sqrt(r1), qm1 = sqrt(r2);
+    double r = qp1 * qm1;
+    double r_1 = 1. / (qp1 + qm1);
+    double u = (qp1 * qp[1] + qm1 * qm[1]) * r_1;
+    double v = (qp1 * qp[2] + qm1 * qm[2]) * r_1;
+    double w = (qp1 * qp[3] + qm1 * qm[3]) * r_1;
+    double h = (qp1 * h1 + qm1 * h2) * r_1;
+    double q = .5 * (u * u + v * v + w * w);
+    double cc = sqrt((gam - 1.) * fabs(h - q));
+    double qn1 = qp[1] * tcx + qp[2] * tcy + qp[3] * tcz;
+    double qn2 = qm[1] * tcx + qm[2] * tcy + qm[3] * tcz;
+    double du = (qm[1] - qp[1]) * s, dv = (qm[2] - qp[2]) * s, dw = (qm[3] - qp[3]) * s;
+    double dp = p2 - p1, dqn = qn2 - qn1;
+    double s_1 = 1.0 / dmax(s, 1.E-30);
+    double nx = tcx * s_1, ny = tcy * s_1, nz = tcz * s_1;
+    double qn = u * nx + v * ny + w * nz;
+    double f1 = qn;
+    double f4 = psiroe * (fabs(f1) + cc);
+    double f2 = 0.5 + dsign(0.5, fabs(f1) - f4);
+    double f3 = (f2 - 1.0) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (r2 - r1 - dp / (cc * cc)) * s;
+    flu1 = f3 * (f1);
+    flu2 = f3 * (f1 * u + r * (du - nx * dqn));
+    flu3 = f3 * (f1 * v + r * (dv - ny * dqn));
+    flu4 = f3 * (f1 * w + r * (dw - nz * dqn));
+    flu5 = f3 * (f1 * q + r * (u * du + v * dv + w * dw - qn * dqn));
+    f1 = qn + cc;
+    f2 = 0.5 + dsign(0.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * (u + nx * cc);
+    flu3 = flu3 + f1 * (v + ny * cc);
+    flu4 = flu4 + f1 * (w + nz * cc);
+    flu5 = flu5 + f1 * (h + qn * cc);
+    f1 = qn - cc;
+    f2 = 0.5 + dsign(0.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp - r * cc * dqn * s_1) / (2. * cc * cc) * f3 * s;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * (u - nx * cc);
+    flu3 = flu3 + f1 * (v - ny * cc);
+    flu4 = flu4 + f1 * (w - nz * cc);
+    flu5 = flu5 + f1 * (h - qn * cc);
+    double rou1 = r1 * qn1, rou2 = r2 * qn2, p1p2 = p1 + p2;
+    flu1 = (flu1 + rou1 + rou2) * 0.5;
+    flu2 = (flu2 + rou1 * qp[1] + rou2 * qm[1] + tcx * p1p2) * 0.5;
+    flu3 = (flu3 + rou1 * qp[2] + rou2 * qm[2] + tcy * p1p2) * 0.5;
+    flu4 = (flu4 + rou1 * qp[3] + rou2 * qm[3] + tcz * p1p2) * 0.5;
+    flu5 = (flu5 + rou1 * h1 + rou2 * h2) * 0.5;
+  } else {
+    const double rgp = c->rgp, gam1 = c->gam1;
+    double r1 = qp[0], rou1 = r1 * qp[1], rov1 = r1 * qp[2], row1 = r1 * qp[3];
+    double p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * p1 + .5 * (rou1 * qp[1] + rov1 * qp[2] + row1 * qp[3]);
+    double r2 = qm[0], rou2 = r2 * qm[1], rov2 = r2 * qm[2], row2 = r2 * qm[3];
+    double p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * p2 + .5 * (rou2 * qm[1] + rov2 * qm[2] + row2 * qm[3]);
+    double qn1 = qp[1] * tcx + qp[2] * tcy + qp[3] * tcz;
+    double qn2 = qm[1] * tcx + qm[2] * tcy + qm[3] * tcz;
+    double u, tdu;
+    if (c->kflu == 1) {
+      double cc = rgp * c->gam * rop[l + 4 * nd];
+      double son = sqrt(qn1 * qn1 / cc);
+      double tam = c->c3 * son + s;
+      double tam1 = dmax(0., tam) * c->c2;
+      u = 0.25 * (qn1 + qn2) - tam1 * (p2 - p1);
+      tdu = dmax(fabs(u), c->c1 * s);
+    } else {
+      double wg = wig[l + dir * nd];
+      u = 0.25 * (qn1 + qn2) - c->c2 * s * (p2 - p1) * (c->opt0 * wg + 1. - c->opt0);
+      tdu = dmax(fabs(u), c->c1 * s) * wg;
+    }
+    double p1p2 = (p1 + p2) * 0.5;
+    flu1 = u * (r1 + r2) - tdu * (r2 - r1);
+    flu2 = u * (rou1 + rou2) - tdu * (rou2 - rou1) + tcx * p1p2;
+    flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1) + tcy * p1p2;
+    flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tcz * p1p2;
+    flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+  }
+  if (c->iflow == 2) {
+    const int a = (dir + 1) % 3, b = (dir + 2) % 3;
+    const long ia = c->inc[a], ib = c->inc[b];
+    const long md = c->minc[dir], ma = c->minc[a], mb = c->minc[b];
+    const double *Ta = c->t[a], *Tb = c->t[b];
+    const long il = l - inc, ir = l;
+    double tn[3], tn1[3], ta[3], ta1[3], tb[3], tb1[3];
+    for (int m = 0; m < 3; m++) {
+      tn[m] = .5 * (Tn[lt + m * ndm] + Tn[lt - md + m * ndm]);
+      tn1[m] = .5 * (Tn[lt + m * ndm] + Tn[lt + md + m * ndm]);
+      ta[m] = .125 * (Ta[lt + m * ndm] + Ta[lt - md + m * ndm]);
+      ta1[m] = .125 * (Ta[lt + ma + m * ndm] + Ta[lt - md + ma + m * ndm]);
+      tb[m] = .125 * (Tb[lt + m * ndm] + Tb[lt - md + m * ndm]);
+      tb1[m] = .125 * (Tb[lt + mb + m * ndm] + Tb[lt - md + mb + m * ndm]);
+    }
+    double g[4][3];   /* gradients of u, v, w, T */
+    for (int e = 1; e <= 4; e++) {
+      const double *q = rop + e * nd;
+      double f1 = q[il], f2 = q[ir];
+      double f3 = q[ir] + q[il] + q[il - ia] + q[ir - ia];
+      double f4 = q[ir] + q[il] + q[il + ia] + q[ir + ia];
+      double f5 = q[ir] + q[il] + q[il - ib] + q[ir - ib];
+      double f6 = q[ir] + q[il] + q[il + ib] + q[ir + ib];
+      for (int m = 0; m < 3; m++)
+        g[e - 1][m] = (f2 * tn1[m] - f1 * tn[m]) + (f4 * ta1[m] - f3 * ta[m]) + (f6 * tb1[m] - f5 * tb[m]);
+    }
+    const double *U = rop + nd, *V = rop + 2 * nd, *W = rop + 3 * nd;
+    double div = (g[0][0] + g[1][1] + g[2][2]) * c->cvisq;
+    double f1 = g[0][0] - div, f2 = g[0][1] + g[1][0], f3 = g[0][2] + g[2][0];
+    double f4 = g[1][1] - div, f5 = g[1][2] + g[2][1], f6 = g[2][2] - div;
+    double volinv = 1. / (c->vol[lt] + c->vol[lt - md]);
+    double xmutvol = (xmut[ir] + xmut[il]) * volinv;
+    double xktvol = xmutvol * c->gam3;
+    double fv, fv5;
+    fv = -(2. * f1 * tcx + f2 * tcy + f3 * tcz) * xmutvol;
+    fv5 = fv * (U[ir] + U[il]);
+    flu2 = flu2 + fv;
+    fv = -(f2 * tcx + 2. * f4 * tcy + f5 * tcz) * xmutvol;
+    fv5 = fv5 + fv * (V[ir] + V[il]);
+    flu3 = flu3 + fv;
+    fv = -(f3 * tcx + f5 * tcy + 2. * f6 * tcz) * xmutvol;
+    fv5 = fv5 + fv * (W[ir] + W[il]);
+    flu4 = flu4 + fv;
+    fv = fv5 * 0.5 - (g[3][0] * tcx + g[3][1] * tcy + g[3][2] * tcz) * xktvol;
+    flu5 = flu5 + fv;
+  }
+  flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
+}
+
 static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const double *ti,
                          const double *tj, const double *tk, const double *vol)
 {
+  c->ityp = p[ITYPZONE];
+  c->t[0] = ti; c->t[1] = tj; c->t[2] = tk; c->vol = vol;
+  c->ndm = p[NDIMDX_MTR];
+  c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
   /* constants: Fast/FastS/FastS/Compute/template_FluxAndBalance.for:108-156 */
   c->kflu = p[KFLUDOM]; c->iflow = p[IFLOW];
   c->tcx = ti[0]; c->tcy = tj[0]; c->tcz = tk[0];
@@ -400,12 +573,17 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
   fluxctx c;
   fluxctx_init(&c, p, pr, ti, tj, tk, vol);
   double f[5];
+#define FACE(l, i, j, k, dir)                                                                     \
+  do {                                                                                            \
+    if (c.ityp == 0) face_flux_full(&c, rop, wig, xmut, (l), INDMTR(p, i, j, k), (dir), f);       \
+    else face_flux(&c, rop, wig, xmut, (l), (dir), f);                                            \
+  } while (0)
   for (int k = ind[4]; k <= ind[5]; k++) {
     for (int j = ind[2]; j <= ind[3]; j++) {
       for (int dir = 2; dir >= 0; dir--)
         for (int i = ind[0]; i <= ind[1]; i++) {
           long l = INDDM(i, j, k), l0 = l - c.inc[dir];
-          face_flux(&c, rop, wig, xmut, l, dir, f);
+          FACE(l, i, j, k, dir);
           for (int e = 0; e < 5; e++) {
             drodm[l + e * nd] = drodm[l + e * nd] + f[e];
             drodm[l0 + e * nd] = drodm[l0 + e * nd] - f[e];
@@ -413,7 +591,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
         }
       {
         long l = INDDM(ind[1] + 1, j, k), ls = l - 1;
-        face_flux(&c, rop, wig, xmut, l, 0, f);
+        FACE(l, ind[1] + 1, j, k, 0);
         for (int e = 0; e < 5; e++) {
           drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
           drodm[l + e * nd] = drodm[l + e * nd] + f[e];
@@ -422,7 +600,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
     }
     for (int i = ind[0]; i <= ind[1]; i++) {
       long l = INDDM(i, ind[3] + 1, k), ls = l - c.inc[1];
-      face_flux(&c, rop, wig, xmut, l, 1, f);
+      FACE(l, i, ind[3] + 1, k, 1);
       for (int e = 0; e < 5; e++) {
         drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
         drodm[l + e * nd] = drodm[l + e * nd] + f[e];
@@ -432,12 +610,13 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
   for (int j = ind[2]; j <= ind[3]; j++)
     for (int i = ind[0]; i <= ind[1]; i++) {
       long l = INDDM(i, j, ind[5] + 1), ls = l - c.inc[2];
-      face_flux(&c, rop, wig, xmut, l, 2, f);
+      FACE(l, i, j, ind[5] + 1, 2);
       for (int e = 0; e < 5; e++) {
         drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
         drodm[l + e * nd] = drodm[l + e * nd] + f[e];
       }
     }
+#undef FACE
 }
 
 /* Runge-Kutta stage update in conservative form, back to (rho,u,v,w,T)
@@ -578,12 +757,22 @@ void fo_bc_wall_viscous(const i32 *p, int idir, const i32 *cl, double *rop)
       }
 }
 
-/* Face normal (unit, then scaled quantities) of a Cartesian zone for the BC routines: only the
- * component along the face normal is non zero (Fast/FastC/FastC/Compute/shape_tab_mtr.for:32-52,
- * neq_mtr = 1). */
-static void fo_bc_metric(int idir, const double *ti, const double *tj, const double *tk, double *tc)
+/* Face metric seen by the BC routines for the face cell (i,j,k) (first interior cell of the
+ * column): tijk(lmtr, ic)*ci_mtr, ... of Fast/FastC/FastC/Compute/shape_tab_mtr.for:14-52.  On a
+ * Cartesian zone (neq_mtr = 1) only the component along the face normal is kept; on a curvilinear
+ * zone (neq_mtr = 3) the three components of the boundary face are read at
+ * lmtr = indmtr(face) with face = first cell (min side) or first cell + 1 (max side). */
+static void fo_bc_metric(const i32 *p, int idir, int i, int j, int k, const double *ti, const double *tj,
+                         const double *tk, double *tc)
 {
-  tc[0] = tc[1] = tc[2] = 0.;
+  if (p[ITYPZONE] == 0) {
+    const double *t = idir <= 2 ? ti : (idir <= 4 ? tj : tk);
+    int q[3] = {i, j, k};
+    if (idir % 2 == 0) q[(idir - 1) / 2] += 1;
+    const long lm = INDMTR(p, q[0], q[1], q[2]), ndm = p[NDIMDX_MTR];
+    tc[0] = t[lm] * 1.; tc[1] = t[lm + ndm] * 1.; tc[2] = t[lm + 2 * ndm] * 1.;
+    return;
+  }
   if (idir <= 2) { tc[0] = ti[0] * 1.; tc[1] = ti[0] * 0.; tc[2] = ti[0] * 0.; }
   else if (idir <= 4) { tc[0] = tj[0] * 0.; tc[1] = tj[0] * 1.; tc[2] = tj[0] * 0.; }
   else { tc[0] = tk[0] * 0.; tc[1] = tk[0] * 0.; tc[2] = tk[0] * 1.; }
@@ -599,12 +788,13 @@ void fo_bc_wall_inviscid(const i32 *p, int idir, const i32 *cl, double *rop, con
   const fo_face f = fo_face_of(p, idir);
   const int ref = 2 * f.first - f.sgn;
   double tc[3];
-  fo_bc_metric(idir, ti, tj, tk, tc);
   for (int k = cl[4]; k <= cl[5]; k++)
     for (int j = cl[2]; j <= cl[3]; j++)
       for (int i = cl[0]; i <= cl[1]; i++) {
         int q[3] = {i, j, k};
-        q[f.d] = ref - q[f.d];
+        q[f.d] = f.first;
+        fo_bc_metric(p, idir, q[0], q[1], q[2], ti, tj, tk, tc);
+        q[f.d] = ref - (f.d == 0 ? i : (f.d == 1 ? j : k));
         long l = INDDM(i, j, k), lm = INDDM(q[0], q[1], q[2]);
         double tcx = tc[0], tcy = tc[1], tcz = tc[2];
         double surf = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
@@ -648,7 +838,6 @@ void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, dou
   st[4] = pr[PINF] / (pr[GAMMA] - 1.) + 0.5 * (pr[VXINF] * st[1] + pr[VYINF] * st[2] + pr[VZINF] * st[3]);
   const double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
   double tc[3];
-  fo_bc_metric(idir, ti, tj, tk, tc);
   /* transverse window */
   int lo[3] = {cl[0], cl[2], cl[4]}, hi[3] = {cl[1], cl[3], cl[5]};
   lo[f.d] = hi[f.d] = f.first;
@@ -657,6 +846,7 @@ void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, dou
       for (int i = lo[0]; i <= hi[0]; i++) {
         const long l1 = INDDM(i, j, k);      /* first interior cell */
         long l = l1 - inc;                   /* first ghost rank */
+        fo_bc_metric(p, idir, i, j, k, ti, tj, tk, tc);
         {
           double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
           double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
@@ -833,11 +1023,12 @@ void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in
   const i32 grad[6] = {0, iv + 1, 0, jv + 1, 0, kv + 1};
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, grad, rop_in, xmut);
-    double volinv = pr[DTC] / vol[0]; /* Fast/FastS/FastS/Compute/tstb3_global.for:72-78 */
+    double volinv = pr[DTC] / vol[0]; /* Fast/FastS/FastS/Compute/tstb3_global.for:64-78 */
     GEOM(p)
     for (int k = 1; k <= kv; k++)
       for (int j = 1; j <= jv; j++)
-        for (int i = 1; i <= iv; i++) coe[INDDM(i, j, k)] = volinv;
+        for (int i = 1; i <= iv; i++)
+          coe[INDDM(i, j, k)] = p[ITYPZONE] != 2 ? pr[DTC] / vol[INDMTR(p, i, j, k)] : volinv;
   }
   fo_init_rhs(p, nitcfg, sdm, drodm);
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_in, wig);

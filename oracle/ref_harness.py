@@ -97,14 +97,19 @@ def ref_metrics(param_int, param_real, x, y, z):
     (loop range (1,1,1,1,1,1), Fast/FastC/FastC/Metric/indice_omp1.h:24-28)."""
     L = lib()
     p = np.ascontiguousarray(param_int, dtype=np.int32)
-    assert p[ITYPZONE] == 2, "ref_metrics: Cartesian zones only"
+    assert p[ITYPZONE] in (0, 2), "ref_metrics: Cartesian and curvilinear zones only"
     nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
     mtr = np.zeros(nm * (2 * nij + nk + 1))
     ti = mtr[0:nm * nij]; tj = mtr[nm * nij:2 * nm * nij]
     tk = mtr[2 * nm * nij:2 * nm * nij + nm * nk]; vol = mtr[2 * nm * nij + nm * nk:]
     xf = np.ascontiguousarray(x.reshape(-1, order='F')); yf = np.ascontiguousarray(y.reshape(-1, order='F'))
     zf = np.ascontiguousarray(z.reshape(-1, order='F'))
-    ind = np.ones(6, dtype=np.int32)
+    if p[ITYPZONE] == 2:
+        ind = np.ones(6, dtype=np.int32)
+    else:   # whole zone, ghost cells included (indice_omp1.h:11-16)
+        f, fk = int(p[NIJK + 3]), int(p[NIJK + 4])
+        ind = np.array([1 - f, int(p[IJKV]) + f, 1 - f, int(p[IJKV + 1]) + f, 1 - fk, int(p[IJKV + 2]) + fk],
+                       dtype=np.int32)
     L.cp_tijk_(_p(p), _p(xf), _p(yf), _p(zf), _p(ti), _p(tj), _p(tk), _p(ti), _p(tj), _p(tk), _p(ind))
     L.cp_vol_(_p(p), _p(xf), _p(yf), _p(zf), _p(ti), _p(tj), _p(tk), _p(ti), _p(tj), _p(tk), _p(vol), _p(ind))
     return mtr
