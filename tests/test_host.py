@@ -99,12 +99,21 @@ def test_switch_pointers_rotation():
     assert [FastC.level_buffer(z, s).ctypes.data for s in ('', '_M1', '_P1')] == a
 
 
-def test_non_cartesian_zone_is_refused():
+def test_zone_classification_curvilinear_accepted_k_homogeneous_refused():
     t = cases.tgv(6, 'senseur')
     z = _zone(t)
     g = Internal.getNodeFromName1(z, 'GridCoordinates')
     x = Internal.getNodeFromName1(g, 'CoordinateX')[1]
     x[3, 3, 3] += 0.01        # one displaced node: curvilinear
+    m = prepare(t)
+    pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
+    assert pint[25] == 0 and list(pint[5:10]) == [1, 11, 121, 2, 2] and pint[43] == 11 ** 3
+    assert m[0][0].size == 10 * 11 ** 3
+    t = cases.tgv(6, 'senseur')
+    z = _zone(t)
+    g = Internal.getNodeFromName1(z, 'GridCoordinates')
+    x = Internal.getNodeFromName1(g, 'CoordinateX')[1]
+    x[3, 3, :] += 0.01        # the same displacement on every k plane: k-homogeneous (type 1)
     with pytest.raises((ValueError, NotImplementedError)):
         prepare(t)
 
