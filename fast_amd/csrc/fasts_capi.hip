@@ -13,7 +13,7 @@
 namespace {
 
 // Parameter_int / Parameter_real slots (Fast/FastS/FastS/param_solver.h:77-306)
-enum { NIJK = 0, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
+enum { NIJK = 0, NIJK_MTR = 5, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
        NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
        SLOPE = 64, PT_BC = 70, SENSORTYPE = 85 };
 enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
@@ -27,6 +27,7 @@ struct Zone {
   double *host[3] = {nullptr, nullptr, nullptr};  // roles: 0 = N, 1 = M1, 2 = P1
   double *dev[3] = {nullptr, nullptr, nullptr};
   double *drodm = nullptr, *xmut = nullptr, *wig = nullptr;
+  double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]
   double *res_part = nullptr, *res_out = nullptr;
   FsBcWin *bc_dev = nullptr;
   std::vector<FsBcWin> bc;
@@ -130,7 +131,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     for (int r = 0; r < 3; r++) (void)hipFree(zn.dev[r]);
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev);
-    (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev);
+    (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
   }
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
@@ -187,7 +188,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (n_int < 137 || n_real < 41) return fail(ctx, FS_ERR_ARG, "fs_zone_add: Parameter_int/real too short");
   if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_zone_add: zones must be registered before fs_upload");
   const int32_t *p = pint;
-  if (p[ITYPZONE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Cartesian zones (zone type 2) are implemented");
+  if (p[ITYPZONE] != 2 && p[ITYPZONE] != 0)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Cartesian (zone type 2) and curvilinear (zone type 0) zones are implemented");
   if (p[ITYPCP] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only the explicit scheme is implemented");
   if (p[NEQ] != 5 || p[IFLOW] > 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Euler / NSLaminar (5 equations) are implemented");
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
@@ -196,6 +198,14 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK]) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
   if (p[NIJK + 3] != 2 || p[NIJK + 4] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two ghost layers in every direction are required");
   if (n_mtr < 4) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short");
+  if (p[ITYPZONE] == 0) {
+    // metric arrays dimensioned on the nodes, strides (1, ni+1, (ni+1)(nj+1)) (nature_geom_dom.for:186-503)
+    const long long nn = (long long)(p[NIJK] + 1) * (p[NIJK + 1] + 1) * (p[NIJK + 2] + 1);
+    if (p[NDIMDX_MTR] != nn || p[NEQ_IJ] != 3 || p[NEQ_K] != 3 || p[NIJK_MTR] != 1 || p[NIJK_MTR + 1] != p[NIJK] + 1 ||
+        p[NIJK_MTR + 2] != (p[NIJK] + 1) * (p[NIJK + 1] + 1) || p[NIJK_MTR + 3] != p[NIJK + 3] || p[NIJK_MTR + 4] != p[NIJK + 4])
+      return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric layout of a curvilinear zone must be node-dimensioned with 3 components per direction");
+    if ((long long)n_mtr < 10 * nn) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short for a curvilinear zone");
+  }
   if ((long long)p[NIJK] * p[NIJK + 1] * p[NIJK + 2] > p[NDIMDX]) return fail(ctx, FS_ERR_ARG, "fs_zone_add: NDIMDX smaller than the zone");
   if (p[IJKV] < 4 || p[IJKV + 1] < 4 || p[IJKV + 2] < 4) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: at least 4 interior cells per direction");
 
@@ -228,6 +238,13 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   z.cvisq = 1. / 3;
   z.dt = r[DTC];
   z.coe = r[DTC] / mtr[3];  // tstb3_global.for:72-78
+  z.ityp = p[ITYPZONE]; z.ndm = 0; z.mincj = z.minck = 0;
+  z.mt[0] = z.mt[1] = z.mt[2] = z.vol = nullptr;
+  if (z.ityp == 0) {
+    z.ndm = p[NDIMDX_MTR]; z.mincj = p[NIJK_MTR + 1]; z.minck = p[NIJK_MTR + 2];
+    // the scalars of the Cartesian path are not used by the curvilinear kernels
+    z.tcx = z.tcy = z.tcz = z.si = z.sj = z.sk = z.volinv = z.coe = 0.;
+  }
   z.cv = r[CVINF]; z.cvinv = 1. / z.cv; z.cvinv2 = 0.5 * z.cvinv;  // core3ark3.for:44-46
   {  // invist.for:49-51
     double cmus1 = r[CS], temp01 = 1. / r[TEMP0];
@@ -277,6 +294,18 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
     if (cells > zn.bc_max_cells) zn.bc_max_cells = cells;
     zn.bc.push_back(w);
+  }
+  if (z.ityp == 0) {   // last step that can fail: nothing to release on the error paths above
+    (void)hipSetDevice(ctx->device);
+    const size_t nb = sizeof(double) * 10 * (size_t)z.ndm;
+    HIPCHK(ctx, hipMalloc(&zn.mtr_dev, nb));
+    hipError_t e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(zn.mtr_dev);
+      return fail(ctx, FS_ERR_HIP, std::string("fs_zone_add: metric upload: ") + hipGetErrorString(e));
+    }
+    z.mt[0] = zn.mtr_dev; z.mt[1] = zn.mtr_dev + 3 * z.ndm; z.mt[2] = zn.mtr_dev + 6 * z.ndm;
+    z.vol = zn.mtr_dev + 9 * z.ndm;
   }
   ctx->zones.push_back(std::move(zn));
   return (int)ctx->zones.size() - 1;
@@ -350,7 +379,7 @@ extern "C" int fs_upload(fs_ctx *ctx)
       HIPCHK(ctx, hipMemsetAsync(zn.xmut, 0, sizeof(double) * (size_t)zn.z.nd, ctx->stream));
       if (zn.z.kflu == 2) {
         // face sensors: 0/1 values, one byte each in the tiled kernel, doubles in the plain one
-        const size_t nw = (ctx->plain_stage ? sizeof(double) : 1) * 3 * (size_t)zn.z.nd;
+        const size_t nw = (ctx->plain_stage && zn.z.ityp != 0 ? sizeof(double) : 1) * 3 * (size_t)zn.z.nd;
         HIPCHK(ctx, hipMalloc(&zn.wig, nw));
         HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, nw, ctx->stream));
       }
@@ -428,6 +457,7 @@ static int build_shell_lists(fs_ctx *ctx)
   for (size_t nz = 0; nz < ctx->zones.size(); nz++) {
     Zone &zn = ctx->zones[nz];
     const FsZone &z = zn.z;
+    if (z.ityp == 0) continue;   // curvilinear zones run their stage in one launch
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
     std::vector<char> mark((size_t)nblk, 0);
@@ -481,14 +511,17 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     if (part == 0 && !split) continue;
     if (opens && nstep == 1) {
       if (z.iflow == 2) fsk_invist(z, zn.dev[in], zn.xmut, ctx->stream);
-      if (z.kflu == 2 && ctx->plain_stage) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
+      if (z.kflu == 2 && ctx->plain_stage && z.ityp != 0) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }
     if (ctx->timing && opens) {
       if (!zn.ev_part) HIPCHK(ctx, hipEventCreate(&zn.ev_part));
       HIPCHK(ctx, hipEventRecord(zn.ev_part, ctx->stream));
     }
     int krc = 0;
-    if (ctx->plain_stage)
+    if (z.ityp == 0)
+      krc = fsk_stage_full(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
+                           (unsigned char *)zn.wig, ctx->stream);
+    else if (ctx->plain_stage)
       krc = fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
     else if (!ctx->dma_stage)
       krc = fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
@@ -755,7 +788,7 @@ extern "C" int fs_debug_fetch(fs_ctx *ctx, int zone, int which, double *host, in
   long long n = which == 0 ? (long long)zn.z.neq * zn.z.nd : (which == 1 ? 3 * zn.z.nd : zn.z.nd);
   if (!src) return fail(ctx, FS_ERR_STATE, "fs_debug_fetch: array not allocated for this scheme");
   if (n_doubles != n) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: size mismatch");
-  if (which == 1 && !ctx->plain_stage) {  // byte sensors: widen on the host
+  if (which == 1 && (!ctx->plain_stage || zn.z.ityp == 0)) {  // byte sensors: widen on the host
     std::vector<unsigned char> b((size_t)n);
     HIPCHK(ctx, hipMemcpyAsync(b.data(), src, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

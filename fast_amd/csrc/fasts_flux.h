@@ -1,4 +1,5 @@
-// Device-side numerics of the FastS face flux for Cartesian zones (zone type 2), gfx950.
+// Device-side numerics of the FastS face flux for Cartesian (zone type 2) and curvilinear (zone
+// type 0) zones, gfx950.
 //
 // Every expression keeps the operand order of the reference fragment it implements and the
 // translation unit is built with -ffp-contract=off, so a face flux is bit-identical to the
@@ -13,6 +14,9 @@
 //   roe + Harten fix       ROE/3dcart/fluFaceEuler_o3_3dcart_*.for, Vit_ent/fludiffer_3dcart_*.for
 //   viscous flux           fluvisq_3dcart_{i,j,k}.for, mut_interface.for
 //   sensor                 SENSOR/wiggle.for, SENSOR/wiggle_{i,j,k}.for
+//   curvilinear zones      AUSM|SENSOR|ROE/3dfull/fluFaceEuler_o3_3dfull_{i,j,k}.for,
+//                          Vit_ent/fluvector_3dfull_*.for, Vit_ent/fludiffer_3dfull_*.for,
+//                          fluvisq_3dfull_{i,j,k}.for
 //   constants              template_FluxAndBalance.for:108-156
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,6 +33,12 @@ struct FsZone {
   double tcx, tcy, tcz, si, sj, sk, volinv;
   double coe;              // dt/vol (constant on a Cartesian zone with a global time step)
   double dt, cv, cvinv, cvinv2, coesut, cmus1;
+  // curvilinear zones (ityp 0): device arrays ti,tj,tk(ndm,3) and vol(ndm), dimensioned on the nodes;
+  // metric index of cell (i,j,k) = (i+ific-1) + (j+ific-1)*mincj + (k+ifick-1)*minck
+  int ityp;
+  long long ndm, mincj, minck;
+  const double *mt[3];
+  const double *vol;
 };
 
 #define FS_DEV static __device__ __forceinline__
@@ -167,6 +177,164 @@ FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *q
   flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
 }
 
+// Inviscid flux of a curvilinear zone: (tcx,tcy,tcz) = surface vector of the face between the cells
+// of qm1_ and q0.  Same expressions for the three directions.
+template <int KFLU>
+FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, double tcz, const double *qm2,
+                                  const double *qm1_, const double *q0, const double *qp1_, double wg, double *flu)
+{
+  const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+  double qm[5], qp[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    qm[e] = z.c4 * q0[e] + z.c5 * qm1_[e] + z.c6 * qp1_[e];
+    qp[e] = z.c4 * qm1_[e] + z.c6 * qm2[e] + z.c5 * q0[e];
+  }
+  double flu1, flu2, flu3, flu4, flu5;
+  if (KFLU == 5) {
+    const double gam = z.gam, rgp = z.rgp, gam1 = z.gam1, psiroe = z.psiroe;
+    double r1 = qp[0], p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * qp[4] * rgp + .5 * (qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+    double r2 = qm[0], p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * qm[4] * rgp + .5 * (qm[1] * qm[1] + qm[2] * qm[2] + qm[3] * qm[3]);
+    double qp1 = sqrt(r1), qm1 = sqrt(r2);
+    double r = qp1 * qm1;
+    double r_1 = 1. / (qp1 + qm1);
+    double u = (qp1 * qp[1] + qm1 * qm[1]) * r_1;
+    double v = (qp1 * qp[2] + qm1 * qm[2]) * r_1;
+    double w = (qp1 * qp[3] + qm1 * qm[3]) * r_1;
+    double h = (qp1 * h1 + qm1 * h2) * r_1;
+    double q = .5 * (u * u + v * v + w * w);
+    double cc = sqrt((gam - 1.) * fabs(h - q));
+    double qn1 = qp[1] * tcx + qp[2] * tcy + qp[3] * tcz;
+    double qn2 = qm[1] * tcx + qm[2] * tcy + qm[3] * tcz;
+    double du = (qm[1] - qp[1]) * s, dv = (qm[2] - qp[2]) * s, dw = (qm[3] - qp[3]) * s;
+    double dp = p2 - p1, dqn = qn2 - qn1;
+    double s_1 = 1. / fs_max(s, 1.e-30);
+    double nx = tcx * s_1, ny = tcy * s_1, nz = tcz * s_1;
+    double qn = u * nx + v * ny + w * nz;
+    double f1 = qn;
+    double f4 = psiroe * (fabs(f1) + cc);
+    double f2 = .5 + fs_sign(.5, fabs(f1) - f4);
+    double f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (r2 - r1 - dp / (cc * cc)) * s;
+    flu1 = f3 * (f1);
+    flu2 = f3 * (f1 * u + r * (du - nx * dqn));
+    flu3 = f3 * (f1 * v + r * (dv - ny * dqn));
+    flu4 = f3 * (f1 * w + r * (dw - nz * dqn));
+    flu5 = f3 * (f1 * q + r * (u * du + v * dv + w * dw - qn * dqn));
+    f1 = qn + cc;
+    f2 = .5 + fs_sign(.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * (u + nx * cc);
+    flu3 = flu3 + f1 * (v + ny * cc);
+    flu4 = flu4 + f1 * (w + nz * cc);
+    flu5 = flu5 + f1 * (h + qn * cc);
+    f1 = qn - cc;
+    f2 = .5 + fs_sign(.5, fabs(f1) - f4);
+    f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
+    f1 = (dp - r * cc * dqn * s_1) / (2. * cc * cc) * f3 * s;
+    flu1 = flu1 + f1;
+    flu2 = flu2 + f1 * (u - nx * cc);
+    flu3 = flu3 + f1 * (v - ny * cc);
+    flu4 = flu4 + f1 * (w - nz * cc);
+    flu5 = flu5 + f1 * (h - qn * cc);
+    double rou1 = r1 * qn1, rou2 = r2 * qn2, p1p2 = p1 + p2;
+    flu1 = (flu1 + rou1 + rou2) * 0.5;
+    flu2 = (flu2 + rou1 * qp[1] + rou2 * qm[1] + tcx * p1p2) * 0.5;
+    flu3 = (flu3 + rou1 * qp[2] + rou2 * qm[2] + tcy * p1p2) * 0.5;
+    flu4 = (flu4 + rou1 * qp[3] + rou2 * qm[3] + tcz * p1p2) * 0.5;
+    flu5 = (flu5 + rou1 * h1 + rou2 * h2) * 0.5;
+  } else {
+    const double rgp = z.rgp, gam1 = z.gam1;
+    double r1 = qp[0], rou1 = r1 * qp[1], rov1 = r1 * qp[2], row1 = r1 * qp[3];
+    double p1 = r1 * qp[4] * rgp;
+    double h1 = gam1 * p1 + .5 * (rou1 * qp[1] + rov1 * qp[2] + row1 * qp[3]);
+    double r2 = qm[0], rou2 = r2 * qm[1], rov2 = r2 * qm[2], row2 = r2 * qm[3];
+    double p2 = r2 * qm[4] * rgp;
+    double h2 = gam1 * p2 + .5 * (rou2 * qm[1] + rov2 * qm[2] + row2 * qm[3]);
+    double qn1 = qp[1] * tcx + qp[2] * tcy + qp[3] * tcz;
+    double qn2 = qm[1] * tcx + qm[2] * tcy + qm[3] * tcz;
+    double u, tdu;
+    if (KFLU == 1) {
+      double cc = rgp * z.gam * q0[4];
+      double son = sqrt(qn1 * qn1 / cc);
+      double tam = z.c3 * son + s;
+      double tam1 = fs_max(0., tam) * z.c2;
+      u = 0.25 * (qn1 + qn2) - tam1 * (p2 - p1);
+      tdu = fs_max(fabs(u), z.c1 * s);
+    } else {
+      u = 0.25 * (qn1 + qn2) - z.c2 * s * (p2 - p1) * (z.opt0 * wg + 1. - z.opt0);
+      tdu = fs_max(fabs(u), z.c1 * s) * wg;
+    }
+    double p1p2 = (p1 + p2) * 0.5;
+    flu1 = u * (r1 + r2) - tdu * (r2 - r1);
+    flu2 = u * (rou1 + rou2) - tdu * (rou2 - rou1) + tcx * p1p2;
+    flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1) + tcy * p1p2;
+    flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tcz * p1p2;
+    flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+  }
+  flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
+}
+
+// Viscous part of a curvilinear zone, added to flu[1..4].  The three reference fragments are one
+// pattern: with a = DIR+1, b = DIR+2 (cyclic) the cross sums take the neighbours along a, then b.
+//   q(e, da, db, dn)  variable e at offset dn along DIR (0 = right cell ir, -1 = left cell il) and
+//                     (da, db) along a and b
+//   T(c, m, o)        component m of the surface vector of direction c (0 = DIR, 1 = a, 2 = b) at
+//                     metric offset o: 0 = lt, 1 = lt - md, 2 = lt + md, 3 = lt + m(c), 4 = lt - md + m(c)
+//   vol_r, vol_l      volumes of ir and il;  (tcx,tcy,tcz) = surface vector of the face
+template <class Q, class TT>
+FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, double vol_r, double vol_l, double mul,
+                                 double mur, double tcx, double tcy, double tcz, double *flu)
+{
+  double tn[3], tn1[3], ta[3], ta1[3], tb[3], tb1[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    tn[m] = .5 * (T(0, m, 0) + T(0, m, 1));
+    tn1[m] = .5 * (T(0, m, 0) + T(0, m, 2));
+    ta[m] = .125 * (T(1, m, 0) + T(1, m, 1));
+    ta1[m] = .125 * (T(1, m, 3) + T(1, m, 4));
+    tb[m] = .125 * (T(2, m, 0) + T(2, m, 1));
+    tb1[m] = .125 * (T(2, m, 3) + T(2, m, 4));
+  }
+  double g[4][3];
+  double sum_lr[4];
+#pragma unroll
+  for (int e = 1; e <= 4; e++) {
+    const double qr = q(e, 0, 0, 0), ql = q(e, 0, 0, -1);
+    double f1 = ql, f2 = qr;
+    double f3 = qr + ql + q(e, -1, 0, -1) + q(e, -1, 0, 0);
+    double f4 = qr + ql + q(e, 1, 0, -1) + q(e, 1, 0, 0);
+    double f5 = qr + ql + q(e, 0, -1, -1) + q(e, 0, -1, 0);
+    double f6 = qr + ql + q(e, 0, 1, -1) + q(e, 0, 1, 0);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+      g[e - 1][m] = (f2 * tn1[m] - f1 * tn[m]) + (f4 * ta1[m] - f3 * ta[m]) + (f6 * tb1[m] - f5 * tb[m]);
+    sum_lr[e - 1] = qr + ql;
+  }
+  double div = (g[0][0] + g[1][1] + g[2][2]) * z.cvisq;
+  double f1 = g[0][0] - div, f2 = g[0][1] + g[1][0], f3 = g[0][2] + g[2][0];
+  double f4 = g[1][1] - div, f5 = g[1][2] + g[2][1], f6 = g[2][2] - div;
+  double volinv = 1. / (vol_r + vol_l);
+  double xmutvol = (mur + mul) * volinv;
+  double xktvol = xmutvol * z.gam3;
+  double fv, fv5;
+  fv = -(2. * f1 * tcx + f2 * tcy + f3 * tcz) * xmutvol;
+  fv5 = fv * sum_lr[0];
+  flu[1] = flu[1] + fv;
+  fv = -(f2 * tcx + 2. * f4 * tcy + f5 * tcz) * xmutvol;
+  fv5 = fv5 + fv * sum_lr[1];
+  flu[2] = flu[2] + fv;
+  fv = -(f3 * tcx + f5 * tcy + 2. * f6 * tcz) * xmutvol;
+  fv5 = fv5 + fv * sum_lr[2];
+  flu[3] = flu[3] + fv;
+  fv = fv5 * 0.5 - (g[3][0] * tcx + g[3][1] * tcy + g[3][2] * tcz) * xktvol;
+  flu[4] = flu[4] + fv;
+}
+
 // Viscous part added to flu[1..4].  il = l - inc(DIR), ir = l.  The accessor gives
 //   q(e, da, db, dn): variable e (1 u, 2 v, 3 w, 4 T) at offset dn along DIR (0 = ir, -1 = il)
 //   and (da, db) along the two transverse directions in the order (i,j,k) minus DIR.
@@ -256,9 +424,9 @@ FS_DEV void fs_flux_viscous(const FsZone &z, const Q &q, double mul, double mur,
 
 // Runge-Kutta stage update of one cell in conservative form, back to primitive variables
 // (core3ark3.for:108-154).  q = stage input, d = balance, out = stage output.
-FS_DEV void fs_rk_update(const FsZone &z, double coefW, const double *q, const double *d, double *out)
+FS_DEV void fs_rk_update_c(const FsZone &z, double coefW, double coe, const double *q, const double *d, double *out)
 {
-  double r_1 = coefW * z.coe;
+  double r_1 = coefW * coe;
   double tab1 = d[0] * r_1, tab2 = d[1] * r_1, tab3 = d[2] * r_1, tab4 = d[3] * r_1, tab5 = d[4] * r_1;
   double ro_old = q[0], u_old = q[1], v_old = q[2], w_old = q[3], t_old = q[4];
   double ro_new = q[0] + tab1;
@@ -269,4 +437,9 @@ FS_DEV void fs_rk_update(const FsZone &z, double coefW, const double *q, const d
   double roe_old = ro_old * (z.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
   out[0] = ro_new; out[1] = un; out[2] = vn; out[3] = wn;
   out[4] = (roe_old + tab5) * r_1 * z.cvinv - z.cvinv2 * (un * un + vn * vn + wn * wn);
+}
+
+FS_DEV void fs_rk_update(const FsZone &z, double coefW, const double *q, const double *d, double *out)
+{
+  fs_rk_update_c(z, coefW, z.coe, q, d, out);
 }

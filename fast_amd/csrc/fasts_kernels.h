@@ -31,6 +31,9 @@ struct FsTiling { int nti, ntj, ntk, kchunk, ti, tj; };
 FsTiling fsk_stage_dma_tiling(const FsZone &z);
 int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                   double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, hipStream_t s);
+// stage kernel of curvilinear zones (zone type 0, fasts_stage_full.hip); sensors stored as bytes
+int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                   double *drodm, const double *xmut, unsigned char *wig, hipStream_t s);
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop,
                     hipStream_t s);
 void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);

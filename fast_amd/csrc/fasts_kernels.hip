@@ -1,4 +1,5 @@
-// HIP kernels of the FastS explicit time step on Cartesian zones, gfx950 (MI355X).
+// HIP kernels of the FastS explicit time step around the stage kernels (viscosity, ghost fill, joins,
+// residual norms) and the untiled stage kernel of Cartesian zones, gfx950 (MI355X).
 // Built with -ffp-contract=off (see fasts_flux.h for why results must be bit-reproducible).
 #include "fasts_kernels.h"
 #include "fasts_flux.h"
@@ -183,6 +184,25 @@ FS_DEV void fs_bc_farfield_first(const FsZone &z, const double *st, double tcx, 
   rop[l + 4 * nd] = (qvar5 * roinv - .5 * (u * u + v * v + w * w)) * cvinv;
 }
 
+// Face metric seen by the BC routines for the column whose first interior cell is q
+// (Fast/FastC/FastC/Compute/shape_tab_mtr.for:14-52).  Cartesian zone: only the component along the
+// face normal is kept.  Curvilinear zone: the surface vector of the boundary face, stored with the
+// first interior cell on a min face and with the cell after it on a max face.
+FS_DEV void fs_bc_metric(const FsZone &z, const FsBcWin &w, int d, const int *q, double *tc)
+{
+  if (z.ityp == 0) {
+    int p[3] = {q[0], q[1], q[2]};
+    if (!(w.idir & 1)) p[d] += 1;
+    const long long lm = (long long)(p[0] + z.ific - 1) + (long long)(p[1] + z.ific - 1) * z.mincj +
+                         (long long)(p[2] + z.ifick - 1) * z.minck;
+    const double *__restrict__ t = z.mt[d];
+    tc[0] = t[lm] * 1.; tc[1] = t[lm + z.ndm] * 1.; tc[2] = t[lm + 2 * z.ndm] * 1.;
+    return;
+  }
+  tc[0] = w.tcn * 0.; tc[1] = w.tcn * 0.; tc[2] = w.tcn * 0.;
+  tc[d] = w.tcn * 1.;
+}
+
 // One block-row per window, one thread per face cell of the window; the thread walks the ghost
 // ranks outwards (rank 2 of the far field reads rank 1).
 //   BCautoperiod       ghost = rop(l + shift)                     bvbs_periodique.for:150-171
@@ -224,9 +244,8 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         rop[l + 4 * nd] = rop[lm + 4 * nd];
       }
     } else if (w.type == FS_BC_WALL_SLIP) {
-      // shape_tab_mtr.for:32-52: only the metric component along the face normal is kept
-      double tc[3] = {w.tcn * 0., w.tcn * 0., w.tcn * 0.};
-      tc[d] = w.tcn * 1.;
+      double tc[3];
+      fs_bc_metric(z, w, d, q, tc);
       for (int r = 1; r <= nr; r++) {
         const long long l = l1 - r * inc, lm = l1 + (r - 1) * inc;
         double tcx = tc[0], tcy = tc[1], tcz = tc[2];
@@ -246,9 +265,9 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
       }
     } else {  // FS_BC_FARFIELD
       const double snorm = (w.idir & 1) ? -1. : 1.;
-      double tc[3] = {w.tcn * 0. * snorm, w.tcn * 0. * snorm, w.tcn * 0. * snorm};
-      tc[d] = w.tcn * 1. * snorm;
-      fs_bc_farfield_first(z, w.st, tc[0], tc[1], tc[2], rop, l1 - inc, l1);
+      double tc[3];
+      fs_bc_metric(z, w, d, q, tc);
+      fs_bc_farfield_first(z, w.st, tc[0] * snorm, tc[1] * snorm, tc[2] * snorm, rop, l1 - inc, l1);
       const double c4 = 5. / 6., c5 = 2. / 6., c6 = -1. / 6.;
       const double c0 = 1. / c6, c1 = -(c4 + c5) * c0, c2 = -c6 * c0, c3 = (2. - c5 - c4) * c0;
       for (int r = 2; r <= nr; r++) {   // BC_nextrank.for
@@ -372,8 +391,12 @@ __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, const double
   double s[5] = {0, 0, 0, 0, 0}, m[5] = {0, 0, 0, 0, 0};
   for (int i = threadIdx.x + 1; i <= z.iv; i += blockDim.x) {
     long long l = fs_inddm(z, i, j, k);
+    double coe = z.coe;
+    if (z.ityp == 0)   // dt/vol of the cell (tstb3_global.for:64-78)
+      coe = z.dt / z.vol[(long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj +
+                         (long long)(k + z.ifick - 1) * z.minck];
     for (int e = 0; e < 5; e++) {
-      double r = z.coe * drodm[e * z.nd + l];
+      double r = coe * drodm[e * z.nd + l];
       s[e] = s[e] + r * r;
       m[e] = fs_max(m[e], fabs(r));
     }
