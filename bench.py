@@ -81,6 +81,8 @@ def main():
     ap.add_argument('--cells', dest='n', type=int, default=256, help='cells per direction per GPU block')
     ap.add_argument('--scheme', default='senseur', choices=['senseur', 'ausmpred', 'roe'])
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--perturb', type=float, default=0., help='node displacement in mesh steps: > 0 makes the block '
+                    'curvilinear (per-cell metrics); not the headline workload')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -109,8 +111,10 @@ def main():
             dist.init_process_group(backend)
     model = 'Euler' if a.scheme == 'roe' else 'NSLaminar'
 
+    if a.perturb and world > 1:
+        raise SystemExit("bench.py: --perturb is a single-GPU option")
     if world == 1:
-        t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n)
+        t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n, perturb=a.perturb)
         (t, tc, metrics) = FastS.warmup(t, None, device=local_rank)
         ctx = FastC.HOOK['ctx']
         run_step = lambda it: ctx.compute(it, 1, 3, 1)
@@ -157,11 +161,12 @@ def main():
         # HBM bytes per launch from the PMC passes of this same command (collected in runs of their
         # own by profiles/run_profiles.sh; counters cannot be read inside a timed run)
         traffic = None
-        tf = os.path.join(ROOT, 'profiles', 'traffic_%s_%d.json' % (a.scheme, a.n))
+        tf = os.path.join(ROOT, 'profiles', 'traffic_%s_%d%s.json' % (a.scheme, a.n, '_curvilinear' if a.perturb else ''))
         if os.path.exists(tf):
             with open(tf) as fh:
                 traffic = json.load(fh).get('traffic_bytes_per_launch')
-        bpl = BYTES_PER_CELL_STEP[a.scheme] / 3.0 * a.n ** 3     # algorithmic bytes per launch
+        # algorithmic bytes per launch; per-cell metrics (9 surface-vector components + volume) are read once per stage
+        bpl = (BYTES_PER_CELL_STEP[a.scheme] + (240.0 if a.perturb else 0.)) / 3.0 * a.n ** 3
         ach = bpl / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.
         out = {
             "metric": "Mcell-iter/s (fp64 RK3 TGV 256^3)",
@@ -174,7 +179,8 @@ def main():
             "config": {"workload": "TGV Re=1600 M=0.1, %d^3 cells per GPU, NSLaminar, scheme=%s, RK3, periodic"
                                    % (a.n, a.scheme) if model != 'Euler' else
                                    "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
-                       "blocks": list(split_for(world) or (1, 1, 1)), "ghost_layers": 2},
+                       "blocks": list(split_for(world) or (1, 1, 1)), "ghost_layers": 2,
+                       "mesh": "curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n},

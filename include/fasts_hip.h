@@ -72,7 +72,12 @@ int fs_set_verif(fs_ctx *ctx, int modulo_verif);
  * fasts.allocate_metric / fastc.init_metric
  * (Fast/FastS/FastS/Metric/allocate_metric.cpp:464-471).
  * ro / ro_m1 / ro_p1 are the host buffers of the three time levels (Density, Density_M1,
- * Density_P1 and the fields compacted behind them). */
+ * Density_P1 and the fields compacted behind them).
+ * mtr is metrics[0] of the reference: [ti | tj | tk | vol].  Cartesian zone (ITYPZONE 2): four
+ * scalars.  Curvilinear zone (ITYPZONE 0): ti,tj,tk(NDIMDX_MTR,3) and vol(NDIMDX_MTR), dimensioned
+ * on the nodes with the strides of NIJK_MTR (Fast/FastC/FastC/Metric/nature_geom_dom.for:186-503,
+ * cp_tijk.for:60-123, cp_vol.for:55-93); the array is copied to the device during this call.
+ * Zone types 1 (k-homogeneous) and 3 (2-D) return FS_ERR_UNSUPPORTED. */
 int fs_zone_add(fs_ctx *ctx, const int32_t *param_int, int n_int, const double *param_real,
                 int n_real, double *ro, double *ro_m1, double *ro_p1, const double *mtr,
                 int n_mtr);
