@@ -60,7 +60,7 @@ def tgv_fields(t, state, L0=1.):
 
 def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
         temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None, bcs=None,
-        perturb=0.):
+        perturb=0., extra_numb=None):
     """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
     whole box; blocks = (bi,bj,bk) split; only = block numbers to instantiate (the blocks of one
     rank; block b = ib + jb*bi + kb*bi*bj is named 'cart<b>').  Split directions carry no BC:
@@ -105,12 +105,14 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
     numz = {'time_step': time_step, 'scheme': scheme}
     if extra_numz:
         numz.update(extra_numz)
+    if extra_numb:
+        numb.update(extra_numb)
     FastC._setNum2Zones(t, numz)
     FastC._setNum2Base(t, numb)
     return t
 
 
-def vortex(n=64, scheme='roe', time_step=None, extra_numz=None):
+def vortex(n=64, scheme='roe', time_step=None, extra_numz=None, extra_numb=None):
     """Isentropic vortex (strength beta=5, core radius 1) in a 10^3 periodic box, free
     stream along x at M=0.5, Euler, sound-speed scaling (rho_inf = c_inf = T_inf = 1)."""
     Lb = 10.
@@ -154,6 +156,8 @@ def vortex(n=64, scheme='roe', time_step=None, extra_numz=None):
     numz = {'time_step': time_step, 'scheme': scheme}
     if extra_numz:
         numz.update(extra_numz)
+    if extra_numb:
+        numb.update(extra_numb)
     FastC._setNum2Zones(t, numz)
     FastC._setNum2Base(t, numb)
     return t

@@ -1074,3 +1074,335 @@ void fo_residual(const i32 *p, const double *drodm, const double *coe, double *s
         }
       }
 }
+
+/* =====================================================================================
+ * Implicit time step: BDF Newton residual + LU-SGS (nb_relax = 1, lu_match = 0, 5 equations,
+ * fixed mesh, global time step).  The LU range is the zone interior (no wall boundary).
+ * ===================================================================================== */
+#define NEQ_COE 39
+#define DTLOC 46
+#define NB_RELAX 71
+#define LU_MATCH 75
+
+/* dt/vol and the LU coefficients: coe(:,1) = dt/vol (Fast/FastS/FastS/Compute/tstb3_global.for:64-78),
+ * coe(:,2..4) = spectral radii of the i, j, k directions (convective + viscous), coe(:,5) = diagonal
+ * xid + coe1*(coe2+coe3+coe4)/2 (tstb3c.for:62-76,86-176,262-311).  Range = the whole zone,
+ * ghost cells included (ind_coe of indice_boucle_ssdom.for:108-112 with one cache block). */
+void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *ind, const double *rop,
+                       const double *xmut, double *coe, const double *ti, const double *tj, const double *tk,
+                       const double *vol)
+{
+  GEOM(p)
+  const double cut0x = 1e-20;
+  const double gamma = pr[GAMMA], rgp = pr[CVINF] * (gamma - 1.), prandt = pr[PRANDT];
+  double xid = 1.5;
+  if (first_it == 0) xid = 1.;
+  double gam1 = gamma / prandt;
+  if (p[IFLOW] == 1) gam1 = 0.;
+  const double gam2 = gamma * rgp;
+  const long ndm = p[NDIMDX_MTR];
+  const long minc[3] = {p[NIJK_MTR], p[NIJK_MTR + 1], p[NIJK_MTR + 2]};
+  const int full = p[ITYPZONE] == 0;
+  const double *T[3] = {ti, tj, tk};
+  double tcc[3] = {ti[0], tj[0], tk[0]}, tc2c[3];
+  for (int d = 0; d < 3; d++) tc2c[d] = sqrt(tcc[d] * tcc[d]);
+  const double volinv = pr[DTC] / vol[0];
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k);
+        const long lt = full ? INDMTR(p, i, j, k) : 0;
+        coe[l] = full ? pr[DTC] / vol[lt] : volinv;
+        const double r = rop[l], detj = dmax(vol[lt], cut0x);
+        const double u = rop[l + nd], v = rop[l + 2 * nd], w = rop[l + 3 * nd];
+        const double c = sqrt(gam2 * rop[l + 4 * nd]);
+        const double vmu = gam1 * xmut[l], volu = detj * r, xmvis = vmu / volu;
+        for (int d = 0; d < 3; d++) {
+          double qn, tc2;
+          if (full) {
+            const double *t = T[d];
+            const long lp = lt + minc[d];
+            const double tcx = .5 * (t[lt] + t[lp]), tcy = .5 * (t[lt + ndm] + t[lp + ndm]);
+            const double tcz = .5 * (t[lt + 2 * ndm] + t[lp + 2 * ndm]);
+            tc2 = .5 * (sqrt(t[lt] * t[lt] + t[lt + ndm] * t[lt + ndm] + t[lt + 2 * ndm] * t[lt + 2 * ndm]) +
+                        sqrt(t[lp] * t[lp] + t[lp + ndm] * t[lp + ndm] + t[lp + 2 * ndm] * t[lp + 2 * ndm]));
+            qn = tcx * u + tcy * v + tcz * w;
+          } else {
+            tc2 = tc2c[d];
+            qn = tcc[d] * (d == 0 ? u : (d == 1 ? v : w));
+          }
+          const double cn = c * tc2, vm = fabs(qn) + cn;
+          coe[l + (1 + d) * nd] = vm * 2. + xmvis * tc2 * tc2 * 4.;
+        }
+        coe[l + 4 * nd] = xid + coe[l] * (coe[l + nd] + coe[l + 2 * nd] + coe[l + 3 * nd]) * 0.5;
+      }
+}
+
+/* Newton residual of the BDF scheme (Fast/FastS/FastS/Compute/core3as2.for:37-45,232-266,300-338):
+ * drodm = dt/vol * balance + c1 W(iterate) + c2 W(n) + c3 W(n-1), BDF1 at the very first time step. */
+void fo_core3as2(const i32 *p, const double *pr, int nitcfg, int first_it, const i32 *ind, const double *rop,
+                 const double *rop_n, const double *rop_n1, double *drodm, const double *coe)
+{
+  GEOM(p)
+  const double cv = pr[CVINF];
+  double c1, c2, c3;
+  if (first_it == 0 || p[DTLOC] == 1) { c1 = -1.; c2 = 1.; c3 = 0.; }
+  else { c1 = -1.5; c2 = 2.; c3 = -0.5; }
+  const double c4 = c1 + c2;
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k);
+#define Q(a, e) (a)[l + (e) * nd]
+        const double roe = Q(rop, 0) * (cv * Q(rop, 4) + 0.5 * (Q(rop, 1) * Q(rop, 1) + Q(rop, 2) * Q(rop, 2) + Q(rop, 3) * Q(rop, 3)));
+        const double roe_n1 = Q(rop_n1, 0) * (cv * Q(rop_n1, 4) + 0.5 * (Q(rop_n1, 1) * Q(rop_n1, 1) + Q(rop_n1, 2) * Q(rop_n1, 2) + Q(rop_n1, 3) * Q(rop_n1, 3)));
+        if (nitcfg == 1) {
+          Q(drodm, 0) = coe[l] * Q(drodm, 0) + c4 * Q(rop, 0) + c3 * Q(rop_n1, 0);
+          for (int e = 1; e <= 3; e++)
+            Q(drodm, e) = coe[l] * Q(drodm, e) + c4 * Q(rop, e) * Q(rop, 0) + c3 * Q(rop_n1, e) * Q(rop_n1, 0);
+          Q(drodm, 4) = coe[l] * Q(drodm, 4) + c4 * roe + c3 * roe_n1;
+        } else {
+          const double roe_n = Q(rop_n, 0) * (cv * Q(rop_n, 4) + 0.5 * (Q(rop_n, 1) * Q(rop_n, 1) + Q(rop_n, 2) * Q(rop_n, 2) + Q(rop_n, 3) * Q(rop_n, 3)));
+          Q(drodm, 0) = coe[l] * Q(drodm, 0) + c1 * Q(rop, 0) + c2 * Q(rop_n, 0) + c3 * Q(rop_n1, 0);
+          for (int e = 1; e <= 3; e++)
+            Q(drodm, e) = coe[l] * Q(drodm, e) + c1 * Q(rop, e) * Q(rop, 0) + c2 * Q(rop_n, e) * Q(rop_n, 0) +
+                          c3 * Q(rop_n1, e) * Q(rop_n1, 0);
+          Q(drodm, 4) = coe[l] * Q(drodm, 4) + c1 * roe + c2 * roe_n + c3 * roe_n1;
+        }
+#undef Q
+      }
+}
+
+typedef struct {
+  const i32 *p;
+  double gam1, gamm1, gam2, cp, signe;
+  long nd, inc[3], ndm, minc[3];
+  int full, sgn;              /* sgn = +1 lower sweep (neighbour l - inc), -1 upper sweep (neighbour l + inc) */
+  const double *t[3];
+  double tcc[3];
+} luctx;
+
+/* b = [A(q_m) + signe*rho_d(m) I] dW(m) for the neighbour m = l -/+ inc(d) of cell l:
+ *   Cartesian zone    Fast/FastS/FastS/Compute/LU/lu_i_3dcart.for, lu_j_3dcart.for, lu_k_3dcart.for
+ *   curvilinear zone  LU/lu_i_3dfull.for, lu_j_3dfull.for, lu_k_3dfull.for (metric = mean of the two faces
+ *                     of the neighbour along d) */
+static inline void lu_neighbour(const luctx *c, int d, long l, long lt, const double *rop, const double *dw,
+                                const double *coe, double *b)
+{
+  const long nd = c->nd;
+  const long l1 = l - c->sgn * c->inc[d];
+  const double signe = c->signe, gamm1 = c->gamm1, gam2 = c->gam2, gam1 = c->gam1, cp = c->cp;
+  const double u = rop[l1 + nd], v = rop[l1 + 2 * nd], w = rop[l1 + 3 * nd], t = rop[l1 + 4 * nd];
+  const double q2 = .5 * (u * u + v * v + w * w);
+  const double h = cp * t + q2;
+  const double ph2 = gamm1 * q2;
+  const double cr = coe[l1 + (1 + d) * nd] * signe;
+  const double d1 = dw[l1], d2 = dw[l1 + nd], d3 = dw[l1 + 2 * nd], d4 = dw[l1 + 3 * nd], d5 = dw[l1 + 4 * nd];
+  if (c->full) {
+    const double *tt = c->t[d];
+    const long ndm = c->ndm;
+    long lt1, lt2;
+    if (c->sgn > 0) { lt1 = lt - c->minc[d]; lt2 = lt; }
+    else { lt1 = lt + c->minc[d]; lt2 = lt + 2 * c->minc[d]; }
+    const double tcx = 0.5 * (tt[lt2] + tt[lt1]);
+    const double tcy = 0.5 * (tt[lt2 + ndm] + tt[lt1 + ndm]);
+    const double tcz = 0.5 * (tt[lt2 + 2 * ndm] + tt[lt1 + 2 * ndm]);
+    const double qn = tcx * u + tcy * v + tcz * w;
+    const double b11 = cr, b12 = tcx, b13 = tcy, b14 = tcz;
+    const double b21 = (tcx * ph2 - u * qn), b22 = (qn - tcx * gam2 * u) + cr;
+    const double b23 = (tcy * u - tcx * gamm1 * v), b24 = (tcz * u - tcx * gamm1 * w), b25 = tcx * gamm1;
+    const double b31 = (tcy * ph2 - v * qn), b32 = (tcx * v - tcy * gamm1 * u);
+    const double b33 = (qn - tcy * gam2 * v) + cr, b34 = (tcz * v - tcy * gamm1 * w), b35 = tcy * gamm1;
+    const double b41 = (tcz * ph2 - w * qn), b42 = (tcx * w - tcz * gamm1 * u);
+    const double b43 = (tcy * w - tcz * gamm1 * v), b44 = (qn - tcz * gam2 * w) + cr, b45 = tcz * gamm1;
+    const double b51 = qn * (ph2 - h), b52 = (tcx * h - gamm1 * u * qn), b53 = (tcy * h - gamm1 * v * qn);
+    const double b54 = (tcz * h - gamm1 * w * qn), b55 = (gam1 * qn) + cr;
+    b[0] = b11 * d1 + b12 * d2 + b13 * d3 + b14 * d4;
+    b[1] = b21 * d1 + b22 * d2 + b23 * d3 + b24 * d4 + b25 * d5;
+    b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
+    b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
+    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    return;
+  }
+  const double tc = c->tcc[d];
+  if (d == 0) {
+    const double qn = tc * u;
+    const double b11 = cr, b12 = tc, b21 = (tc * ph2 - u * qn), b22 = (qn - tc * gam2 * u) + cr;
+    const double b23 = (-tc * gamm1 * v), b24 = (-tc * gamm1 * w), b25 = tc * gamm1;
+    const double b31 = (-v * qn), b32 = (tc * v), b33 = (qn) + cr;
+    const double b41 = (-w * qn), b42 = (tc * w), b44 = (qn) + cr;
+    const double b51 = qn * (ph2 - h), b52 = (tc * h - gamm1 * u * qn), b53 = (-gamm1 * v * qn);
+    const double b54 = (-gamm1 * w * qn), b55 = (gam1 * qn) + cr;
+    b[0] = b11 * d1 + b12 * d2;
+    b[1] = b21 * d1 + b22 * d2 + b23 * d3 + b24 * d4 + b25 * d5;
+    b[2] = b31 * d1 + b32 * d2 + b33 * d3;
+    b[3] = b41 * d1 + b42 * d2 + b44 * d4;
+    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+  } else if (d == 1) {
+    const double qn = tc * v;
+    const double b11 = cr, b13 = tc, b21 = (-u * qn), b22 = qn + cr, b23 = tc * u;
+    const double b31 = (tc * ph2 - v * qn), b32 = (-tc * gamm1 * u), b33 = (qn - tc * gam2 * v) + cr;
+    const double b34 = (-tc * gamm1 * w), b35 = tc * gamm1;
+    const double b41 = (-w * qn), b43 = (tc * w), b44 = (qn) + cr;
+    const double b51 = qn * (ph2 - h), b52 = (-gamm1 * u * qn), b53 = (tc * h - gamm1 * v * qn);
+    const double b54 = (-gamm1 * w * qn), b55 = (gam1 * qn) + cr;
+    b[0] = b11 * d1 + b13 * d3;
+    b[1] = b21 * d1 + b22 * d2 + b23 * d3;
+    b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
+    b[3] = b41 * d1 + b43 * d3 + b44 * d4;
+    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+  } else {
+    const double qn = tc * w;
+    const double b11 = cr, b14 = tc, b21 = -u * qn, b22 = qn + cr, b24 = tc * u;
+    const double b31 = -v * qn, b33 = qn + cr, b34 = tc * v;
+    const double b41 = tc * ph2 - w * qn, b42 = -tc * gamm1 * u, b43 = -tc * gamm1 * v;
+    const double b44 = (qn - tc * gam2 * w) + cr, b45 = tc * gamm1;
+    const double b51 = qn * (ph2 - h), b52 = -gamm1 * u * qn, b53 = -gamm1 * v * qn;
+    const double b54 = tc * h - gamm1 * w * qn, b55 = gam1 * qn + cr;
+    b[0] = b11 * d1 + b14 * d4;
+    b[1] = b21 * d1 + b22 * d2 + b24 * d4;
+    b[2] = b31 * d1 + b33 * d3 + b34 * d4;
+    b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
+    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+  }
+}
+
+static void luctx_init(luctx *c, const i32 *p, const double *pr, const double *ti, const double *tj,
+                       const double *tk, int sgn)
+{
+  c->p = p;
+  c->gam1 = pr[GAMMA]; c->gamm1 = c->gam1 - 1.; c->cp = pr[GAMMA] * pr[CVINF]; c->gam2 = c->gamm1 - 1.;
+  c->sgn = sgn; c->signe = sgn > 0 ? 0.5 : -0.5;
+  c->nd = p[NDIMDX];
+  c->inc[0] = 1; c->inc[1] = p[NIJK]; c->inc[2] = (long)p[NIJK] * p[NIJK + 1];
+  c->ndm = p[NDIMDX_MTR];
+  c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
+  c->full = p[ITYPZONE] == 0;
+  c->t[0] = ti; c->t[1] = tj; c->t[2] = tk;
+  c->tcc[0] = ti[0]; c->tcc[1] = tj[0]; c->tcc[2] = tk[0];
+}
+
+/* LU-SGS on the range ind, in place in dw (the reference's drodm_in and drodm_out are the same array
+ * when nb_relax = 1 and lu_match = 0, Fast/FastS/FastS/Compute/lhs.cpp:151-153), followed plane by
+ * plane by the Newton update into rop_1.
+ *   lower sweep  LU/invlu_l.for:90-215 (curvilinear: k then j then i), :346-476 (Cartesian: j then k then i)
+ *   upper sweep  LU/invlu_u.for:93-263, :439-615 (multiply by the diagonal, k then j then i, divide)
+ *   update       LU/mjr_newton.for
+ * A cell on the first plane / line / point of a sweep skips the neighbours outside the range. */
+void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const double *rop, double *rop_1,
+              const double *ti, const double *tj, const double *tk, const double *coe)
+{
+  GEOM(p)
+  luctx c;
+  double b[5];
+  const double cvinv = 1. / pr[CVINF], cvinv2 = 0.5 * cvinv;
+  const double *coe5 = coe + 4 * nd;
+  /* ---- lower ---- */
+  luctx_init(&c, p, pr, ti, tj, tk, +1);
+  const int order_lo[2] = {c.full ? 2 : 1, c.full ? 1 : 2};
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++) {
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+        const double xal = coe[l] * c.signe;
+        for (int s = 0; s < 2; s++) {
+          const int d = order_lo[s];
+          if ((d == 1 && j == ind[2]) || (d == 2 && k == ind[4])) continue;
+          lu_neighbour(&c, d, l, lt, rop, dw, coe, b);
+          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+        }
+      }
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+        if (i > ind[0]) {
+          const double xal = coe[l] * c.signe;
+          lu_neighbour(&c, 0, l, lt, rop, dw, coe, b);
+          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+        }
+        const double diag = 1. / coe5[l];
+        for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] * diag;
+      }
+    }
+  /* ---- upper + Newton update ---- */
+  luctx_init(&c, p, pr, ti, tj, tk, -1);
+  for (int k = ind[5]; k >= ind[4]; k--) {
+    for (int j = ind[3]; j >= ind[2]; j--) {
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+        const double xal = coe[l] * c.signe;
+        const double diag = coe5[l];
+        for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] * diag;
+        if (k < ind[5]) {
+          lu_neighbour(&c, 2, l, lt, rop, dw, coe, b);
+          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+        }
+        if (j < ind[3]) {
+          lu_neighbour(&c, 1, l, lt, rop, dw, coe, b);
+          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+        }
+      }
+      for (int i = ind[1]; i >= ind[0]; i--) {
+        const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+        if (i < ind[1]) {
+          const double xal = coe[l] * c.signe;
+          lu_neighbour(&c, 0, l, lt, rop, dw, coe, b);
+          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+        }
+        const double diag = 1. / coe5[l];
+        for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] * diag;
+      }
+    }
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k);
+        const double ro_old = rop[l], u_old = rop[l + nd], v_old = rop[l + 2 * nd], w_old = rop[l + 3 * nd];
+        const double t_old = rop[l + 4 * nd];
+        rop_1[l] = rop[l] + dw[l];
+        const double r_1 = 1. / rop_1[l];
+        rop_1[l + nd] = (ro_old * u_old + dw[l + nd]) * r_1;
+        rop_1[l + 2 * nd] = (ro_old * v_old + dw[l + 2 * nd]) * r_1;
+        rop_1[l + 3 * nd] = (ro_old * w_old + dw[l + 3 * nd]) * r_1;
+        const double roe_old = ro_old * (pr[CVINF] * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+        rop_1[l + 4 * nd] = (roe_old + dw[l + 4 * nd]) * r_1 * cvinv -
+                            cvinv2 * (rop_1[l + nd] * rop_1[l + nd] + rop_1[l + 2 * nd] * rop_1[l + 2 * nd] +
+                                      rop_1[l + 3 * nd] * rop_1[l + 3 * nd]);
+      }
+  }
+}
+
+/* One Newton sub-iteration of one zone, one cache block, one thread: sequence of
+ * Fast/FastS/FastS/Compute/navier_stokes_struct.for:199-275 (viscosity and coefficients at the first
+ * sub-iteration, on the whole zone), :295-301 (drodm = 0), :310-345 (fluxes), :406-419 (core3as2) and
+ * Fast/FastS/FastS/Compute/lhs.cpp:135-161 (invlu).  rop_ss = current Newton iterate (ro at the first
+ * sub-iteration, ro_p1 afterwards); the new iterate is written to ro_p1.  Returns -1 where the LU range
+ * would have to be extended over wall ghost cells (BCzone.cpp:100-127), which is not restated.
+ * newton_rhs (may be NULL) receives the Newton residual before the LU solve, the array whose norms the
+ * reference tabulates (Fast/FastS/FastS/Compute/residus_navier.h, cprdu3s1_incl.for:47-71). */
+int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it, const double *ro,
+                        const double *ro_m1, double *ro_p1, double *drodm, double *coe, double *xmut,
+                        double *wig, const double *ti, const double *tj, const double *tk, const double *vol,
+                        double *newton_rhs)
+{
+  const int iv = p[IJKV], jv = p[IJKV + 1], kv = p[IJKV + 2];
+  const int f = p[NIJK + 3], fk = p[NIJK + 4];
+  const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
+  const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
+  if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[DTLOC] != 0 || p[NEQ] != 5) return -1;
+  const int pt_bcs = p[PT_BC];
+  for (int ndf = 0; ndf < p[pt_bcs]; ndf++) {
+    const int bt = p[p[pt_bcs + 1 + ndf]];
+    if ((bt >= 3 && bt <= 7) || bt == 12 || bt == 18 || bt == 30) return -1;
+  }
+  const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
+  if (nitcfg == 1) {
+    if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);
+    fo_tstb3_implicit(p, pr, first_it, all, rop_ss, xmut, coe, ti, tj, tk, vol);
+  }
+  fo_init_rhs(p, nitcfg, sdm, drodm);
+  if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_ss, wig);
+  fo_flux(p, pr, sdm, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);
+  fo_core3as2(p, pr, nitcfg, first_it, sdm, rop_ss, ro, ro_m1, drodm, coe);
+  if (newton_rhs) memcpy(newton_rhs, drodm, sizeof(double) * 5 * (size_t)p[NDIMDX]);
+  fo_invlu(p, pr, sdm, drodm, rop_ss, ro_p1, ti, tj, tk, coe);
+  return 0;
+}

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libfasts_oracle.so")
 _lib = None
 
 NIJK = 0; IJKV = 20; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NDIMDX = 41; NDIMDX_MTR = 43
-NSSITER = 58; DTC = 0
+NSSITER = 58; DTC = 0; ITYPCP = 29; NEQ_COE = 39
 
 
 def build():
@@ -30,6 +30,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.fo_step.restype = ctypes.c_int
         _lib.fo_bczone.restype = ctypes.c_int
+        _lib.fo_subiter_implicit.restype = ctypes.c_int
     return _lib
 
 
@@ -53,7 +54,9 @@ class OracleZone:
         self.ti = self.mtr[0:nm * nij]; self.tj = self.mtr[nm * nij:2 * nm * nij]
         self.tk = self.mtr[2 * nm * nij:2 * nm * nij + nm * nk]
         self.vol = self.mtr[2 * nm * nij + nm * nk:]
-        self.drodm = np.zeros(n); self.coe = np.zeros(self.ndimdx)
+        self.implicit = int(p[ITYPCP]) == 1
+        self.first_it = 0          # FIRST_IT of the reference: 0 until one time step is done (BDF1)
+        self.drodm = np.zeros(n); self.coe = np.zeros(self.ndimdx * max(1, int(p[NEQ_COE])))
         self.xmut = np.zeros(self.ndimdx); self.wig = np.zeros(3 * self.ndimdx)
         self.stage1_rhs = np.zeros(n)
 
@@ -61,7 +64,18 @@ class OracleZone:
         if lib().fo_bczone(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ti), _p(self.tj), _p(self.tk)) != 0:
             raise NotImplementedError("oracle: unsupported BC tag")
 
+    def nsub(self):
+        """Sub-iterations that advance the solution: the last slot of an implicit step is the
+        verification pass (Fast/FastS/FastS/Compute/computePT.cpp:579-585)."""
+        n = int(self.pint[NSSITER])
+        return n - 1 if self.implicit else n
+
     def step(self):
+        if self.implicit:
+            for nstep in range(1, self.nsub() + 1):
+                self.stage(nstep)
+                self.bcs(nstep)
+            return self.rotate()
         rc = lib().fo_step(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ro_p1), _p(self.drodm),
                            _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj),
                            _p(self.tk), _p(self.vol), _p(self.stage1_rhs))
@@ -71,6 +85,15 @@ class OracleZone:
             self.ro_m1, self.ro, self.ro_p1 = self.ro, self.ro_p1, self.ro_m1
 
     def residuals(self):
+        """L2 and Loo norms of the first sub-iteration: explicit = dt/vol * balance, implicit = Newton
+        residual (display_ss_iteration.cpp:128-141), both divided by dt."""
+        p = self.pint
+        if self.implicit:
+            ni, nj, nk = int(p[NIJK]), int(p[NIJK + 1]), int(p[NIJK + 2]); f = int(p[NIJK + 3]); fk = int(p[NIJK + 4])
+            d = self.stage1_rhs.reshape(self.neq, -1)[:, :ni * nj * nk].reshape(self.neq, nk, nj, ni)
+            d = d[:, fk:nk - fk, f:nj - f, f:ni - f].reshape(self.neq, -1)
+            dt = self.preal[DTC]
+            return np.sqrt((d * d).sum(axis=1) / d.shape[1]) / dt, np.abs(d).max(axis=1) / dt
         s = np.zeros(5); m = np.zeros(5)
         lib().fo_residual(_p(self.pint), _p(self.stage1_rhs), _p(self.coe), _p(s), _p(m))
         p = self.pint
@@ -81,9 +104,19 @@ class OracleZone:
     # -- split form of a time step, for multi-zone jobs -----------------------------------
     def roles(self, nstep):
         """(input, output) arrays of sub-iteration nstep (Fast/FastS/FastS/Compute/gsdr3.cpp:137-145)."""
+        if self.implicit:      # Newton iterate -> P1 (gsdr3.cpp:137-140)
+            return (self.ro if nstep == 1 else self.ro_p1, self.ro_p1)
         return (self.ro, self.ro_p1) if nstep % 2 == 1 else (self.ro_p1, self.ro)
 
     def stage(self, nstep):
+        if self.implicit:
+            rc = lib().fo_subiter_implicit(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), ctypes.c_int(self.first_it),
+                                           _p(self.ro), _p(self.ro_m1), _p(self.ro_p1), _p(self.drodm), _p(self.coe),
+                                           _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj), _p(self.tk), _p(self.vol),
+                                           _p(self.stage1_rhs) if nstep == 1 else None)
+            if rc != 0:
+                raise NotImplementedError("oracle: implicit options outside LU-SGS nb_relax=1 / lu_match=0 / no wall")
+            return
         rin, rout = self.roles(nstep)
         lib().fo_subiter(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), _p(rin), _p(rout),
                          _p(self.drodm), _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti),
@@ -97,8 +130,11 @@ class OracleZone:
             raise NotImplementedError("oracle: unsupported BC tag")
 
     def rotate(self):
-        if int(self.pint[NSSITER]) % 2 == 1:
+        # explicit: the result sits in P1 only after an odd number of stages; implicit: always
+        # (Fast/FastS/FastS/PyTree.py:231-233)
+        if self.implicit or int(self.pint[NSSITER]) % 2 == 1:
             self.ro_m1, self.ro, self.ro_p1 = self.ro, self.ro_p1, self.ro_m1
+        self.first_it = 1
 
 
 class OracleSolver:
@@ -124,8 +160,7 @@ class OracleSolver:
             z.fill_ghostcells()
 
     def step(self):
-        nssiter = int(self.zones[0].pint[NSSITER])
-        for nstep in range(1, nssiter + 1):
+        for nstep in range(1, self.zones[0].nsub() + 1):
             for z in self.zones:
                 z.stage(nstep)
             self.transfers([z.roles(nstep)[1] for z in self.zones])

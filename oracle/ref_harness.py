@@ -242,11 +242,58 @@ class RefSolver:
         for nd, zn in enumerate(self.zones):
             self._bczone(nd, zn, 1, arrays[nd])
 
+    # -- implicit: LU-SGS solve + Newton update of one zone ---------------------------------
+    def _invlu(self, nd, zn, nitrun, nstep, ro_ssiter):
+        """Fast/FastS/FastS/Compute/lhs.cpp:135-161 for nb_relax = 1, lu_match = 0 and no wall BC:
+        BCzone(lrhs=1) then leaves the residual alone and the LU range is the zone interior
+        (Fast/FastS/FastS/BC/BCzone.cpp:100-127)."""
+        L = lib()
+        p = zn.pint
+        pt_bcs = int(p[PT_BC])
+        for ndf in range(int(p[pt_bcs])):
+            bt = int(p[int(p[pt_bcs + 1 + ndf])])
+            if (3 <= bt <= 7) or bt in (12, 18, 30):
+                raise NotImplementedError("ref_harness: implicit wall treatment (BC tag %d)" % bt)
+        assert p[71] == 1 and p[75] == 0, "nb_relax = 1 and lu_match = 0 only"
+        dummy = np.zeros(8)
+        L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(zn.ind_dm), _p(zn.ind_dm), _i(1),
+                 _p(zn.ro_p1), _p(ro_ssiter), _p(zn.drodm), _p(zn.drodm),
+                 _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),
+                 _p(zn.coe), _p(dummy), _i(1))
+
+    def step_implicit(self, nitrun):
+        """One implicit time step: nssiter-1 Newton sub-iterations (the last slot of nssiter is the
+        verification pass, skipped when lssiter_verif = 0: Fast/FastS/FastS/Compute/computePT.cpp:579-585),
+        each = Newton residual (navier_stokes_struct: fluxes + core3as2), LU-SGS + update into P1
+        (invlu), joins and BCs on P1 (gsdr3.cpp:137-140); then the level rotation of
+        Fast/FastS/FastS/PyTree.py:231-232."""
+        z0 = self.zones[0]
+        nssiter = int(z0.pint[NSSITER])
+        assert z0.pint[ITYPCP] == 1
+        for nstep in range(1, nssiter):
+            for nd, zn in enumerate(self.zones):
+                ssiter = zn.ro if nstep == 1 else zn.ro_p1
+                self._navier_stokes(nd, zn, nitrun, nstep, ssiter)
+                if nstep == 1:
+                    zn.stage1_rhs = zn.drodm.copy()
+            for nd, zn in enumerate(self.zones):
+                ssiter = zn.ro if nstep == 1 else zn.ro_p1
+                self._invlu(nd, zn, nitrun, nstep, ssiter)
+            cl = [zn.ro_p1 for zn in self.zones]
+            self._transfers(cl)
+            for nd, zn in enumerate(self.zones):
+                self._bczone(nd, zn, nstep, cl[nd])
+        self.first_it = 1
+        for zn in self.zones:
+            zn.ro_m1, zn.ro, zn.ro_p1 = zn.ro, zn.ro_p1, zn.ro_m1
+
     def step(self, nitrun):
         """One time step = nssiter sub-iterations, then M1 <- N <- P1 rotation."""
         z0 = self.zones[0]
         nssiter = int(z0.pint[NSSITER])
-        assert z0.pint[ITYPCP] == 2, "RefSolver.step: explicit schemes only"
+        if z0.pint[ITYPCP] == 1:
+            return self.step_implicit(nitrun)
+        assert z0.pint[ITYPCP] == 2, "RefSolver.step: explicit and implicit (LU-SGS) schemes only"
         for nstep in range(1, nssiter + 1):
             cl = []
             for nd, zn in enumerate(self.zones):
@@ -280,7 +327,8 @@ class RefSolver:
             d = zn.stage1_rhs.reshape(zn.neq, -1)[:, :ni * nj * nk].reshape(zn.neq, nk, nj, ni)
             d = d[:, fk:nk - fk, f:nj - f, f:ni - f]
             c = zn.coe[:zn.ndimdx][:ni * nj * nk].reshape(nk, nj, ni)[fk:nk - fk, f:nj - f, f:ni - f]
-            r = d * c[None]
+            # implicit: stage1_rhs is the Newton residual, already scaled by dt/vol (core3as2.for)
+            r = d * c[None] if p[ITYPCP] == 2 else d
             n = r[0].size
             dt = zn.preal[DTC]
             out.append((np.sqrt((r * r).reshape(zn.neq, -1).sum(axis=1) / n) / dt,

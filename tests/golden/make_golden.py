@@ -3,7 +3,7 @@
 (oracle/_ref/libfast_ref.so, built by oracle/build_ref.py from the Fortran sources where they
 lie in the reference tree) driven by oracle/ref_harness.py.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case names]
 
 Each file holds the inputs (Parameter_int, Parameter_real, metrics, initial field without
 ghost fill, join tables) and the reference's outputs (field after 1, 3 and `nit` time steps and
@@ -44,24 +44,44 @@ CASES = {
     'box_mixed_bc_euler':       ('tgv', (8, 9, 7), 'ausmpred', 'Euler', (1, 1, 1), 'single', 10,
                                  {'imin': 'BCExtrapolate', 'imax': 'BCFarfield', 'jmin': 'BCWall',
                                   'jmax': 'BCSymmetryPlane', 'kmin': 'BCWallInviscid'}),
+    # curvilinear zones (perturbed mesh) and implicit LU-SGS steps: a dict of options after the BCs
+    'curv_senseur_lamin':       ('tgv', (12, 10, 9), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 20, None,
+                                 {'perturb': 0.15}),
+    'curv_channel_ausmpred':    ('tgv', (10, 9, 8), 'ausmpred', 'NSLaminar', (1, 2, 1), 'single', 10,
+                                 {'imin': 'BCFarfield', 'imax': 'BCFarfield', 'kmin': 'BCWallInviscid', 'kmax': 'BCWall'},
+                                 {'perturb': 0.15}),
+    'implicit_ausmpred_lamin':  ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'single', 10, None,
+                                 {'ss_iteration': 5, 'time_step': 0.02}),
+    'implicit_curv_senseur':    ('tgv', (10, 9, 8), 'senseur', 'NSLaminar', (1, 1, 2), 'single', 6, None,
+                                 {'ss_iteration': 3, 'time_step': 0.02, 'perturb': 0.15}),
     'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
     'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
 }
 
 
-def build(kind, n, scheme, model, blocks, cache, bcs=None):
+def build(kind, n, scheme, model, blocks, cache, bcs=None, opts=None, modulo_verif=50):
+    """The tree of one case; shared with the tests that replay the golden vectors."""
     extra = SINGLE if cache == 'single' else None
+    opts = opts or {}
     if kind == 'tgv':
-        return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra, bcs=bcs)
+        kw = {}
+        if 'ss_iteration' in opts:
+            kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': opts['ss_iteration']}}
+        return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra, bcs=bcs, modulo_verif=modulo_verif,
+                         perturb=opts.get('perturb', 0.), time_step=opts.get('time_step'), **kw)
     return cases.vortex(n, scheme, extra_numz=extra)
 
 
 def main():
     if not R.available():
         raise SystemExit("make_golden: oracle/_ref/libfast_ref.so is missing (python oracle/build_ref.py)")
+    only = sys.argv[1:]          # optional: names of the cases to (re)generate
     for name, spec in CASES.items():
+        if only and name not in only:
+            continue
         (kind, n, scheme, model, blocks, cache, nit) = spec[:7]
-        t = build(kind, n, scheme, model, blocks, cache, spec[7] if len(spec) > 7 else None)
+        t = build(kind, n, scheme, model, blocks, cache, spec[7] if len(spec) > 7 else None,
+                  spec[8] if len(spec) > 8 else None)
         metrics = prepare(t)
         zones = Internal.getZones(t)
         nb = len(zones)
@@ -91,6 +111,7 @@ def main():
         s.fill_ghostcells('ro')
         for b in range(nb):
             out['ghost_%d' % b] = rz[b].ro.copy()
+            rz[b].ro_m1[:] = rz[b].ro; rz[b].ro_p1[:] = rz[b].ro      # the three levels start equal
         res = np.zeros((nit, nb, 2, 5))
         for it in range(1, nit + 1):
             s.step(it)

@@ -2,6 +2,7 @@
 bit-exact fields after 1, 3 and nit time steps, residual history to summation order."""
 import glob
 import os
+import sys
 import numpy as np
 import pytest
 
@@ -14,34 +15,24 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
 
-CASES = {
-    'tgv12_senseur_lamin':      ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1)),
-    'tgv12_ausmpred_lamin':     ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1)),
-    'tgv12_roe_lamin':          ('tgv', 12, 'roe', 'NSLaminar', (1, 1, 1)),
-    'tgv10_senseur_euler':      ('tgv', 10, 'senseur', 'Euler', (1, 1, 1)),
-    'vortex12_roe_euler':       ('vortex', 12, 'roe', None, (1, 1, 1)),
-    'tgv_ragged_senseur_lamin': ('tgv', (13, 6, 9), 'senseur', 'NSLaminar', (1, 1, 1)),
-    'tgv_2x2_senseur_lamin':    ('tgv', (8, 12, 20), 'senseur', 'NSLaminar', (1, 2, 2)),
-    'channel_senseur_lamin':    ('tgv', (12, 10, 8), 'senseur', 'NSLaminar', (1, 1, 1),
-                                 {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}),
-    'box_farfield_ausmpred':    ('tgv', (9, 8, 10), 'ausmpred', 'NSLaminar', (1, 1, 1),
-                                 {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')}),
-    'box_mixed_bc_euler':       ('tgv', (8, 9, 7), 'ausmpred', 'Euler', (1, 1, 1),
-                                 {'imin': 'BCExtrapolate', 'imax': 'BCFarfield', 'jmin': 'BCWall',
-                                  'jmax': 'BCSymmetryPlane', 'kmin': 'BCWallInviscid'}),
-}
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import make_golden as MG
+
+# the single-cache-block cases of the generator (the reference's reproducible operation order)
+CASES = {k: v for k, v in MG.CASES.items() if v[5] == 'single'}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_gpu_equals_reference_golden(name):
-    kind, n, scheme, model, blocks = CASES[name][:5]
-    bcs = CASES[name][5] if len(CASES[name]) > 5 else None
+    spec = CASES[name]
+    kind, n, scheme, model, blocks = spec[:5]
     g = np.load(os.path.join(HERE, 'golden', name + '.npz'))
-    if kind == 'tgv':
-        t = cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=SINGLE, modulo_verif=1, bcs=bcs)
-    else:
-        t = cases.vortex(n, scheme, extra_numz=SINGLE)
+    t = MG.build(kind, n, scheme, model, blocks, 'single', spec[7] if len(spec) > 7 else None,
+                 spec[8] if len(spec) > 8 else None, modulo_verif=1)
+    if kind != 'tgv':
         FastC._setNum2Base(t, {'temporal_scheme': 'explicit', 'modulo_verif': 1})
+    if isinstance(n, int):
+        n = (n, n, n)
     tc = None
     zones = Internal.getZones(t)
     if len(zones) > 1:
