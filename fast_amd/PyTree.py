@@ -141,14 +141,19 @@ def _compute(t, metrics, nitrun, tc=None, graph=None, tc2=None, graph2=None, lay
     dtloc = Internal.getNodeFromName1(own, '.Solver#dtloc')[1]
     nitmax = int(dtloc[0])
     zones = Internal.getZones(t)
+    itypcp = int(Internal.getNodeFromName2(zones[0], 'Parameter_int')[1][29])
+    implicit = itypcp < 2
     if layer == "Python":
         # one sub-iteration per native call, transfers and BCs driven from here
-        # (Fast/FastS/FastS/PyTree.py:119-209)
+        # (Fast/FastS/FastS/PyTree.py:119-209); the last slot of an implicit step is the
+        # verification pass, skipped like there (:123)
         for nstep in range(1, nitmax + 1):
+            if implicit and nstep == nitmax:
+                continue
             ctx.stage(nitrun, nstep)
             ctx.local_joins(nstep)
             ctx.bcs(nstep)
-        if nitmax % 2 == 1:
+        if implicit or nitmax % 2 == 1:
             ctx.rotate()
         nit = 1
     else:
@@ -157,7 +162,7 @@ def _compute(t, metrics, nitrun, tc=None, graph=None, tc2=None, graph2=None, lay
     # switch pointers at the end of the time step (Fast/FastS/FastS/PyTree.py:231-233)
     case = nit % 3
     if case != 0:
-        FastC.switchPointers__(zones, case, nitmax % 2 + 2)
+        FastC.switchPointers__(zones, case, 3 if implicit else nitmax % 2 + 2)
     FastC.HOOK["FIRST_IT"] = 1
     FastC.FIRST_IT = 1
     if not _lazy():

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("FASTS_HIP_LIB", os.path.join(HERE, "csrc", "libfasts_
 FS_LEVEL_N, FS_LEVEL_M1, FS_LEVEL_P1 = 1, 2, 4
 
 SYMBOLS = [
-    "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif",
+    "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif", "fs_set_first_it",
     "fs_zone_add", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_sync",
@@ -96,6 +96,9 @@ class Context:
 
     def set_verif(self, modulo_verif):
         self._chk(lib().fs_set_verif(self._h, ctypes.c_int(int(modulo_verif))), "fs_set_verif")
+
+    def set_first_it(self, first_it):
+        self._chk(lib().fs_set_first_it(self._h, ctypes.c_int(int(first_it))), "fs_set_first_it")
 
     def zone_add(self, param_int, param_real, ro, ro_m1, ro_p1, mtr):
         for a in (ro, ro_m1, ro_p1):

@@ -15,7 +15,7 @@ namespace {
 // Parameter_int / Parameter_real slots (Fast/FastS/FastS/param_solver.h:77-306)
 enum { NIJK = 0, NIJK_MTR = 5, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
        NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
-       SLOPE = 64, PT_BC = 70, SENSORTYPE = 85 };
+       SLOPE = 64, PT_BC = 70, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
 enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
        VXINF = 19, VYINF = 20, VZINF = 21,
        PSIROE = 34 };
@@ -28,6 +28,8 @@ struct Zone {
   double *dev[3] = {nullptr, nullptr, nullptr};
   double *drodm = nullptr, *xmut = nullptr, *wig = nullptr;
   double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]
+  // implicit scheme: coe(nd,5) = dt/vol, spectral radii i/j/k, LU diagonal; one spare time level
+  double *coe = nullptr, *scratch = nullptr;
   double *res_part = nullptr, *res_out = nullptr;
   FsBcWin *bc_dev = nullptr;
   std::vector<FsBcWin> bc;
@@ -63,6 +65,8 @@ struct fs_ctx {
   bool plain_stage = false;   // FASTS_HIP_STAGE=plain: untiled stage kernel (debugging aid)
   bool dma_stage = true;      // default: LDS-DMA staged kernel; FASTS_HIP_STAGE=tile64 selects the register-staged one
   int modulo_verif = 200;
+  bool implicit = false;      // ITYPCP 1: BDF + LU-SGS Newton sub-iterations (all zones of a context agree)
+  int first_it = 0;           // FIRST_IT of the reference: 0 until one time step is complete (BDF1, xid = 1)
   std::string err;
   // stage-kernel timing
   bool timing = false;
@@ -132,6 +136,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
   }
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
@@ -152,6 +157,13 @@ extern "C" int fs_set_verif(fs_ctx *ctx, int modulo_verif)
 {
   if (!ctx || modulo_verif <= 0) return FS_ERR_ARG;
   ctx->modulo_verif = modulo_verif;
+  return FS_OK;
+}
+
+extern "C" int fs_set_first_it(fs_ctx *ctx, int first_it)
+{
+  if (!ctx || (first_it != 0 && first_it != 1)) return FS_ERR_ARG;
+  ctx->first_it = first_it;
   return FS_OK;
 }
 
@@ -190,12 +202,20 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   const int32_t *p = pint;
   if (p[ITYPZONE] != 2 && p[ITYPZONE] != 0)
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Cartesian (zone type 2) and curvilinear (zone type 0) zones are implemented");
-  if (p[ITYPCP] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only the explicit scheme is implemented");
+  if (p[ITYPCP] != 2 && p[ITYPCP] != 1) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: temporal scheme must be explicit or implicit");
+  const bool implicit = p[ITYPCP] == 1;
+  if (!ctx->zones.empty() && implicit != ctx->implicit)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: explicit and implicit zones cannot share a context");
+  if (implicit && (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[IMPLICITSOLVER] != 0))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme is LU-SGS with nb_relax = 1 and lu_match = 0 (no SSOR relaxation, no overlap, no GMRES)");
+  if (implicit && !(ctx->dma_stage && !ctx->plain_stage))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme needs the default stage kernel");
   if (p[NEQ] != 5 || p[IFLOW] > 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Euler / NSLaminar (5 equations) are implemented");
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
   if (p[LALE] != 0 || p[DTLOC] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local time step are not implemented");
-  if (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK]) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
+  if (!implicit && (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK])) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
+  if (implicit && p[NSSITER] < 2) return fail(ctx, FS_ERR_ARG, "fs_zone_add: an implicit step needs at least one Newton sub-iteration (NSSITER >= 2)");
   if (p[NIJK + 3] != 2 || p[NIJK + 4] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two ghost layers in every direction are required");
   if (n_mtr < 4) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short");
   if (p[ITYPZONE] == 0) {
@@ -238,12 +258,13 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   z.cvisq = 1. / 3;
   z.dt = r[DTC];
   z.coe = r[DTC] / mtr[3];  // tstb3_global.for:72-78
+  z.vol0 = mtr[3];
   z.ityp = p[ITYPZONE]; z.ndm = 0; z.mincj = z.minck = 0;
   z.mt[0] = z.mt[1] = z.mt[2] = z.vol = nullptr;
   if (z.ityp == 0) {
     z.ndm = p[NDIMDX_MTR]; z.mincj = p[NIJK_MTR + 1]; z.minck = p[NIJK_MTR + 2];
     // the scalars of the Cartesian path are not used by the curvilinear kernels
-    z.tcx = z.tcy = z.tcz = z.si = z.sj = z.sk = z.volinv = z.coe = 0.;
+    z.tcx = z.tcy = z.tcz = z.si = z.sj = z.sk = z.volinv = z.coe = z.vol0 = 0.;
   }
   z.cv = r[CVINF]; z.cvinv = 1. / z.cv; z.cvinv2 = 0.5 * z.cvinv;  // core3ark3.for:44-46
   {  // invist.for:49-51
@@ -271,6 +292,9 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       snprintf(msg, sizeof msg, "fs_zone_add: boundary condition tag %d is not implemented", tag);
       return fail(ctx, FS_ERR_UNSUPPORTED, msg);
     }
+    if (implicit && ((tag >= 3 && tag <= 7) || tag == 12 || tag == 18 || tag == 30))
+      return fail(ctx, FS_ERR_UNSUPPORTED,
+                  "fs_zone_add: implicit treatment of wall boundaries (LU sweeps extended over the wall ghost cells) is not implemented");
     if ((w.type == FS_BC_WALL_SLIP || w.type == FS_BC_WALL_NOSLIP) && p[KFLUDOM] == 5)
       return fail(ctx, FS_ERR_UNSUPPORTED,
                   "fs_zone_add: the wall-face flux correction of the roe scheme (bfl3) is not implemented; "
@@ -302,11 +326,13 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     hipError_t e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(zn.mtr_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch);
       return fail(ctx, FS_ERR_HIP, std::string("fs_zone_add: metric upload: ") + hipGetErrorString(e));
     }
     z.mt[0] = zn.mtr_dev; z.mt[1] = zn.mtr_dev + 3 * z.ndm; z.mt[2] = zn.mtr_dev + 6 * z.ndm;
     z.vol = zn.mtr_dev + 9 * z.ndm;
   }
+  ctx->implicit = implicit;
   ctx->zones.push_back(std::move(zn));
   return (int)ctx->zones.size() - 1;
 }
@@ -383,6 +409,12 @@ extern "C" int fs_upload(fs_ctx *ctx)
         HIPCHK(ctx, hipMalloc(&zn.wig, nw));
         HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, nw, ctx->stream));
       }
+      if (ctx->implicit) {
+        HIPCHK(ctx, hipMalloc(&zn.coe, nb));
+        HIPCHK(ctx, hipMemsetAsync(zn.coe, 0, nb, ctx->stream));
+        HIPCHK(ctx, hipMalloc(&zn.scratch, nb));
+        HIPCHK(ctx, hipMemsetAsync(zn.scratch, 0, nb, ctx->stream));
+      }
       HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 10 * (size_t)zn.z.jv * zn.z.kv));
       HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * 10));
       if (!zn.bc.empty()) {
@@ -422,10 +454,12 @@ static int level_role(int level)
   return level == FS_LEVEL_N ? 0 : (level == FS_LEVEL_M1 ? 1 : (level == FS_LEVEL_P1 ? 2 : -1));
 }
 
-// stage input / output roles (Fast/FastS/FastS/Compute/gsdr3.cpp:137-145)
-static void stage_roles(int nstep, int &in, int &out)
+// stage input / output roles (Fast/FastS/FastS/Compute/gsdr3.cpp:137-145): explicit stages alternate between N
+// and P1; Newton sub-iterations read N (first) or P1 and always write P1
+static void stage_roles(const fs_ctx *ctx, int nstep, int &in, int &out)
 {
-  if (nstep % 2 == 1) { in = 0; out = 2; }
+  if (ctx->implicit) { in = nstep == 1 ? 0 : 2; out = 2; }
+  else if (nstep % 2 == 1) { in = 0; out = 2; }
   else { in = 2; out = 0; }
 }
 
@@ -457,7 +491,7 @@ static int build_shell_lists(fs_ctx *ctx)
   for (size_t nz = 0; nz < ctx->zones.size(); nz++) {
     Zone &zn = ctx->zones[nz];
     const FsZone &z = zn.z;
-    if (z.ityp == 0) continue;   // curvilinear zones run their stage in one launch
+    if (z.ityp == 0 || ctx->implicit) continue;   // curvilinear / implicit zones run their stage in one piece
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
     std::vector<char> mark((size_t)nblk, 0);
@@ -501,16 +535,27 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
   for (auto &zn : ctx->zones) {
     const FsZone &z = zn.z;
     if (nstep < 1 || nstep > z.nssiter) return fail(ctx, FS_ERR_ARG, std::string(who) + ": sub-iteration out of range");
+    // the last slot of an implicit step is the reference's verification pass (residual only,
+    // Fast/FastS/FastS/Compute/computePT.cpp:579-585): nothing to advance
+    if (ctx->implicit && nstep == z.nssiter) continue;
     int in, out;
-    stage_roles(nstep, in, out);
+    stage_roles(ctx, nstep, in, out);
     double coefH, coefW;
     rk_coefs(z.rk, nstep, coefH, coefW);
     const bool split = part >= 0 && zn.n_shell > 0;
     const bool opens = part <= 0 || !split;      // this call starts the stage of this zone
     const bool closes = part != 0;               // this call ends it (part 0 of an unsplit zone does nothing)
     if (part == 0 && !split) continue;
+    FsBdf bdf = {zn.dev[0], zn.dev[1], -1.5, 2., -0.5, nstep == 1};
+    if (ctx->first_it == 0) { bdf.c1 = -1.; bdf.c2 = 1.; bdf.c3 = 0.; }   // core3as2.for:37-45
+    const FsBdf *pbdf = ctx->implicit ? &bdf : nullptr;
     if (opens && nstep == 1) {
-      if (z.iflow == 2) fsk_invist(z, zn.dev[in], zn.xmut, ctx->stream);
+      if (z.iflow == 2) fsk_invist(z, ctx->implicit ? z.ific : 1, zn.dev[in], zn.xmut, ctx->stream);
+      if (ctx->implicit) {
+        const double *r = zn.preal.data();
+        fsk_coe_implicit(z, ctx->first_it, r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in], zn.xmut, zn.coe,
+                         ctx->stream);
+      }
       if (z.kflu == 2 && ctx->plain_stage && z.ityp != 0) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }
     if (ctx->timing && opens) {
@@ -520,7 +565,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     int krc = 0;
     if (z.ityp == 0)
       krc = fsk_stage_full(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
-                           (unsigned char *)zn.wig, ctx->stream);
+                           (unsigned char *)zn.wig, pbdf, ctx->stream);
     else if (ctx->plain_stage)
       krc = fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
     else if (!ctx->dma_stage)
@@ -531,7 +576,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
       if (!split || nlist > 0)
         krc = fsk_stage_dma(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
-                            (unsigned char *)zn.wig, blist, nlist, ctx->stream);
+                            (unsigned char *)zn.wig, blist, nlist, pbdf, ctx->stream);
     }
     if (krc)
       return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": no kernel for this scheme / model");
@@ -548,8 +593,12 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       ctx->ev_used++;
     }
     if (nstep == 1 && (nitrun % ctx->modulo_verif == 0 || nitrun == 1)) {
-      fsk_residual(z, zn.drodm, zn.res_part, zn.res_out, ctx->stream);
+      fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out, ctx->stream);
       zn.have_res = true;
+    }
+    if (ctx->implicit) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:135-161)
+      if (fsk_lusgs(z, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ctx->stream))
+        return fail(ctx, FS_ERR_STATE, std::string(who) + ": LU-SGS scratch level missing");
     }
   }
   HIPCHK(ctx, hipGetLastError());
@@ -587,10 +636,13 @@ static int local_joins_on(fs_ctx *ctx, int role_of_zone(const void *, int), cons
   return FS_OK;
 }
 
+struct NstepArg { const fs_ctx *ctx; int nstep; };
+
 static int role_from_nstep(const void *arg, int)
 {
+  const NstepArg *a = (const NstepArg *)arg;
   int in, out;
-  stage_roles(*(const int *)arg, in, out);
+  stage_roles(a->ctx, a->nstep, in, out);
   return out;
 }
 
@@ -600,7 +652,8 @@ extern "C" int fs_local_joins(fs_ctx *ctx, int nstep)
 {
   int rc = ensure_ready(ctx, "fs_local_joins");
   if (rc) return rc;
-  local_joins_on(ctx, role_from_nstep, &nstep);
+  NstepArg a = {ctx, nstep};
+  local_joins_on(ctx, role_from_nstep, &a);
   HIPCHK(ctx, hipGetLastError());
   return FS_OK;
 }
@@ -618,7 +671,7 @@ extern "C" int fs_bcs(fs_ctx *ctx, int nstep)
   int rc = ensure_ready(ctx, "fs_bcs");
   if (rc) return rc;
   int in, out;
-  stage_roles(nstep, in, out);
+  stage_roles(ctx, nstep, in, out);
   bcs_on_role(ctx, out);
   HIPCHK(ctx, hipGetLastError());
   return FS_OK;
@@ -631,6 +684,7 @@ extern "C" int fs_rotate(fs_ctx *ctx)
     double *d = zn.dev[1]; zn.dev[1] = zn.dev[0]; zn.dev[0] = zn.dev[2]; zn.dev[2] = d;
     double *h = zn.host[1]; zn.host[1] = zn.host[0]; zn.host[0] = zn.host[2]; zn.host[2] = h;
   }
+  ctx->first_it = 1;   // Fast/FastS/FastS/PyTree.py:235
   return FS_OK;
 }
 
@@ -652,7 +706,7 @@ extern "C" int fs_halo_pack(fs_ctx *ctx, int nstep, int peer_tag, double *dev_bu
   if (rc) return rc;
   if (n_doubles != fs_halo_count(ctx, peer_tag, 1)) return fail(ctx, FS_ERR_ARG, "fs_halo_pack: buffer size mismatch");
   int in, out;
-  if (nstep <= 0) out = level_role(-nstep); else stage_roles(nstep, in, out);
+  if (nstep <= 0) out = level_role(-nstep); else stage_roles(ctx, nstep, in, out);
   if (out < 0) return fail(ctx, FS_ERR_ARG, "fs_halo_pack: bad level");
   long long off = 0;
   for (auto &s : ctx->sends) {
@@ -672,7 +726,7 @@ extern "C" int fs_halo_unpack(fs_ctx *ctx, int nstep, int peer_tag, const double
   if (rc) return rc;
   if (n_doubles != fs_halo_count(ctx, peer_tag, 0)) return fail(ctx, FS_ERR_ARG, "fs_halo_unpack: buffer size mismatch");
   int in, out;
-  if (nstep <= 0) out = level_role(-nstep); else stage_roles(nstep, in, out);
+  if (nstep <= 0) out = level_role(-nstep); else stage_roles(ctx, nstep, in, out);
   if (out < 0) return fail(ctx, FS_ERR_ARG, "fs_halo_unpack: bad level");
   long long off = 0;
   for (auto &j : ctx->joins) {
@@ -701,14 +755,17 @@ extern "C" int fs_compute(fs_ctx *ctx, int nitrun, int nstep_deb, int nstep_fin,
     for (int nstep = nstep_deb; nstep <= nstep_fin; nstep++) {
       rc = fs_stage(ctx, nitrun_loc, nstep);
       if (rc) return rc;
-      local_joins_on(ctx, role_from_nstep, &nstep);
+      if (ctx->implicit && nstep == nssiter) continue;   // verification slot: no update, no ghost fill
+      NstepArg a = {ctx, nstep};
+      local_joins_on(ctx, role_from_nstep, &a);
       int in, out;
-      stage_roles(nstep, in, out);
+      stage_roles(ctx, nstep, in, out);
       bcs_on_role(ctx, out);
     }
-    // the result of the last sub-iteration sits in P1 only when their number is odd
-    // (Fast/FastS/FastS/PyTree.py:233: switchPointers__(zones, case, nitmax%2+2))
-    if (nstep_fin == nssiter && nssiter % 2 == 1) fs_rotate(ctx);
+    // explicit: the result of the last sub-iteration sits in P1 only when their number is odd
+    // (Fast/FastS/FastS/PyTree.py:233: switchPointers__(zones, case, nitmax%2+2)); implicit: always (:232)
+    if (nstep_fin == nssiter && (ctx->implicit || nssiter % 2 == 1)) fs_rotate(ctx);
+    else if (nstep_fin == nssiter) ctx->first_it = 1;
   }
   HIPCHK(ctx, hipGetLastError());
   return FS_OK;

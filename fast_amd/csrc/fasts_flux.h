@@ -32,6 +32,7 @@ struct FsZone {
   double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
   double tcx, tcy, tcz, si, sj, sk, volinv;
   double coe;              // dt/vol (constant on a Cartesian zone with a global time step)
+  double vol0;             // cell volume of a Cartesian zone
   double dt, cv, cvinv, cvinv2, coesut, cmus1;
   // curvilinear zones (ityp 0): device arrays ti,tj,tk(ndm,3) and vol(ndm), dimensioned on the nodes;
   // metric index of cell (i,j,k) = (i+ific-1) + (j+ific-1)*mincj + (k+ifick-1)*minck
@@ -442,4 +443,36 @@ FS_DEV void fs_rk_update_c(const FsZone &z, double coefW, double coe, const doub
 FS_DEV void fs_rk_update(const FsZone &z, double coefW, const double *q, const double *d, double *out)
 {
   fs_rk_update_c(z, coefW, z.coe, q, d, out);
+}
+
+// Newton residual of the implicit (BDF) scheme for one cell, Fast/FastS/FastS/Compute/core3as2.for:37-45,
+// 232-266,300-338:  r = coe*d + c1 W(q) + c2 W(qn) + c3 W(qn1), W = conservative variables; at the
+// first sub-iteration the iterate q is the level n itself and the two terms are merged (c4 = c1+c2).
+// q = current iterate, qn / qn1 = levels n and n-1, d = flux balance, coe = dt/vol.
+struct FsBdf {
+  const double *ro_n, *ro_n1;   // levels n and n-1 (device)
+  double c1, c2, c3;            // BDF1: -1, 1, 0   BDF2: -1.5, 2, -0.5
+  int nit1;                     // 1 at the first Newton sub-iteration
+};
+
+FS_DEV void fs_bdf_residual(const FsZone &z, const FsBdf &b, double coe, const double *q, const double *qn,
+                            const double *qn1, const double *d, double *r)
+{
+  const double cv = z.cv, c1 = b.c1, c2 = b.c2, c3 = b.c3;
+  const double roe = q[0] * (cv * q[4] + 0.5 * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+  const double roe_n1 = qn1[0] * (cv * qn1[4] + 0.5 * (qn1[1] * qn1[1] + qn1[2] * qn1[2] + qn1[3] * qn1[3]));
+  if (b.nit1) {
+    const double c4 = c1 + c2;
+    r[0] = coe * d[0] + c4 * q[0] + c3 * qn1[0];
+#pragma unroll
+    for (int e = 1; e <= 3; e++) r[e] = coe * d[e] + c4 * q[e] * q[0] + c3 * qn1[e] * qn1[0];
+    r[4] = coe * d[4] + c4 * roe + c3 * roe_n1;
+  } else {
+    const double roe_n = qn[0] * (cv * qn[4] + 0.5 * (qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]));
+    r[0] = coe * d[0] + c1 * q[0] + c2 * qn[0] + c3 * qn1[0];
+#pragma unroll
+    for (int e = 1; e <= 3; e++)
+      r[e] = coe * d[e] + c1 * q[e] * q[0] + c2 * qn[e] * qn[0] + c3 * qn1[e] * qn1[0];
+    r[4] = coe * d[4] + c1 * roe + c2 * roe_n + c3 * roe_n1;
+  }
 }

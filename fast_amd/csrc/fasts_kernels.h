@@ -17,7 +17,9 @@ struct FsBcWin {
   double tcn;        // face metric along the normal (ti, tj or tk of the Cartesian zone)
 };
 
-void fsk_invist(const FsZone &z, const double *rop, double *xmut, hipStream_t s);
+// depth = ghost layers covered besides the interior: 1 for the explicit scheme (navier_stokes_struct.for:223,
+// range ind_grad), the whole ghost depth for the implicit one (:219, range ind_coe)
+void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s);
 void fsk_wiggle(const FsZone &z, const double *rop, double *wig, hipStream_t s);
 int fsk_stage(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
               double *drodm, const double *xmut, const double *wig, hipStream_t s);
@@ -29,11 +31,14 @@ int fsk_stage_tiled(const FsZone &z, double coefH, double coefW, int first, cons
 // restricts a launch to a subset of the tiles, NULL launches all of them.
 struct FsTiling { int nti, ntj, ntk, kchunk, ti, tj; };
 FsTiling fsk_stage_dma_tiling(const FsZone &z);
+// bdf != NULL: the kernel writes the Newton residual of the implicit scheme to drodm instead of the
+// Runge-Kutta update (rop_out unused, coefH / coefW ignored)
 int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                  double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, hipStream_t s);
+                  double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, const FsBdf *bdf,
+                  hipStream_t s);
 // stage kernel of curvilinear zones (zone type 0, fasts_stage_full.hip); sensors stored as bytes
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                   double *drodm, const double *xmut, unsigned char *wig, hipStream_t s);
+                   double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, hipStream_t s);
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop,
                     hipStream_t s);
 void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);
@@ -41,4 +46,10 @@ void fsk_join_copy(int npts, int neq, long long nd_r, long long nd_d, const int 
                    double *rop_r, const double *rop_d, hipStream_t s);
 void fsk_halo_pack(int npts, int neq, long long nd, const int *pts, const double *rop, double *buf, hipStream_t s);
 void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *rop, const double *buf, hipStream_t s);
-void fsk_residual(const FsZone &z, const double *drodm, double *part, double *out, hipStream_t s);
+// use_coe = 1: norms of dt/vol * drodm (explicit balance); 0: norms of drodm (Newton residual, already scaled)
+void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s);
+// implicit scheme (fasts_lusgs.hip)
+void fsk_coe_implicit(const FsZone &z, int first_it, double gamma, double prandtl, double rgp, const double *rop,
+                      const double *xmut, double *coe, hipStream_t s);
+int fsk_lusgs(const FsZone &z, double gamma, const double *rop, double *rop_out, double *scratch, double *dw,
+              const double *coe, hipStream_t s);

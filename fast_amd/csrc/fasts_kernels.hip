@@ -45,12 +45,13 @@ FS_DEV void face_flux_g(const FsZone &z, const double *__restrict__ rop, const d
 // (navier_stokes_struct.for:213-225 with ind_grad), sensor on all faces 1..N+1
 // (src_term.for:258-272, SENSOR/wiggle2001.for)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_invist(FsZone z, const double *__restrict__ rop, double *__restrict__ xmut)
+__global__ void __launch_bounds__(256) k_invist(FsZone z, int depth, const double *__restrict__ rop,
+                                                double *__restrict__ xmut)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. iv+1
-  const int j = blockIdx.y;                             // 0 .. jv+1
-  const int k = blockIdx.z;                             // 0 .. kv+1
-  if (i > z.iv + 1) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x + 1 - depth;  // 1-depth .. iv+depth
+  const int j = blockIdx.y + 1 - depth;
+  const int k = blockIdx.z + 1 - depth;
+  if (i > z.iv + depth) return;
   long long l = fs_inddm(z, i, j, k);
   xmut[l] = fs_sutherland(z, rop[4 * z.nd + l]);
 }
@@ -382,7 +383,7 @@ __global__ void __launch_bounds__(256) k_halo_unpack(int npts, int neq, long lon
 // residual norms: per-block partial sums in a fixed order, then one block folds the partials
 // in index order, so the result does not depend on scheduling.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_residual_partial(FsZone z, const double *__restrict__ drodm,
+__global__ void __launch_bounds__(256) k_residual_partial(FsZone z, int use_coe, const double *__restrict__ drodm,
                                                           double *__restrict__ part)
 {
   __shared__ double ssum[5][256];
@@ -392,11 +393,12 @@ __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, const double
   for (int i = threadIdx.x + 1; i <= z.iv; i += blockDim.x) {
     long long l = fs_inddm(z, i, j, k);
     double coe = z.coe;
-    if (z.ityp == 0)   // dt/vol of the cell (tstb3_global.for:64-78)
+    if (!use_coe) coe = 1.;
+    else if (z.ityp == 0)   // dt/vol of the cell (tstb3_global.for:64-78)
       coe = z.dt / z.vol[(long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj +
                          (long long)(k + z.ifick - 1) * z.minck];
     for (int e = 0; e < 5; e++) {
-      double r = coe * drodm[e * z.nd + l];
+      double r = use_coe ? coe * drodm[e * z.nd + l] : drodm[e * z.nd + l];
       s[e] = s[e] + r * r;
       m[e] = fs_max(m[e], fabs(r));
     }
@@ -444,10 +446,10 @@ __global__ void __launch_bounds__(256) k_residual_final(long long nblk, const do
 // ------------------------------------------------------------------------------------------
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
-void fsk_invist(const FsZone &z, const double *rop, double *xmut, hipStream_t s)
+void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s)
 {
-  dim3 g(cdiv(z.iv + 2, 256), z.jv + 2, z.kv + 2);
-  hipLaunchKernelGGL(k_invist, g, dim3(256), 0, s, z, rop, xmut);
+  dim3 g(cdiv(z.iv + 2 * depth, 256), z.jv + 2 * depth, z.kv + 2 * depth);
+  hipLaunchKernelGGL(k_invist, g, dim3(256), 0, s, z, depth, rop, xmut);
 }
 
 void fsk_wiggle(const FsZone &z, const double *rop, double *wig, hipStream_t s)
@@ -520,8 +522,8 @@ void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *ro
   hipLaunchKernelGGL(k_halo_unpack, dim3(gx), dim3(256), 0, s, npts, neq, nd, pts, rop, buf);
 }
 
-void fsk_residual(const FsZone &z, const double *drodm, double *part, double *out, hipStream_t s)
+void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_residual_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, drodm, part);
+  hipLaunchKernelGGL(k_residual_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, use_coe, drodm, part);
   hipLaunchKernelGGL(k_residual_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv, part, out);
 }

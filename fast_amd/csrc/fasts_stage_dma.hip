@@ -106,11 +106,14 @@ FS_DEV double face_ij(const FsZone &z, const Smem &sm, int k, int c, double wg_i
   return wg;
 }
 
-template <int KFLU, int IFLOW, bool FIRST, bool WIDE>
+// BDF = false: Runge-Kutta stage (drodm = balance, rop_out = updated state).
+// BDF = true: Newton residual of the implicit scheme (drodm = dt/vol * balance + BDF terms, rop_out unused).
+template <int KFLU, int IFLOW, bool FIRST, bool WIDE, bool BDF>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int ntile_j, int nblk,
             const double *__restrict__ rop, double *__restrict__ rop_out, double *__restrict__ drodm,
-            const double *__restrict__ xmut, unsigned char *__restrict__ wig, const int *__restrict__ blist)
+            const double *__restrict__ xmut, unsigned char *__restrict__ wig, const int *__restrict__ blist,
+            FsBdf bdf)
 {
   __shared__ Smem sm;
   // blocks that share an XCD (same blockIdx % 8) get consecutive tiles, so halo rows of
@@ -261,7 +264,7 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
 #ifndef FS_EXP_NOREG
       r_nn = ldg(P(rop, 0, k + 2), ob); t_nn = ldg(P(rop, 4, k + 2), ob);
 #endif
-      if (!FIRST) {
+      if (!FIRST && !BDF) {
 #pragma unroll
         for (int e = 0; e < 5; e++) dr_nn[e] = ldg(P(drodm, e, k + 1), ob);
       }
@@ -308,14 +311,26 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
     if (k > k0 && cell_ok) {
       double d[5];
 #pragma unroll
-      for (int e = 0; e < 5; e++) {
-        d[e] = part[e] - fk[e];
-        stg(PW_(drodm, e, k - 1), ob, d[e]);
-      }
-      double o[5];
-      fs_rk_update(z, coefW, qb, d, o);
+      for (int e = 0; e < 5; e++) d[e] = part[e] - fk[e];
+      if (BDF) {
+        double qn[5] = {0., 0., 0., 0., 0.}, qn1[5], r[5];
 #pragma unroll
-      for (int e = 0; e < 5; e++) stg(PW_(rop_out, e, k - 1), ob, o[e]);
+        for (int e = 0; e < 5; e++) qn1[e] = ldg(P(bdf.ro_n1, e, k - 1), ob);
+        if (!bdf.nit1) {
+#pragma unroll
+          for (int e = 0; e < 5; e++) qn[e] = ldg(P(bdf.ro_n, e, k - 1), ob);
+        }
+        fs_bdf_residual(z, bdf, z.coe, qb, qn, qn1, d, r);
+#pragma unroll
+        for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, r[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, d[e]);
+        double o[5];
+        fs_rk_update(z, coefW, qb, d, o);
+#pragma unroll
+        for (int e = 0; e < 5; e++) stg(PW_(rop_out, e, k - 1), ob, o[e]);
+      }
     }
     STAMP(3)
     // ---- i- and j-faces of plane k ------------------------------------------------------------------
@@ -360,7 +375,7 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
         const double v = __shfl_down(fim[e], 1, 64);
         const double fip = ti == TI - 1 ? sm.fi_extra[e][tj] : v;
         const double fjp = sm.fj[e][tj + 1][ti];
-        double a = FIRST ? 0. : dr_n[e] * coefH;
+        double a = (FIRST || BDF) ? 0. : dr_n[e] * coefH;
         a = a + fk[e]; a = a + fjm[e]; a = a + fim[e];
         a = a - fip; a = a - fjp;
         part[e] = a;
@@ -380,7 +395,8 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
 
 template <int KFLU, int IFLOW>
 void launch(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-            double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, hipStream_t s)
+            double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, const FsBdf *bdf,
+            hipStream_t s)
 {
   const FsTiling t = fsk_stage_dma_tiling(z);
   const int nblk = blist ? nlist : t.nti * t.ntj * t.ntk;
@@ -388,11 +404,18 @@ void launch(const FsZone &z, double coefH, double coefW, int first, const double
   // 16-byte DMA needs pairs of cells that are 16-byte aligned in every row and plane
   const bool wide = z.ni % 2 == 0 && z.nd % 2 == 0 && z.ific % 2 == 0 && ((uintptr_t)rop % 16 == 0) &&
                     (xmut == nullptr || (uintptr_t)xmut % 16 == 0);
-#define FS_LAUNCH(FIRST_, WIDE_)                                                                       \
-  hipLaunchKernelGGL((k_stage_dma<KFLU, IFLOW, FIRST_, WIDE_>), dim3(nblk), dim3(NTHREADS), 0, s, z, coefH, coefW, \
-                     t.kchunk, t.nti, t.ntj, nblk, rop, rop_out, drodm, xmut, wig, blist)
-  if (first) { if (wide) FS_LAUNCH(true, true); else FS_LAUNCH(true, false); }
-  else       { if (wide) FS_LAUNCH(false, true); else FS_LAUNCH(false, false); }
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0};
+  if (bdf) b = *bdf;
+#define FS_LAUNCH(FIRST_, WIDE_, BDF_)                                                                       \
+  hipLaunchKernelGGL((k_stage_dma<KFLU, IFLOW, FIRST_, WIDE_, BDF_>), dim3(nblk), dim3(NTHREADS), 0, s, z, coefH, coefW, \
+                     t.kchunk, t.nti, t.ntj, nblk, rop, rop_out, drodm, xmut, wig, blist, b)
+  if (bdf) {
+    if (first) { if (wide) FS_LAUNCH(true, true, true); else FS_LAUNCH(true, false, true); }
+    else       { if (wide) FS_LAUNCH(false, true, true); else FS_LAUNCH(false, false, true); }
+  } else {
+    if (first) { if (wide) FS_LAUNCH(true, true, false); else FS_LAUNCH(true, false, false); }
+    else       { if (wide) FS_LAUNCH(false, true, false); else FS_LAUNCH(false, false, false); }
+  }
 #undef FS_LAUNCH
 }
 
@@ -420,13 +443,14 @@ FsTiling fsk_stage_dma_tiling(const FsZone &z)
 }
 
 int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                  double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, hipStream_t s)
+                  double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, const FsBdf *bdf,
+                  hipStream_t s)
 {
   // one k-plane must stay below 4 GiB / 8 so that in-plane byte offsets fit 32 bits
   if ((long long)z.ni * z.nj >= (1ll << 28)) return -2;
 #define FS_CASE(K, F)                                                                       \
   if (z.kflu == K && z.iflow == F) {                                                        \
-    launch<K, F>(z, coefH, coefW, first, rop, rop_out, drodm, xmut, wig, blist, nlist, s);  \
+    launch<K, F>(z, coefH, coefW, first, rop, rop_out, drodm, xmut, wig, blist, nlist, bdf, s);  \
     return 0;                                                                               \
   }
   FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)

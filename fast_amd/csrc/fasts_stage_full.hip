@@ -64,11 +64,12 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
   }
 }
 
-template <int KFLU, int IFLOW, bool FIRST>
+// BDF = false: Runge-Kutta stage.  BDF = true: Newton residual of the implicit scheme (rop_out unused).
+template <int KFLU, int IFLOW, bool FIRST, bool BDF>
 __global__ void __launch_bounds__(256)
 k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
-             unsigned char *__restrict__ wig)
+             unsigned char *__restrict__ wig, FsBdf bdf)
 {
   __shared__ double sfj[2][5][TJ][TI];
   const int ti = threadIdx.x & 31, tj = threadIdx.x >> 5;
@@ -105,10 +106,26 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
         const long long lb = l - z.inck;
         double d[5], o[5];
 #pragma unroll
-        for (int e = 0; e < 5; e++) { d[e] = part[e] - fk[e]; drodm[e * nd + lb] = d[e]; }
-        fs_rk_update_c(z, coefW, z.dt / z.vol[lt - z.minck], qb, d, o);
+        for (int e = 0; e < 5; e++) d[e] = part[e] - fk[e];
+        const double coe = z.dt / z.vol[lt - z.minck];
+        if (BDF) {
+          double qn[5] = {0., 0., 0., 0., 0.}, qn1[5];
 #pragma unroll
-        for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
+          for (int e = 0; e < 5; e++) qn1[e] = bdf.ro_n1[e * nd + lb];
+          if (!bdf.nit1) {
+#pragma unroll
+            for (int e = 0; e < 5; e++) qn[e] = bdf.ro_n[e * nd + lb];
+          }
+          fs_bdf_residual(z, bdf, coe, qb, qn, qn1, d, o);
+#pragma unroll
+          for (int e = 0; e < 5; e++) drodm[e * nd + lb] = o[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 5; e++) drodm[e * nd + lb] = d[e];
+          fs_rk_update_c(z, coefW, coe, qb, d, o);
+#pragma unroll
+          for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
+        }
       }
     }
     if (!last) {
@@ -139,7 +156,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
       if (own) {
 #pragma unroll
         for (int e = 0; e < 5; e++) {
-          const double dr = FIRST ? 0. : drodm[e * nd + l] * coefH;
+          const double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
           part[e] = dr + fk[e] + fjm[e] + fim[e] - fip[e] - sfj[buf][e][tj + 1][ti];
         }
       }
@@ -153,7 +170,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
 }  // namespace
 
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                   double *drodm, const double *xmut, unsigned char *wig, hipStream_t s)
+                   double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, hipStream_t s)
 {
   if (z.ityp != 0 || !z.vol || !z.mt[0] || !z.mt[1] || !z.mt[2]) return -1;
   int kchunk = 32;
@@ -163,17 +180,19 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
   }
   if (kchunk > z.kv) kchunk = z.kv;
   dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0};
+  if (bdf) b = *bdf;
+#define FS_GO(K, F, FIRST_, BDF_)                                                                             \
+  hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, \
+                     drodm, xmut, wig, b)
 #define FS_CASE(K, F)                                                                                         \
   if (z.kflu == K && z.iflow == F) {                                                                          \
-    if (first)                                                                                                \
-      hipLaunchKernelGGL((k_stage_full<K, F, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, \
-                         drodm, xmut, wig);                                                                   \
-    else                                                                                                      \
-      hipLaunchKernelGGL((k_stage_full<K, F, false>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, \
-                         drodm, xmut, wig);                                                                   \
+    if (bdf) { if (first) FS_GO(K, F, true, true); else FS_GO(K, F, false, true); }                           \
+    else { if (first) FS_GO(K, F, true, false); else FS_GO(K, F, false, false); }                             \
     return 0;                                                                                                 \
   }
   FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)
 #undef FS_CASE
+#undef FS_GO
   return -1;
 }

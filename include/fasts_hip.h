@@ -66,6 +66,13 @@ int fs_set_stream(fs_ctx *ctx, void *hip_stream);
  * .Solver#dtloc[1], Fast/FastC/FastC/PyTree.py:1186).  Default 200. */
 int fs_set_verif(fs_ctx *ctx, int modulo_verif);
 
+/* FIRST_IT of the reference (FastC.HOOK["FIRST_IT"], Fast/FastS/FastS/PyTree.py:235,
+ * Fast/FastC/FastC/PyTree.py:2195-2222): 0 = no time step completed yet, the implicit scheme then uses
+ * BDF1 and a unit diagonal shift (Fast/FastS/FastS/Compute/core3as2.for:37-45, tstb3c.for:67-68); 1 = BDF2.
+ * A context starts at 0 and switches to 1 at the end of its first time step; a restart from a stored
+ * M1 level sets 1 here. */
+int fs_set_first_it(fs_ctx *ctx, int first_it);
+
 /* Register one zone.  Returns the zone index (>= 0) or an error code.
  * Replaces the per-zone pointer gathering of K_FASTS::_computePT
  * (Fast/FastS/FastS/Compute/computePT.cpp:225-369) and the metric list produced by

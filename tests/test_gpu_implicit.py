@@ -1,0 +1,89 @@
+"""GPU parity of the implicit time step (BDF Newton residual + LU-SGS + Newton update) against the CPU
+restatement, itself bit-exact against navier_stokes_struct_ / invlu_ of the compiled reference
+(test_oracle_vs_ref.py).  The device sweeps hyperplanes where the reference sweeps lexicographically;
+per cell the operations and their order are the same, so fields must agree bit for bit."""
+import numpy as np
+import pytest
+
+from fast_amd import cases, connect, FastC, Internal
+import fast_amd.pytree_lite as C
+import fast_amd.PyTree as FastS
+from oracle import oracle as O
+from common import zone_arrays, rel_err, SINGLE, prepare
+
+pytestmark = pytest.mark.gpu
+
+FAR = {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')}
+
+CASES = [
+    # n, scheme, model, perturb, bcs, ss_iteration, steps, layer
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', 0., None, 4, 4, 'c'),
+    ((12, 10, 9), 'senseur', 'NSLaminar', 0., None, 3, 4, 'Python'),
+    ((10, 9, 12), 'roe', 'Euler', 0., None, 3, 3, 'c'),
+    ((9, 12, 10), 'senseur', 'Euler', 0., None, 2, 3, 'c'),
+    ((40, 11, 35), 'ausmpred', 'NSLaminar', 0., None, 2, 2, 'c'),       # several tiles and k chunks
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', 0.15, None, 4, 4, 'c'),      # curvilinear
+    ((10, 9, 8), 'senseur', 'NSLaminar', 0.15, None, 3, 3, 'Python'),
+    ((10, 8, 9), 'roe', 'NSLaminar', 0.15, None, 2, 3, 'c'),
+    ((34, 9, 36), 'senseur', 'Euler', 0.15, None, 2, 2, 'c'),
+    ((9, 8, 10), 'ausmpred', 'NSLaminar', 0., FAR, 3, 4, 'c'),
+    ((9, 8, 10), 'senseur', 'NSLaminar', 0.15, {'imin': 'BCExtrapolate', 'imax': 'BCFarfield'}, 3, 3, 'c'),
+]
+
+
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs,ssit,nit,layer", CASES)
+def test_implicit_bit_exact_vs_oracle(n, scheme, model, perturb, bcs, ssit, nit, layer):
+    t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': ssit}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb, modulo_verif=1)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[29]) == 1 and int(pint[58]) == ssit + 1
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)
+    ro0 = oz.ro.copy()
+    for it in range(1, nit + 1):
+        FastS._compute(t, metrics, it, None, layer=layer)
+        oz.step()
+        got = FastC.level_buffer(z)
+        assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+        if it == 1:   # Newton residual of the first sub-iteration
+            l2, loo = FastS.display_temporal_criteria(t, metrics, it, format='none')[z[0]]
+            rl2, rloo = oz.residuals()
+            np.testing.assert_allclose(l2, rl2, rtol=1e-11)
+            np.testing.assert_allclose(loo, rloo, rtol=1e-13)
+    FastS.sync_to_host(t)
+    assert np.array_equal(FastC.level_buffer(z, '_M1'), oz.ro_m1)
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4
+
+
+@pytest.mark.parametrize("blocks,nn,scheme,perturb", [
+    ((2, 1, 2), (16, 9, 12), 'senseur', 0.),
+    ((1, 2, 1), (10, 16, 8), 'ausmpred', 0.15),
+])
+def test_implicit_blocks_with_joins(blocks, nn, scheme, perturb):
+    """Several zones: each runs its own LU-SGS sweep (block Jacobi across the joins, lu_match = 0), the
+    Newton iterates are exchanged through the joins after every sub-iteration."""
+    nv = tuple(nn[d] // blocks[d] for d in range(3))
+    joins = connect.periodic_block_joins(blocks, nv)
+    kw = dict(blocks=blocks, extra_numz=SINGLE, extra_numb={'ss_iteration': 3}, temporal_scheme='implicit',
+              time_step=0.02, perturb=perturb)
+    to = cases.tgv(nn, scheme, **kw)
+    m = prepare(to)
+    zs = []
+    for z, mm in zip(Internal.getZones(to), m):
+        p, pr, _ = zone_arrays(z)
+        zs.append(O.OracleZone(p, pr, FastC.level_buffer(z), mm[0]))
+    s = O.OracleSolver(zs, [(br, r, bd, d) for br, bd, r, d in joins])
+    s.fill_ghostcells()
+    t = cases.tgv(nn, scheme, **kw)
+    tc = C.node2Center(t)
+    connect.add_joins_to_tc(tc, joins, [z[0] for z in Internal.getZones(t)])
+    (t, tc, metrics) = FastS.warmup(t, tc)
+    zones = Internal.getZones(t)
+    for it in range(1, 4):
+        FastS._compute(t, metrics, it, tc)
+        s.step()
+        for z, oz in zip(zones, s.zones):
+            assert np.array_equal(FastC.level_buffer(z), oz.ro), "step %d zone %s" % (it, z[0])
