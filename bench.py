@@ -81,6 +81,8 @@ def main():
     ap.add_argument('--cells', dest='n', type=int, default=256, help='cells per direction per GPU block')
     ap.add_argument('--scheme', default='senseur', choices=['senseur', 'ausmpred', 'roe'])
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--implicit', type=int, default=0, metavar='SS_ITERATION', help='implicit BDF/LU-SGS steps with '
+                    'this many Newton sub-iterations; not the headline workload')
     ap.add_argument('--perturb', type=float, default=0., help='node displacement in mesh steps: > 0 makes the block '
                     'curvilinear (per-cell metrics); not the headline workload')
     a = ap.parse_args()
@@ -111,13 +113,18 @@ def main():
             dist.init_process_group(backend)
     model = 'Euler' if a.scheme == 'roe' else 'NSLaminar'
 
-    if a.perturb and world > 1:
-        raise SystemExit("bench.py: --perturb is a single-GPU option")
+    if (a.perturb or a.implicit) and world > 1:
+        raise SystemExit("bench.py: --perturb / --implicit are single-GPU options")
     if world == 1:
-        t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n, perturb=a.perturb)
+        kw = {}
+        if a.implicit:
+            kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': a.implicit}}
+        t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n * (10. if a.implicit else 1.),
+                      perturb=a.perturb, **kw)
         (t, tc, metrics) = FastS.warmup(t, None, device=local_rank)
         ctx = FastC.HOOK['ctx']
-        run_step = lambda it: ctx.compute(it, 1, 3, 1)
+        nss = a.implicit + 1 if a.implicit else 3
+        run_step = lambda it: ctx.compute(it, 1, nss, 1)
         ncell_total = a.n ** 3
     else:
         import fast_amd.Mpi as FastSmpi
@@ -180,7 +187,8 @@ def main():
                                    % (a.n, a.scheme) if model != 'Euler' else
                                    "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
                        "blocks": list(split_for(world) or (1, 1, 1)), "ghost_layers": 2,
-                       "mesh": "curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"},
+                       "mesh": "curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian",
+                       "time_scheme": "implicit BDF2 LU-SGS, %d Newton sub-iterations" % a.implicit if a.implicit else "explicit RK3"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n},

@@ -13,6 +13,9 @@
 #include "fasts_kernels.h"
 #include "fasts_flux.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace {
 
 struct LuRange { int i0, i1, j0, j1, k0, k1; };
@@ -74,23 +77,19 @@ __global__ void __launch_bounds__(256) k_coe_implicit(FsZone z, double xid, doub
 
 struct LuConst { double gam1, gamm1, gam2, cp, cvinv, cvinv2, cv; };
 
-// b = [A(q_m) + signe*rho_d(m) I] dW(m), m = l - SGN*inc(D): SGN = +1 lower sweep, -1 upper sweep.
-// rs = state array the neighbour is read from.
+// b = [A(q_m) + signe*rho_d(m) I] dW(m) for the neighbour m = l - SGN*inc(D) of cell l (SGN = +1 lower
+// sweep, -1 upper sweep), from the neighbour's state (u,v,w,t), its increment d1..d5 and its spectral
+// radius crad = coe(m, 2+D); lt = metric index of cell l.
 template <bool FULL, int D, int SGN>
-FS_DEV void lu_neighbour(const FsZone &z, const LuConst &c, long long l, long long lt, const double *__restrict__ rs,
-                         const double *__restrict__ dw, const double *__restrict__ coe, double *b)
+FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, double v, double w, double t,
+                    double d1, double d2, double d3, double d4, double d5, double crad, double *b)
 {
-  const long long nd = z.nd;
-  const long long inc = D == 0 ? 1 : (D == 1 ? z.incj : z.inck);
-  const long long l1 = l - SGN * inc;
   const double signe = SGN > 0 ? 0.5 : -0.5;
   const double gamm1 = c.gamm1, gam2 = c.gam2, gam1 = c.gam1, cp = c.cp;
-  const double u = rs[l1 + nd], v = rs[l1 + 2 * nd], w = rs[l1 + 3 * nd], t = rs[l1 + 4 * nd];
   const double q2 = .5 * (u * u + v * v + w * w);
   const double h = cp * t + q2;
   const double ph2 = gamm1 * q2;
-  const double cr = coe[l1 + (1 + D) * nd] * signe;
-  const double d1 = dw[l1], d2 = dw[l1 + nd], d3 = dw[l1 + 2 * nd], d4 = dw[l1 + 3 * nd], d5 = dw[l1 + 4 * nd];
+  const double cr = crad * signe;
   if (FULL) {
     const double *__restrict__ tt = z.mt[D];
     const long long ndm = z.ndm, minc = D == 0 ? 1 : (D == 1 ? z.mincj : z.minck);
@@ -157,6 +156,18 @@ FS_DEV void lu_neighbour(const FsZone &z, const LuConst &c, long long l, long lo
     b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
   }
+}
+
+// rs = state array the neighbour is read from, dw = increments, coe = coefficient array
+template <bool FULL, int D, int SGN>
+FS_DEV void lu_neighbour(const FsZone &z, const LuConst &c, long long l, long long lt, const double *__restrict__ rs,
+                         const double *__restrict__ dw, const double *__restrict__ coe, double *b)
+{
+  const long long nd = z.nd;
+  const long long inc = D == 0 ? 1 : (D == 1 ? z.incj : z.inck);
+  const long long l1 = l - SGN * inc;
+  lu_term<FULL, D, SGN>(z, c, lt, rs[l1 + nd], rs[l1 + 2 * nd], rs[l1 + 3 * nd], rs[l1 + 4 * nd], dw[l1], dw[l1 + nd],
+                        dw[l1 + 2 * nd], dw[l1 + 3 * nd], dw[l1 + 4 * nd], coe[l1 + (1 + D) * nd], b);
 }
 
 // cell of hyperplane h handled by this thread: threads run over j (x) and k (y, offset kbase)
@@ -233,6 +244,300 @@ __global__ void __launch_bounds__(64) k_lu_upper(FsZone z, LuConst c, LuRange r,
   rop_new[l + 4 * nd] = (roe_old + a[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Chunked sweeps: a thread owns CH consecutive cells of one i-line (one or two cache lines per array,
+// read in full) and runs the i recurrence over them serially, as the reference does over the whole
+// line.  The unit (c, j, k), c = chunk number along i, depends on (c-1, j, k), (c, j-1, k), (c, j, k-1):
+// units of a hyperplane c + j + k = const are independent.  Far fewer, shorter launches than one
+// hyperplane of single cells per launch, and no partially used cache lines.
+// ------------------------------------------------------------------------------------------------------
+FS_DEV bool plane_unit(const LuRange &r, int nchunk, int h, int kbase, int &c, int &j, int &k)
+{
+  j = r.j0 + blockIdx.x * blockDim.x + threadIdx.x;
+  k = kbase + blockIdx.y;
+  c = h - (j - r.j0) - (k - r.k0);
+  return j <= r.j1 && k <= r.k1 && c >= 0 && c < nchunk;
+}
+
+// Three phases per unit so that no memory access sits in the serial chain: (A) every load of the unit and
+// the j/k neighbour terms, all independent; (B) the i recurrence over the CH cells, registers only;
+// (C) the stores.
+template <bool FULL, int CH>
+__global__ void __launch_bounds__(64) k_lu_lower_chunk(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+                                                       const double *__restrict__ rop, double *__restrict__ dw,
+                                                       const double *__restrict__ coe)
+{
+  int cn, j, k;
+  if (!plane_unit(r, nchunk, h, kbase, cn, j, k)) return;
+  const long long nd = z.nd;
+  const int ia = r.i0 + cn * CH;
+  const int n = (ia + CH - 1 < r.i1 ? CH : r.i1 - ia + 1);   // cells of this unit
+  const long long l0 = lcell(z, ia, j, k), lt0 = FULL ? lmtr(z, ia, j, k) : 0;
+  const bool has_j = j > r.j0, has_k = k > r.k0, has_i0 = ia > r.i0;
+  double A[CH][5], S[CH][4], CR[CH], XAL[CH], DG[CH];
+  double p[5] = {0., 0., 0., 0., 0.};   // increment of the cell before the unit, final
+  if (has_i0) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) p[e] = dw[l0 - 1 + e * nd];
+  }
+#pragma unroll
+  for (int m = 0; m < CH; m++) {
+    if (m < n) {
+      const long long l = l0 + m, lt = lt0 + (FULL ? m : 0);
+      const double xal = coe[l] * 0.5;
+      double b[5];
+#pragma unroll
+      for (int e = 0; e < 5; e++) A[m][e] = dw[l + e * nd];
+      if (FULL) {
+        if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
+        if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
+      } else {
+        if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
+        if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
+      }
+      XAL[m] = xal;
+      DG[m] = 1. / coe[l + 4 * nd];
+      if (m > 0 || has_i0) {
+        S[m][0] = rop[l - 1 + nd]; S[m][1] = rop[l - 1 + 2 * nd]; S[m][2] = rop[l - 1 + 3 * nd]; S[m][3] = rop[l - 1 + 4 * nd];
+        CR[m] = coe[l - 1 + nd];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < CH; m++) {
+    if (m < n) {
+      if (m > 0 || has_i0) {
+        double b[5];
+        lu_term<FULL, 0, 1>(z, c, lt0 + (FULL ? m : 0), S[m][0], S[m][1], S[m][2], S[m][3], p[0], p[1], p[2], p[3], p[4], CR[m], b);
+#pragma unroll
+        for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * XAL[m];
+      }
+#pragma unroll
+      for (int e = 0; e < 5; e++) { p[e] = A[m][e] * DG[m]; A[m][e] = p[e]; }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < CH; m++) {
+    if (m < n) {
+#pragma unroll
+      for (int e = 0; e < 5; e++) dw[l0 + m + e * nd] = A[m][e];
+    }
+  }
+}
+
+template <bool FULL, int CH>
+__global__ void __launch_bounds__(64) k_lu_upper_chunk(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+                                                       const double *__restrict__ rop, const double *rop_kn,
+                                                       double *rop_new, double *__restrict__ dw,
+                                                       const double *__restrict__ coe)
+{
+  int cn, j, k;
+  if (!plane_unit(r, nchunk, h, kbase, cn, j, k)) return;
+  const long long nd = z.nd;
+  const int ia = r.i0 + cn * CH;
+  const int n = (ia + CH - 1 < r.i1 ? CH : r.i1 - ia + 1);
+  const long long l0 = lcell(z, ia, j, k), lt0 = FULL ? lmtr(z, ia, j, k) : 0;
+  const bool has_j = j < r.j1, has_k = k < r.k1, has_in = ia + n - 1 < r.i1;   // a cell after the unit exists
+  double A[CH][5], S[CH][4], CR[CH], XAL[CH], DG[CH];
+  double p[5] = {0., 0., 0., 0., 0.};   // increment of the cell after the unit, final
+  if (has_in) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) p[e] = dw[l0 + n + e * nd];
+  }
+#pragma unroll
+  for (int m = 0; m < CH; m++) {
+    if (m < n) {
+      const long long l = l0 + m, lt = lt0 + (FULL ? m : 0);
+      const double xal = coe[l] * -0.5;
+      const double c5 = coe[l + 4 * nd];
+      double b[5];
+#pragma unroll
+      for (int e = 0; e < 5; e++) A[m][e] = dw[l + e * nd] * c5;
+      if (has_k) { lu_neighbour<FULL, 2, -1>(z, c, l, lt, rop_kn, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
+      if (has_j) { lu_neighbour<FULL, 1, -1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
+      XAL[m] = xal;
+      DG[m] = 1. / c5;
+      if (m < n - 1 || has_in) {
+        S[m][0] = rop[l + 1 + nd]; S[m][1] = rop[l + 1 + 2 * nd]; S[m][2] = rop[l + 1 + 3 * nd]; S[m][3] = rop[l + 1 + 4 * nd];
+        CR[m] = coe[l + 1 + nd];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = CH - 1; m >= 0; m--) {
+    if (m < n) {
+      if (m < n - 1 || has_in) {
+        double b[5];
+        lu_term<FULL, 0, -1>(z, c, lt0 + (FULL ? m : 0), S[m][0], S[m][1], S[m][2], S[m][3], p[0], p[1], p[2], p[3], p[4], CR[m], b);
+#pragma unroll
+        for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * XAL[m];
+      }
+#pragma unroll
+      for (int e = 0; e < 5; e++) { p[e] = A[m][e] * DG[m]; A[m][e] = p[e]; }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < CH; m++) {
+    if (m < n) {
+      const long long l = l0 + m;
+#pragma unroll
+      for (int e = 0; e < 5; e++) dw[l + e * nd] = A[m][e];
+      // Newton update (mjr_newton.for)
+      const double ro_old = rop[l], u_old = rop[l + nd], v_old = rop[l + 2 * nd], w_old = rop[l + 3 * nd];
+      const double t_old = rop[l + 4 * nd];
+      const double rn = ro_old + A[m][0];
+      const double r_1 = 1. / rn;
+      const double un = (ro_old * u_old + A[m][1]) * r_1;
+      const double vn = (ro_old * v_old + A[m][2]) * r_1;
+      const double wn = (ro_old * w_old + A[m][3]) * r_1;
+      const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+      rop_new[l] = rn; rop_new[l + nd] = un; rop_new[l + 2 * nd] = vn; rop_new[l + 3 * nd] = wn;
+      rop_new[l + 4 * nd] = (roe_old + A[m][4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Wave-cooperative form of the chunked sweeps: a wave handles 8 units of 8 cells, lane = (unit, cell).
+// The loads and the j/k neighbour terms are done one cell per lane (8 lanes read 64 contiguous bytes of
+// every array); the i recurrence then runs in 8 steps, the increment of cell m-1 reaching cell m through
+// a shuffle inside each group of 8 lanes.
+// ------------------------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+                                                      const double *__restrict__ rop, double *__restrict__ dw,
+                                                      const double *__restrict__ coe)
+{
+  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
+  const int j = r.j0 + blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int cn = h - (j - r.j0) - (k - r.k0);
+  const int i = r.i0 + cn * 8 + m;
+  const bool active = j <= r.j1 && k <= r.k1 && cn >= 0 && cn < nchunk && i <= r.i1;
+  const long long nd = z.nd;
+  const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
+  const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
+  const bool has_prev = active && i > r.i0;
+  double A[5] = {0., 0., 0., 0., 0.}, P[5] = {0., 0., 0., 0., 0.}, S[4] = {0., 0., 0., 0.};
+  double CR = 0., XAL = 0., DG = 0.;
+  if (active) {
+    XAL = coe[l] * 0.5;
+    double b[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) A[e] = dw[l + e * nd];
+    const bool has_j = j > r.j0, has_k = k > r.k0;
+    if (FULL) {
+      if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+      if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+    } else {
+      if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+      if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+    }
+    DG = 1. / coe[l + 4 * nd];
+    if (has_prev) {
+      S[0] = rop[l - 1 + nd]; S[1] = rop[l - 1 + 2 * nd]; S[2] = rop[l - 1 + 3 * nd]; S[3] = rop[l - 1 + 4 * nd];
+      CR = coe[l - 1 + nd];
+      if (m == 0) {   // the cell before the unit belongs to an earlier hyperplane: final
+#pragma unroll
+        for (int e = 0; e < 5; e++) P[e] = dw[l - 1 + e * nd];
+      }
+    }
+  }
+  // P of lane m holds: before its step, the increment of cell m-1 (lane 0: preloaded); after, its own
+  for (int st = 0; st < 8; st++) {
+    double pin[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+      const double up = __shfl_up(P[e], 1, 8);
+      pin[e] = m == 0 ? P[e] : up;
+    }
+    if (m == st && active) {
+      if (has_prev) {
+        double b[5];
+        lu_term<FULL, 0, 1>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+#pragma unroll
+        for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL;
+      }
+#pragma unroll
+      for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) dw[l + e * nd] = P[e];
+  }
+}
+
+template <bool FULL>
+__global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+                                                      const double *__restrict__ rop, const double *rop_kn,
+                                                      double *rop_new, double *__restrict__ dw,
+                                                      const double *__restrict__ coe)
+{
+  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
+  const int j = r.j0 + blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int cn = h - (j - r.j0) - (k - r.k0);
+  const int i = r.i0 + cn * 8 + m;
+  const bool active = j <= r.j1 && k <= r.k1 && cn >= 0 && cn < nchunk && i <= r.i1;
+  const long long nd = z.nd;
+  const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
+  const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
+  const bool has_next = active && i < r.i1;
+  const bool last_of_unit = m == 7 || i == r.i1;     // its i+1 neighbour lies outside the unit
+  double A[5] = {0., 0., 0., 0., 0.}, P[5] = {0., 0., 0., 0., 0.}, S[4] = {0., 0., 0., 0.};
+  double CR = 0., XAL = 0., DG = 0.;
+  double q[5] = {1., 0., 0., 0., 1.};
+  if (active) {
+    XAL = coe[l] * -0.5;
+    const double c5 = coe[l + 4 * nd];
+    double b[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) { A[e] = dw[l + e * nd] * c5; q[e] = rop[l + e * nd]; }
+    if (k < r.k1) { lu_neighbour<FULL, 2, -1>(z, c, l, lt, rop_kn, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+    if (j < r.j1) { lu_neighbour<FULL, 1, -1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+    DG = 1. / c5;
+    if (has_next) {
+      S[0] = rop[l + 1 + nd]; S[1] = rop[l + 1 + 2 * nd]; S[2] = rop[l + 1 + 3 * nd]; S[3] = rop[l + 1 + 4 * nd];
+      CR = coe[l + 1 + nd];
+      if (last_of_unit) {
+#pragma unroll
+        for (int e = 0; e < 5; e++) P[e] = dw[l + 1 + e * nd];
+      }
+    }
+  }
+  for (int st = 7; st >= 0; st--) {
+    double pin[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+      const double dn = __shfl_down(P[e], 1, 8);
+      pin[e] = last_of_unit ? P[e] : dn;
+    }
+    if (m == st && active) {
+      if (has_next) {
+        double b[5];
+        lu_term<FULL, 0, -1>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+#pragma unroll
+        for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL;
+      }
+#pragma unroll
+      for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) dw[l + e * nd] = P[e];
+    // Newton update (mjr_newton.for)
+    const double ro_old = q[0], u_old = q[1], v_old = q[2], w_old = q[3], t_old = q[4];
+    const double rn = ro_old + P[0];
+    const double r_1 = 1. / rn;
+    const double un = (ro_old * u_old + P[1]) * r_1;
+    const double vn = (ro_old * v_old + P[2]) * r_1;
+    const double wn = (ro_old * w_old + P[3]) * r_1;
+    const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+    rop_new[l] = rn; rop_new[l + nd] = un; rop_new[l + 2 * nd] = vn; rop_new[l + 3 * nd] = wn;
+    rop_new[l + 4 * nd] = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const double *__restrict__ src,
                                                     double *__restrict__ dst)
 {
@@ -275,20 +580,61 @@ int fsk_lusgs(const FsZone &z, double gamma, const double *rop, double *rop_out,
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
   const unsigned gx = (unsigned)((z.jv + 63) / 64);
-  for (int h = 0; h < nh; h++) {
-    // k values that can hold a cell of this plane
-    int klo = h - (z.iv - 1) - (z.jv - 1); if (klo < 0) klo = 0;
-    int khi = h < z.kv - 1 ? h : z.kv - 1;
-    dim3 g(gx, (unsigned)(khi - klo + 1));
-    if (full) hipLaunchKernelGGL((k_lu_lower<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
-    else hipLaunchKernelGGL((k_lu_lower<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
-  }
-  for (int h = nh - 1; h >= 0; h--) {
-    int klo = h - (z.iv - 1) - (z.jv - 1); if (klo < 0) klo = 0;
-    int khi = h < z.kv - 1 ? h : z.kv - 1;
-    dim3 g(gx, (unsigned)(khi - klo + 1));
-    if (full) hipLaunchKernelGGL((k_lu_upper<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-    else hipLaunchKernelGGL((k_lu_upper<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+  // FASTS_HIP_LU = cell | chunk selects the simpler forms of the sweeps (debugging aids)
+  static const bool per_cell = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "cell") == 0;
+  static const bool per_chunk = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "chunk") == 0;
+  if (!per_cell && !per_chunk) {
+    const int nchunk = (z.iv + 7) / 8;
+    const int nhc = nchunk + z.jv + z.kv - 2;
+    const unsigned gx8 = (unsigned)((z.jv + 7) / 8);
+    for (int pass = 0; pass < 2; pass++)
+      for (int n = 0; n < nhc; n++) {
+        const int h = pass == 0 ? n : nhc - 1 - n;
+        int klo = h - (nchunk - 1) - (z.jv - 1); if (klo < 0) klo = 0;
+        int khi = h < z.kv - 1 ? h : z.kv - 1;
+        dim3 g(gx8, (unsigned)(khi - klo + 1));
+        if (pass == 0) {
+          if (full) hipLaunchKernelGGL((k_lu_lower_wave<true>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+          else hipLaunchKernelGGL((k_lu_lower_wave<false>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+        } else {
+          if (full) hipLaunchKernelGGL((k_lu_upper_wave<true>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+          else hipLaunchKernelGGL((k_lu_upper_wave<false>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+        }
+      }
+  } else if (per_cell) {
+    for (int h = 0; h < nh; h++) {
+      // k values that can hold a cell of this plane
+      int klo = h - (z.iv - 1) - (z.jv - 1); if (klo < 0) klo = 0;
+      int khi = h < z.kv - 1 ? h : z.kv - 1;
+      dim3 g(gx, (unsigned)(khi - klo + 1));
+      if (full) hipLaunchKernelGGL((k_lu_lower<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
+      else hipLaunchKernelGGL((k_lu_lower<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
+    }
+    for (int h = nh - 1; h >= 0; h--) {
+      int klo = h - (z.iv - 1) - (z.jv - 1); if (klo < 0) klo = 0;
+      int khi = h < z.kv - 1 ? h : z.kv - 1;
+      dim3 g(gx, (unsigned)(khi - klo + 1));
+      if (full) hipLaunchKernelGGL((k_lu_upper<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+      else hipLaunchKernelGGL((k_lu_upper<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+    }
+  } else {
+    constexpr int CH = 8;
+    const int nchunk = (z.iv + CH - 1) / CH;
+    const int nhc = nchunk + z.jv + z.kv - 2;
+    for (int pass = 0; pass < 2; pass++)
+      for (int n = 0; n < nhc; n++) {
+        const int h = pass == 0 ? n : nhc - 1 - n;
+        int klo = h - (nchunk - 1) - (z.jv - 1); if (klo < 0) klo = 0;
+        int khi = h < z.kv - 1 ? h : z.kv - 1;
+        dim3 g(gx, (unsigned)(khi - klo + 1));
+        if (pass == 0) {
+          if (full) hipLaunchKernelGGL((k_lu_lower_chunk<true, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+          else hipLaunchKernelGGL((k_lu_lower_chunk<false, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+        } else {
+          if (full) hipLaunchKernelGGL((k_lu_upper_chunk<true, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+          else hipLaunchKernelGGL((k_lu_upper_chunk<false, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+        }
+      }
   }
   if (inplace) {
     dim3 g((unsigned)((z.iv + 255) / 256), (unsigned)z.jv, (unsigned)z.kv);
