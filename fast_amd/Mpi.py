@@ -214,10 +214,19 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     return (t, tc, metrics)
 
 
-def _steps(ctx, halo, nitrun, nitmax, nit=1):
+def _is_implicit(zones):
+    return int(Internal.getNodeFromName2(zones[0], 'Parameter_int')[1][29]) < 2
+
+
+def _steps(ctx, halo, nitrun, nitmax, nit=1, implicit=False):
+    """implicit: the last of the nitmax slots is the reference's verification pass and is skipped
+    (Fast/FastS/FastS/PyTree.py:123); the Newton iterates travel through the joins after every
+    sub-iteration, each zone runs its own LU-SGS sweep (lu_match = 0)."""
     main, comm = getattr(halo, 'main', None), getattr(halo, 'stream', None)
     for it in range(nit):
         for nstep in range(1, nitmax + 1):
+            if implicit and nstep == nitmax:
+                continue
             n = nitrun * nit + it
             if main is not None and getattr(halo, 'overlap', False):
                 ctx.stage_part(n, nstep, 0)          # tiles that feed the messages
@@ -233,7 +242,7 @@ def _steps(ctx, halo, nitrun, nitmax, nit=1):
                 main.wait_stream(comm)
             ctx.local_joins(nstep)
             ctx.bcs(nstep)
-        if nitmax % 2 == 1:
+        if implicit or nitmax % 2 == 1:
             ctx.rotate()
 
 
@@ -250,10 +259,11 @@ def _compute(t, metrics, nitrun, tc=None, graph=None, tc2=None, graph2=None, lay
     dtloc = FastC.HOOK['dtloc']
     nitmax = int(dtloc[0])
     nit = 1 if layer == "Python" else NIT
-    _steps(ctx, halo, nitrun, nitmax, nit)
+    implicit = _is_implicit(Internal.getZones(t))
+    _steps(ctx, halo, nitrun, nitmax, nit, implicit)
     case = nit % 3
     if case != 0:
-        FastC.switchPointers__(Internal.getZones(t), case, nitmax % 2 + 2)
+        FastC.switchPointers__(Internal.getZones(t), case, 3 if implicit else nitmax % 2 + 2)
     FastC.HOOK["FIRST_IT"] = 1
     FastC.FIRST_IT = 1
     if not FastS._lazy():
@@ -267,7 +277,7 @@ class tgv_job:
     """Weak-scaling Taylor-Green job: the periodic box is split in `blocks` equal blocks of n^3
     cells, rank r owns block r (the layout of Fast/FastS/test/tgvMpi.py:29-50)."""
 
-    def __init__(self, n, blocks, scheme, model, my_rank, world, local_rank, time_step=None):
+    def __init__(self, n, blocks, scheme, model, my_rank, world, local_rank, time_step=None, **case_options):
         from . import cases, connect
         from . import pytree_lite as C
         nb = blocks[0] * blocks[1] * blocks[2]
@@ -276,7 +286,7 @@ class tgv_job:
         nn = (n * blocks[0], n * blocks[1], n * blocks[2])
         if time_step is None:
             time_step = 0.003 * 32. / max(nn)
-        self.t = cases.tgv(nn, scheme, model=model, time_step=time_step, blocks=blocks, only=[my_rank])
+        self.t = cases.tgv(nn, scheme, model=model, time_step=time_step, blocks=blocks, only=[my_rank], **case_options)
         names = ['cart%d' % b for b in range(nb)]
         self.tc = C.node2Center(self.t)
         joins = [j for j in connect.periodic_block_joins(blocks, (n, n, n)) if j[1] == my_rank]
@@ -287,6 +297,7 @@ class tgv_job:
         self.halo = FastC.HOOK['halo']
         self.zone = Internal.getZones(self.t)[0]
         self.nitmax = int(FastC.HOOK['dtloc'][0])
+        self.implicit = _is_implicit([self.zone])
 
     def step(self, it):
-        _steps(self.ctx, self.halo, it, self.nitmax)
+        _steps(self.ctx, self.halo, it, self.nitmax, 1, self.implicit)

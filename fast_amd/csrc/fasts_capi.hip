@@ -38,6 +38,7 @@ struct Zone {
   // stage-kernel tiles that hold donor cells of joins to other contexts ("shell") and the others
   int *shell_dev = nullptr, *inner_dev = nullptr;
   int n_shell = 0, n_inner = 0;
+  bool has_sends = false;         // some of its cells are donors of joins to other contexts
   hipEvent_t ev_part = nullptr;   // start of a split stage (timing)
 };
 
@@ -491,6 +492,7 @@ static int build_shell_lists(fs_ctx *ctx)
   for (size_t nz = 0; nz < ctx->zones.size(); nz++) {
     Zone &zn = ctx->zones[nz];
     const FsZone &z = zn.z;
+    for (auto &s : ctx->sends) if (s.donor_zone == (int)nz) zn.has_sends = true;
     if (z.ityp == 0 || ctx->implicit) continue;   // curvilinear / implicit zones run their stage in one piece
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
@@ -525,7 +527,8 @@ static int build_shell_lists(fs_ctx *ctx)
 }
 
 // part < 0: the whole stage.  part 0: viscosity + the shell tiles.  part 1: the remaining tiles
-// (+ residual norms).  Zones without joins to other contexts run entirely in part 1.
+// (+ residual norms).  Zones that are not split (no joins to other contexts, curvilinear zones, implicit
+// scheme) run in one piece: in part 0 if other contexts wait for their cells, else in part 1.
 static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *who)
 {
   int rc = ensure_ready(ctx, who);
@@ -543,9 +546,10 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     double coefH, coefW;
     rk_coefs(z.rk, nstep, coefH, coefW);
     const bool split = part >= 0 && zn.n_shell > 0;
+    // a zone that cannot be split runs in one piece: in part 0 when messages wait for its cells, else in part 1
+    if (part >= 0 && !split && part != (zn.has_sends ? 0 : 1)) continue;
     const bool opens = part <= 0 || !split;      // this call starts the stage of this zone
-    const bool closes = part != 0;               // this call ends it (part 0 of an unsplit zone does nothing)
-    if (part == 0 && !split) continue;
+    const bool closes = part != 0 || !split;     // this call ends it
     FsBdf bdf = {zn.dev[0], zn.dev[1], -1.5, 2., -0.5, nstep == 1};
     if (ctx->first_it == 0) { bdf.c1 = -1.; bdf.c2 = 1.; bdf.c3 = 0.; }   // core3as2.for:37-45
     const FsBdf *pbdf = ctx->implicit ? &bdf : nullptr;

@@ -3,7 +3,7 @@ fast_amd.Mpi (warmup / _compute over torch.distributed) with every rank on GPU 0
 messages staged through the host by the gloo backend.  Each rank compares its block with a
 serial run of the whole job by the CPU restatement.
 
-    python mpi_gpu_worker.py <bi> <bj> <bk> <n> <nsteps>
+    python mpi_gpu_worker.py <bi> <bj> <bk> <n> <nsteps> [explicit|implicit|curvilinear]
 """
 import os
 import sys
@@ -28,15 +28,21 @@ SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blockin
 def main():
     blocks = tuple(int(a) for a in sys.argv[1:4])
     n = int(sys.argv[4]); nsteps = int(sys.argv[5])
+    mode = sys.argv[6] if len(sys.argv) > 6 else 'explicit'
+    nn = tuple(n * b for b in blocks)
+    opts = {'time_step': 0.003 * 32. / max(nn)}
+    if mode == 'implicit':      # BDF + LU-SGS, the Newton iterates cross the rank boundary every sub-iteration
+        opts = {'time_step': 0.02, 'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': 3}}
+    elif mode == 'curvilinear':
+        opts['perturb'] = 0.15
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
-    job = FastSmpi.tgv_job(n, blocks, 'senseur', 'NSLaminar', rank, world, 0)
+    job = FastSmpi.tgv_job(n, blocks, 'senseur', 'NSLaminar', rank, world, 0, **opts)
     for it in range(1, nsteps + 1):
         FastSmpi._compute(job.t, job.metrics, it, job.tc, job.graph)
     got = FastC.level_buffer(Internal.getZones(job.t)[0])
 
-    nn = tuple(n * b for b in blocks)
-    tt = cases.tgv(nn, 'senseur', blocks=blocks, time_step=0.003 * 32. / max(nn))
+    tt = cases.tgv(nn, 'senseur', blocks=blocks, **opts)
     mm = prepare(tt)
     zs = []
     for zz, m in zip(Internal.getZones(tt), mm):
