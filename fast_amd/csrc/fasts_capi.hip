@@ -30,6 +30,12 @@ struct Zone {
   double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]
   // implicit scheme: coe(nd,5) = dt/vol, spectral radii i/j/k, LU diagonal; one spare time level
   double *coe = nullptr, *scratch = nullptr;
+  // implicit scheme with wall BCs: windows applied to the Newton residual before the LU solve (whole-face
+  // extrapolation first, then the BCs of the wall faces) and the LU range (one ghost layer over wall faces)
+  std::vector<FsBcWin> rhs_face, rhs_bc;
+  FsBcWin *rhs_face_dev = nullptr, *rhs_bc_dev = nullptr;
+  long long rhs_max_cells = 0;
+  int lu[6] = {0, 0, 0, 0, 0, 0};
   double *res_part = nullptr, *res_out = nullptr;
   FsBcWin *bc_dev = nullptr;
   std::vector<FsBcWin> bc;
@@ -137,7 +143,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
   }
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
@@ -293,9 +299,6 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       snprintf(msg, sizeof msg, "fs_zone_add: boundary condition tag %d is not implemented", tag);
       return fail(ctx, FS_ERR_UNSUPPORTED, msg);
     }
-    if (implicit && ((tag >= 3 && tag <= 7) || tag == 12 || tag == 18 || tag == 30))
-      return fail(ctx, FS_ERR_UNSUPPORTED,
-                  "fs_zone_add: implicit treatment of wall boundaries (LU sweeps extended over the wall ghost cells) is not implemented");
     if ((w.type == FS_BC_WALL_SLIP || w.type == FS_BC_WALL_NOSLIP) && p[KFLUDOM] == 5)
       return fail(ctx, FS_ERR_UNSUPPORTED,
                   "fs_zone_add: the wall-face flux correction of the roe scheme (bfl3) is not implemented; "
@@ -320,6 +323,49 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     if (cells > zn.bc_max_cells) zn.bc_max_cells = cells;
     zn.bc.push_back(w);
   }
+  if (implicit) {
+    // BCzone with lrhs = 1 (Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,262-264): faces that carry a wall
+    // BC (tags 3..7) get the residual extrapolated over the whole face, then their BCs applied to it (walls as
+    // walls, the rest as extrapolation); the LU range grows by one ghost layer there
+    int lskip[6] = {1, 1, 1, 1, 1, 1};
+    for (int ndf = 0; ndf < nb; ndf++) {
+      const int pt = p[pt_bcs + 1 + ndf], tag = p[pt], idir = p[pt + 1];
+      if (tag >= 3 && tag <= 7 && idir >= 1 && idir <= 6) lskip[idir - 1] = 0;
+    }
+    const int ijkv[3] = {z.iv, z.jv, z.kv};
+    for (int d = 0; d < 3; d++) {
+      zn.lu[2 * d] = 1 - (1 - lskip[2 * d]);
+      zn.lu[2 * d + 1] = ijkv[d] + (1 - lskip[2 * d + 1]);
+    }
+    for (int f = 0; f < 6; f++) {
+      if (lskip[f]) continue;
+      int32_t fen[6] = {1, z.iv, 1, z.jv, 1, z.kv};
+      const int d = f / 2;
+      if (f % 2 == 0) fen[2 * d + 1] = 1; else fen[2 * d] = fen[2 * d + 1];
+      FsBcWin w;
+      memset(&w, 0, sizeof w);
+      w.type = FS_BC_EXTRAPOLATE; w.idir = f + 1;
+      if (!bc_window(p, w.idir, fen, w)) continue;
+      long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
+      if (cells > zn.rhs_max_cells) zn.rhs_max_cells = cells;
+      zn.rhs_face.push_back(w);
+    }
+    for (int ndf = 0; ndf < nb; ndf++) {
+      const int pt = p[pt_bcs + 1 + ndf], tag = p[pt], idir = p[pt + 1];
+      if (tag == 22 || idir < 1 || idir > 6 || lskip[idir - 1]) continue;
+      FsBcWin w;
+      memset(&w, 0, sizeof w);
+      w.idir = idir;
+      if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
+      else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
+      else w.type = FS_BC_EXTRAPOLATE;
+      if (!bc_window(p, idir, p + pt + 2, w)) continue;
+      w.tcn = idir <= 2 ? mtr[0] : (idir <= 4 ? mtr[1] : mtr[2]);
+      long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
+      if (cells > zn.rhs_max_cells) zn.rhs_max_cells = cells;
+      zn.rhs_bc.push_back(w);
+    }
+  }
   if (z.ityp == 0) {   // last step that can fail: nothing to release on the error paths above
     (void)hipSetDevice(ctx->device);
     const size_t nb = sizeof(double) * 10 * (size_t)z.ndm;
@@ -327,7 +373,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     hipError_t e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
       return fail(ctx, FS_ERR_HIP, std::string("fs_zone_add: metric upload: ") + hipGetErrorString(e));
     }
     z.mt[0] = zn.mtr_dev; z.mt[1] = zn.mtr_dev + 3 * z.ndm; z.mt[2] = zn.mtr_dev + 6 * z.ndm;
@@ -421,6 +467,14 @@ extern "C" int fs_upload(fs_ctx *ctx)
       if (!zn.bc.empty()) {
         HIPCHK(ctx, hipMalloc(&zn.bc_dev, sizeof(FsBcWin) * zn.bc.size()));
         HIPCHK(ctx, hipMemcpy(zn.bc_dev, zn.bc.data(), sizeof(FsBcWin) * zn.bc.size(), hipMemcpyHostToDevice));
+      }
+      if (!zn.rhs_face.empty()) {
+        HIPCHK(ctx, hipMalloc(&zn.rhs_face_dev, sizeof(FsBcWin) * zn.rhs_face.size()));
+        HIPCHK(ctx, hipMemcpy(zn.rhs_face_dev, zn.rhs_face.data(), sizeof(FsBcWin) * zn.rhs_face.size(), hipMemcpyHostToDevice));
+      }
+      if (!zn.rhs_bc.empty()) {
+        HIPCHK(ctx, hipMalloc(&zn.rhs_bc_dev, sizeof(FsBcWin) * zn.rhs_bc.size()));
+        HIPCHK(ctx, hipMemcpy(zn.rhs_bc_dev, zn.rhs_bc.data(), sizeof(FsBcWin) * zn.rhs_bc.size(), hipMemcpyHostToDevice));
       }
     }
     for (int r = 0; r < 3; r++)
@@ -600,8 +654,13 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out, ctx->stream);
       zn.have_res = true;
     }
-    if (ctx->implicit) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:135-161)
-      if (fsk_lusgs(z, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ctx->stream))
+    if (ctx->implicit) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:53-68,135-161)
+      if (!zn.rhs_face.empty()) {   // wall faces: BCs on the residual, two ordered passes, then edges/corners
+        fsk_bc_windows(z, (int)zn.rhs_face.size(), zn.rhs_face_dev, zn.rhs_max_cells, zn.drodm, ctx->stream);
+        fsk_bc_windows(z, (int)zn.rhs_bc.size(), zn.rhs_bc_dev, zn.rhs_max_cells, zn.drodm, ctx->stream);
+        fsk_bc_edges(z, zn.drodm, ctx->stream);
+      }
+      if (fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ctx->stream))
         return fail(ctx, FS_ERR_STATE, std::string(who) + ": LU-SGS scratch level missing");
     }
   }

@@ -51,5 +51,6 @@ void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *par
 // implicit scheme (fasts_lusgs.hip)
 void fsk_coe_implicit(const FsZone &z, int first_it, double gamma, double prandtl, double rgp, const double *rop,
                       const double *xmut, double *coe, hipStream_t s);
-int fsk_lusgs(const FsZone &z, double gamma, const double *rop, double *rop_out, double *scratch, double *dw,
-              const double *coe, hipStream_t s);
+// range[6] = cells swept (interior, plus one ghost layer on wall faces)
+int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out, double *scratch,
+              double *dw, const double *coe, hipStream_t s);

@@ -566,32 +566,34 @@ void fsk_coe_implicit(const FsZone &z, int first_it, double gamma, double prandt
 // LU-SGS on the interior of the zone + Newton update.  rop = current iterate; the new iterate is
 // written to rop_out.  When rop_out == rop (in-place update, sub-iterations after the first) the new
 // state is built in scratch (a full time level) and copied back.
-int fsk_lusgs(const FsZone &z, double gamma, const double *rop, double *rop_out, double *scratch, double *dw,
-              const double *coe, hipStream_t s)
+int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out, double *scratch,
+              double *dw, const double *coe, hipStream_t s)
 {
   LuConst c;
   c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
   c.cv = z.cv; c.cvinv = 1. / z.cv; c.cvinv2 = 0.5 * c.cvinv;
-  LuRange r = {1, z.iv, 1, z.jv, 1, z.kv};
-  const int nh = z.iv + z.jv + z.kv - 2;
+  LuRange r = {range[0], range[1], range[2], range[3], range[4], range[5]};
+  const int ni = r.i1 - r.i0 + 1, nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
+  if (ni < 1 || nj < 1 || nk < 1) return -1;
+  const int nh = ni + nj + nk - 2;
   const bool full = z.ityp == 0;
   const bool inplace = rop_out == rop;
   if (inplace && !scratch) return -1;
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
-  const unsigned gx = (unsigned)((z.jv + 63) / 64);
+  const unsigned gx = (unsigned)((nj + 63) / 64);
   // FASTS_HIP_LU = cell | chunk selects the simpler forms of the sweeps (debugging aids)
   static const bool per_cell = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "cell") == 0;
   static const bool per_chunk = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "chunk") == 0;
   if (!per_cell && !per_chunk) {
-    const int nchunk = (z.iv + 7) / 8;
-    const int nhc = nchunk + z.jv + z.kv - 2;
-    const unsigned gx8 = (unsigned)((z.jv + 7) / 8);
+    const int nchunk = (ni + 7) / 8;
+    const int nhc = nchunk + nj + nk - 2;
+    const unsigned gx8 = (unsigned)((nj + 7) / 8);
     for (int pass = 0; pass < 2; pass++)
       for (int n = 0; n < nhc; n++) {
         const int h = pass == 0 ? n : nhc - 1 - n;
-        int klo = h - (nchunk - 1) - (z.jv - 1); if (klo < 0) klo = 0;
-        int khi = h < z.kv - 1 ? h : z.kv - 1;
+        int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
+        int khi = h < nk - 1 ? h : nk - 1;
         dim3 g(gx8, (unsigned)(khi - klo + 1));
         if (pass == 0) {
           if (full) hipLaunchKernelGGL((k_lu_lower_wave<true>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
@@ -604,28 +606,28 @@ int fsk_lusgs(const FsZone &z, double gamma, const double *rop, double *rop_out,
   } else if (per_cell) {
     for (int h = 0; h < nh; h++) {
       // k values that can hold a cell of this plane
-      int klo = h - (z.iv - 1) - (z.jv - 1); if (klo < 0) klo = 0;
-      int khi = h < z.kv - 1 ? h : z.kv - 1;
+      int klo = h - (ni - 1) - (nj - 1); if (klo < 0) klo = 0;
+      int khi = h < nk - 1 ? h : nk - 1;
       dim3 g(gx, (unsigned)(khi - klo + 1));
       if (full) hipLaunchKernelGGL((k_lu_lower<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
       else hipLaunchKernelGGL((k_lu_lower<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
     }
     for (int h = nh - 1; h >= 0; h--) {
-      int klo = h - (z.iv - 1) - (z.jv - 1); if (klo < 0) klo = 0;
-      int khi = h < z.kv - 1 ? h : z.kv - 1;
+      int klo = h - (ni - 1) - (nj - 1); if (klo < 0) klo = 0;
+      int khi = h < nk - 1 ? h : nk - 1;
       dim3 g(gx, (unsigned)(khi - klo + 1));
       if (full) hipLaunchKernelGGL((k_lu_upper<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
       else hipLaunchKernelGGL((k_lu_upper<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
     }
   } else {
     constexpr int CH = 8;
-    const int nchunk = (z.iv + CH - 1) / CH;
-    const int nhc = nchunk + z.jv + z.kv - 2;
+    const int nchunk = (ni + CH - 1) / CH;
+    const int nhc = nchunk + nj + nk - 2;
     for (int pass = 0; pass < 2; pass++)
       for (int n = 0; n < nhc; n++) {
         const int h = pass == 0 ? n : nhc - 1 - n;
-        int klo = h - (nchunk - 1) - (z.jv - 1); if (klo < 0) klo = 0;
-        int khi = h < z.kv - 1 ? h : z.kv - 1;
+        int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
+        int khi = h < nk - 1 ? h : nk - 1;
         dim3 g(gx, (unsigned)(khi - klo + 1));
         if (pass == 0) {
           if (full) hipLaunchKernelGGL((k_lu_lower_chunk<true, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
@@ -637,7 +639,7 @@ int fsk_lusgs(const FsZone &z, double gamma, const double *rop, double *rop_out,
       }
   }
   if (inplace) {
-    dim3 g((unsigned)((z.iv + 255) / 256), (unsigned)z.jv, (unsigned)z.kv);
+    dim3 g((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
     hipLaunchKernelGGL(k_copy_range, g, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
   }
   return 0;

@@ -1370,12 +1370,58 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
   }
 }
 
+/* BCzone with lrhs = 1 on the Newton residual (Fast/FastS/FastS/Compute/lhs.cpp:53-68,
+ * Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,451-523).  On every zone face that carries a wall-type BC
+ * (tags 3..7) the residual is extrapolated into the ghost cells over the whole face, then every BC of that
+ * face is applied to the residual (walls as walls: bvbs_wall_* with lrhs = 1 only switch the mesh velocity
+ * off; every other type as extrapolation), the LU range grows by one ghost layer on that face, and edges
+ * and corners are averaged.  lu receives the LU range; returns -1 for BC types that are not restated. */
+int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *tj, const double *tk, i32 *lu)
+{
+  const int pt_bcs = p[PT_BC], nb = p[pt_bcs];
+  const i32 sdm[6] = {1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2]};
+  int lskip[6] = {1, 1, 1, 1, 1, 1}, any = 0;
+  i32 cl[6];
+  for (int ndf = 0; ndf < nb; ndf++) {
+    const int pt = p[pt_bcs + 1 + ndf], type = p[pt], idir = p[pt + 1];
+    if (type == 12 || type == 18 || type == 30) return -1;
+    if (type >= 3 && type <= 7) { lskip[idir - 1] = 0; any = 1; }
+  }
+  for (int d = 0; d < 3; d++) {
+    lu[2 * d] = sdm[2 * d] - (1 - lskip[2 * d]);
+    lu[2 * d + 1] = sdm[2 * d + 1] + (1 - lskip[2 * d + 1]);
+  }
+  if (!any) return 0;
+  for (int f = 0; f < 6; f++) {
+    if (lskip[f]) continue;
+    i32 fen[6] = {sdm[0], sdm[1], sdm[2], sdm[3], sdm[4], sdm[5]};
+    const int d = f / 2;
+    if (f % 2 == 0) { fen[2 * d] = 1; fen[2 * d + 1] = 1; }
+    else fen[2 * d] = fen[2 * d + 1];
+    if (fo_indice_cl(f + 1, p, fen, sdm, cl)) continue;
+    fo_bc_extrapolate(p, f + 1, cl, drodm);
+  }
+  for (int ndf = 0; ndf < nb; ndf++) {
+    const int pt = p[pt_bcs + 1 + ndf], type = p[pt], idir = p[pt + 1];
+    if (lskip[idir - 1]) continue;
+    if (fo_indice_cl(idir, p, p + pt + 2, sdm, cl)) continue;
+    if (type == 0 || type == 1 || type == 2 || type == 10 || type == 11 || type == 14 || type == 16 || type == 17 ||
+        type == 20 || type == 21)
+      fo_bc_extrapolate(p, idir, cl, drodm);
+    else if (type == 22) continue;
+    else if (type == 3 || (type == 4 && p[IFLOW] == 1) || type == 5) fo_bc_wall_inviscid(p, idir, cl, drodm, ti, tj, tk);
+    else if ((type == 6 || type == 4) && p[IFLOW] > 1) fo_bc_wall_viscous(p, idir, cl, drodm);
+    else return -1;
+  }
+  fo_correct_coins(p, drodm);
+  return 0;
+}
+
 /* One Newton sub-iteration of one zone, one cache block, one thread: sequence of
  * Fast/FastS/FastS/Compute/navier_stokes_struct.for:199-275 (viscosity and coefficients at the first
  * sub-iteration, on the whole zone), :295-301 (drodm = 0), :310-345 (fluxes), :406-419 (core3as2) and
- * Fast/FastS/FastS/Compute/lhs.cpp:135-161 (invlu).  rop_ss = current Newton iterate (ro at the first
- * sub-iteration, ro_p1 afterwards); the new iterate is written to ro_p1.  Returns -1 where the LU range
- * would have to be extended over wall ghost cells (BCzone.cpp:100-127), which is not restated.
+ * Fast/FastS/FastS/Compute/lhs.cpp:53-68,135-161 (BCs on the residual, invlu).  rop_ss = current Newton
+ * iterate (ro at the first sub-iteration, ro_p1 afterwards); the new iterate is written to ro_p1.
  * newton_rhs (may be NULL) receives the Newton residual before the LU solve, the array whose norms the
  * reference tabulates (Fast/FastS/FastS/Compute/residus_navier.h, cprdu3s1_incl.for:47-71). */
 int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it, const double *ro,
@@ -1388,11 +1434,6 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
   const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
   if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[DTLOC] != 0 || p[NEQ] != 5) return -1;
-  const int pt_bcs = p[PT_BC];
-  for (int ndf = 0; ndf < p[pt_bcs]; ndf++) {
-    const int bt = p[p[pt_bcs + 1 + ndf]];
-    if ((bt >= 3 && bt <= 7) || bt == 12 || bt == 18 || bt == 30) return -1;
-  }
   const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);
@@ -1403,6 +1444,8 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   fo_flux(p, pr, sdm, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);
   fo_core3as2(p, pr, nitcfg, first_it, sdm, rop_ss, ro, ro_m1, drodm, coe);
   if (newton_rhs) memcpy(newton_rhs, drodm, sizeof(double) * 5 * (size_t)p[NDIMDX]);
-  fo_invlu(p, pr, sdm, drodm, rop_ss, ro_p1, ti, tj, tk, coe);
+  i32 lu[6];
+  if (fo_bczone_rhs(p, drodm, ti, tj, tk, lu)) return -1;
+  fo_invlu(p, pr, lu, drodm, rop_ss, ro_p1, ti, tj, tk, coe);
   return 0;
 }

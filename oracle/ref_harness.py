@@ -243,20 +243,82 @@ class RefSolver:
             self._bczone(nd, zn, 1, arrays[nd])
 
     # -- implicit: LU-SGS solve + Newton update of one zone ---------------------------------
-    def _invlu(self, nd, zn, nitrun, nstep, ro_ssiter):
-        """Fast/FastS/FastS/Compute/lhs.cpp:135-161 for nb_relax = 1, lu_match = 0 and no wall BC:
-        BCzone(lrhs=1) then leaves the residual alone and the LU range is the zone interior
-        (Fast/FastS/FastS/BC/BCzone.cpp:100-127)."""
+    def _bczone_rhs(self, nd, zn, nstep):
+        """BCzone with lrhs = 1 on the Newton residual (Fast/FastS/FastS/Compute/lhs.cpp:53-68,
+        Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,451-523): on every zone face that carries a wall-type
+        BC the residual is first extrapolated into the ghost cells over the whole face, then every BC of
+        that face is applied to it (walls as walls, the others as extrapolation); the LU range grows by
+        one ghost layer on those faces; edges and corners are then averaged (correct_coins).
+        Returns the LU range."""
         L = lib()
         p = zn.pint
-        pt_bcs = int(p[PT_BC])
-        for ndf in range(int(p[pt_bcs])):
-            bt = int(p[int(p[pt_bcs + 1 + ndf])])
+        pt_bcs = int(p[PT_BC]); nb_bc = int(p[pt_bcs])
+        lskip = [1] * 6
+        for ndf in range(nb_bc):
+            pt_bc = int(p[pt_bcs + 1 + ndf]); bt = int(p[pt_bc]); ipara = int(p[pt_bc + 1]) - 1
             if (3 <= bt <= 7) or bt in (12, 18, 30):
-                raise NotImplementedError("ref_harness: implicit wall treatment (BC tag %d)" % bt)
+                if bt in (12, 18, 30) or (bt == 4 and p[IFLOW] == 1 and False):
+                    raise NotImplementedError("ref_harness: implicit treatment of BC tag %d" % bt)
+                lskip[ipara] = 0
+        shift = zn.ind_dm.copy()
+        for d in range(3):
+            shift[2 * d] -= (1 - lskip[2 * d]); shift[2 * d + 1] += (1 - lskip[2 * d + 1])
+        if all(lskip):
+            return shift
+        state = np.zeros(6)
+        ind_cl = np.zeros(6, dtype=np.int32); ind_cl119 = np.zeros(6, dtype=np.int32)
+        lsk = ctypes.c_int32(0)
+        ijkv = np.ascontiguousarray(p[IJKV:IJKV + 3])
+
+        def call(fn, idir, cl, tijk, neq_mtr):
+            fn(_i(idir), _i(1), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(cl),
+               _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+               _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(zn.drodm), _p(zn.xmut), _p(state))
+
+        for idir0 in range(6):
+            if lskip[idir0]:
+                continue
+            ind_rhs = zn.ind_dm.copy()
+            d = idir0 // 2
+            if idir0 % 2 == 0: ind_rhs[2 * d] = 1; ind_rhs[2 * d + 1] = 1
+            else: ind_rhs[2 * d] = ind_rhs[2 * d + 1]
+            L.indice_cl_sdm_(_i(idir0 + 1), _i(0), ctypes.byref(lsk), _i(0), _i(p[NIJK + 3]), _i(p[NIJK + 4]),
+                             _p(ijkv), _p(ind_rhs), _p(zn.ind_dm), _p(zn.ind_dm), _p(ind_cl), _p(ind_cl119))
+            if lsk.value == 0:
+                call(L.bvbs_extrapolate_, idir0 + 1, ind_cl119, zn.ti, int(p[NEQ_IJ]))
+        for ndf in range(nb_bc):
+            pt_bc = int(p[pt_bcs + 1 + ndf]); bt = int(p[pt_bc]); idir = int(p[pt_bc + 1])
+            if lskip[idir - 1]:
+                continue
+            if idir <= 2: tijk, neq_mtr = zn.ti, int(p[NEQ_IJ])
+            elif idir <= 4: tijk, neq_mtr = zn.tj, int(p[NEQ_IJ])
+            else: tijk, neq_mtr = zn.tk, int(p[NEQ_K])
+            fen = np.ascontiguousarray(p[pt_bc + 2:pt_bc + 8])
+            L.indice_cl_sdm_(_i(idir), _i(0), ctypes.byref(lsk), _i(bt), _i(p[NIJK + 3]), _i(p[NIJK + 4]),
+                             _p(ijkv), _p(fen), _p(zn.ind_dm), _p(zn.ind_dm), _p(ind_cl), _p(ind_cl119))
+            if lsk.value != 0:
+                continue
+            if bt in (0, 1, 2, 10, 11, 14, 16, 17, 20, 21):
+                call(L.bvbs_extrapolate_, idir, ind_cl119, tijk, neq_mtr)
+            elif bt == 3 or (bt == 4 and p[IFLOW] == 1) or bt == 5:
+                call(L.bvbs_wall_inviscid_, idir, ind_cl, tijk, neq_mtr)
+            elif bt in (4, 6) and p[IFLOW] > 1:
+                call(L.bvbs_wall_viscous_adia_, idir, ind_cl, tijk, neq_mtr)
+            elif bt == 22:
+                pass
+            else:
+                raise NotImplementedError("ref_harness: implicit treatment of BC tag %d" % bt)
+        L.correct_coins_(_i(nd), _p(p), _p(shift), _p(zn.drodm))
+        return shift
+
+    def _invlu(self, nd, zn, nitrun, nstep, ro_ssiter):
+        """Fast/FastS/FastS/Compute/lhs.cpp:135-161 for nb_relax = 1, lu_match = 0."""
+        L = lib()
+        p = zn.pint
         assert p[71] == 1 and p[75] == 0, "nb_relax = 1 and lu_match = 0 only"
+        shift = self._bczone_rhs(nd, zn, nstep)
         dummy = np.zeros(8)
-        L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(zn.ind_dm), _p(zn.ind_dm), _i(1),
+        L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(shift), _p(zn.ind_dm), _i(1),
                  _p(zn.ro_p1), _p(ro_ssiter), _p(zn.drodm), _p(zn.drodm),
                  _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),
                  _p(zn.coe), _p(dummy), _i(1))

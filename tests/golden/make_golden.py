@@ -54,6 +54,9 @@ CASES = {
                                  {'ss_iteration': 5, 'time_step': 0.02}),
     'implicit_curv_senseur':    ('tgv', (10, 9, 8), 'senseur', 'NSLaminar', (1, 1, 2), 'single', 6, None,
                                  {'ss_iteration': 3, 'time_step': 0.02, 'perturb': 0.15}),
+    'implicit_channel_curv':    ('tgv', (10, 9, 8), 'ausmpred', 'NSLaminar', (1, 1, 1), 'single', 8,
+                                 {'jmin': 'BCWall', 'jmax': 'BCWallViscous', 'kmin': 'BCFarfield'},
+                                 {'ss_iteration': 4, 'time_step': 0.02, 'perturb': 0.15}),
     'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
     'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
 }

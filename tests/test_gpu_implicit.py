@@ -28,6 +28,12 @@ CASES = [
     ((34, 9, 36), 'senseur', 'Euler', 0.15, None, 2, 2, 'c'),
     ((9, 8, 10), 'ausmpred', 'NSLaminar', 0., FAR, 3, 4, 'c'),
     ((9, 8, 10), 'senseur', 'NSLaminar', 0.15, {'imin': 'BCExtrapolate', 'imax': 'BCFarfield'}, 3, 3, 'c'),
+    # walls: BCs on the residual + LU range over the wall ghost layer
+    ((12, 9, 10), 'ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 3, 4, 'c'),
+    ((10, 9, 8), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 3, 3, 'Python'),
+    ((9, 10, 8), 'senseur', 'Euler', 0.15, {'jmin': 'BCWall', 'kmax': 'BCWallInviscid', 'imin': 'BCFarfield',
+                                            'imax': 'BCSymmetryPlane'}, 2, 3, 'c'),
+    ((20, 9, 19), 'ausmpred', 'NSLaminar', 0., {'imin': 'BCWall', 'imax': 'BCWall', 'kmax': 'BCWall'}, 2, 3, 'c'),
 ]
 
 

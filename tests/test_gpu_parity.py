@@ -78,9 +78,6 @@ def test_unsupported_options_are_refused():
     t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCInflow'})
     with pytest.raises(_capi.FastsHipError, match="tag 13"):
         FastS.warmup(t, None)
-    t = cases.tgv(8, 'senseur', temporal_scheme='implicit', bcs={'jmin': 'BCWall'})
-    with pytest.raises(_capi.FastsHipError, match="implicit treatment of wall"):
-        FastS.warmup(t, None)
     t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'nb_relax': 2})
     with pytest.raises(_capi.FastsHipError, match="nb_relax"):
         FastS.warmup(t, None)

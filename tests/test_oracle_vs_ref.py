@@ -105,6 +105,11 @@ def test_curvilinear_zone_bit_exact(scheme, model, bcs, blocks):
     ('ausmpred', 'NSLaminar', 0., FAR, (1, 1, 1)),
     ('senseur', 'NSLaminar', 0., None, (2, 1, 2)),
     ('ausmpred', 'NSLaminar', 0.15, None, (1, 2, 1)),
+    # walls: the residual is mirrored into the ghost cells and the LU range grows over them
+    ('ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, (1, 1, 1)),
+    ('senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, (1, 1, 1)),
+    ('senseur', 'Euler', 0.15, {'jmin': 'BCWall', 'kmax': 'BCWallInviscid', 'imin': 'BCFarfield', 'imax': 'BCSymmetryPlane'}, (1, 1, 1)),
+    ('ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWall'}, (2, 1, 1)),
 ])
 def test_implicit_lusgs_bit_exact(scheme, model, perturb, bcs, blocks):
     """Implicit time step (BDF1 then BDF2 Newton residual of core3as2.for, coefficients of tstb3c.for,
@@ -126,16 +131,6 @@ def test_implicit_lusgs_bit_exact(scheme, model, perturb, bcs, blocks):
         for a, b in zip(so.zones, sr.zones):
             assert np.array_equal(a.ro, b.ro) and np.array_equal(a.ro_m1, b.ro_m1), "step %d" % it
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
-
-
-def test_implicit_with_walls_is_refused_by_the_oracle():
-    """With wall boundaries the reference extends the LU sweeps over one ghost layer
-    (BC/BCzone.cpp:100-127); that is not restated, so the combination is refused."""
-    t = cases.tgv(8, 'ausmpred', temporal_scheme='implicit', bcs={'jmin': 'BCWall'})
-    so, _ = _pair(t)
-    so.fill_ghostcells()
-    with pytest.raises(NotImplementedError):
-        so.step()
 
 
 def test_roe_with_walls_is_refused_by_the_oracle():
