@@ -17,7 +17,7 @@ enum { NIJK = 0, NIJK_MTR = 5, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29
        NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
        SLOPE = 64, PT_BC = 70, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
 enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
-       VXINF = 19, VYINF = 20, VZINF = 21,
+       CFL = 15, VXINF = 19, VYINF = 20, VZINF = 21,
        PSIROE = 34 };
 
 struct Zone {
@@ -220,7 +220,9 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (p[NEQ] != 5 || p[IFLOW] > 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Euler / NSLaminar (5 equations) are implemented");
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
-  if (p[LALE] != 0 || p[DTLOC] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local time step are not implemented");
+  if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
+  if (p[DTLOC] != 0 && !(p[ITYPCP] == 1 && p[DTLOC] == 1))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: a local time step (time_step_nature='local') needs the implicit scheme");
   if (!implicit && (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK])) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
   if (implicit && p[NSSITER] < 2) return fail(ctx, FS_ERR_ARG, "fs_zone_add: an implicit step needs at least one Newton sub-iteration (NSSITER >= 2)");
   if (p[NIJK + 3] != 2 || p[NIJK + 4] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two ghost layers in every direction are required");
@@ -604,15 +606,16 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     if (part >= 0 && !split && part != (zn.has_sends ? 0 : 1)) continue;
     const bool opens = part <= 0 || !split;      // this call starts the stage of this zone
     const bool closes = part != 0 || !split;     // this call ends it
-    FsBdf bdf = {zn.dev[0], zn.dev[1], -1.5, 2., -0.5, nstep == 1};
-    if (ctx->first_it == 0) { bdf.c1 = -1.; bdf.c2 = 1.; bdf.c3 = 0.; }   // core3as2.for:37-45
+    const bool dtloc = zn.pint[DTLOC] == 1;
+    FsBdf bdf = {zn.dev[0], zn.dev[1], -1.5, 2., -0.5, nstep == 1, dtloc ? zn.coe : nullptr};
+    if (ctx->first_it == 0 || dtloc) { bdf.c1 = -1.; bdf.c2 = 1.; bdf.c3 = 0.; }   // core3as2.for:37-45
     const FsBdf *pbdf = ctx->implicit ? &bdf : nullptr;
     if (opens && nstep == 1) {
       if (z.iflow == 2) fsk_invist(z, ctx->implicit ? z.ific : 1, zn.dev[in], zn.xmut, ctx->stream);
       if (ctx->implicit) {
         const double *r = zn.preal.data();
-        fsk_coe_implicit(z, ctx->first_it, r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in], zn.xmut, zn.coe,
-                         ctx->stream);
+        fsk_coe_implicit(z, ctx->first_it, dtloc, r[CFL], r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in],
+                         zn.xmut, zn.coe, ctx->stream);
       }
       if (z.kflu == 2 && ctx->plain_stage && z.ityp != 0) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }

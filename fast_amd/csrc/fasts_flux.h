@@ -453,6 +453,7 @@ struct FsBdf {
   const double *ro_n, *ro_n1;   // levels n and n-1 (device)
   double c1, c2, c3;            // BDF1: -1, 1, 0   BDF2: -1.5, 2, -0.5
   int nit1;                     // 1 at the first Newton sub-iteration
+  const double *coe1;           // local time step: dt of every cell (coe(:,1)); NULL = global dt/vol
 };
 
 FS_DEV void fs_bdf_residual(const FsZone &z, const FsBdf &b, double coe, const double *q, const double *qn,

@@ -49,8 +49,8 @@ void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *ro
 // use_coe = 1: norms of dt/vol * drodm (explicit balance); 0: norms of drodm (Newton residual, already scaled)
 void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s);
 // implicit scheme (fasts_lusgs.hip)
-void fsk_coe_implicit(const FsZone &z, int first_it, double gamma, double prandtl, double rgp, const double *rop,
-                      const double *xmut, double *coe, hipStream_t s);
+void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, double gamma, double prandtl, double rgp,
+                      const double *rop, const double *xmut, double *coe, hipStream_t s);
 // range[6] = cells swept (interior, plus one ghost layer on wall faces)
 int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out, double *scratch,
               double *dw, const double *coe, hipStream_t s);

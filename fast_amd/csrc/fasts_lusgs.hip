@@ -31,8 +31,10 @@ FS_DEV long long lmtr(const FsZone &z, int i, int j, int k)
 
 // dt/vol, spectral radii and the LU diagonal of every cell of the zone, ghost cells included
 // (storage indices si, sj, sk from 0).
-template <bool FULL>
-__global__ void __launch_bounds__(256) k_coe_implicit(FsZone z, double xid, double gam1, double gam2,
+// DTLOC: local time step, coe(:,1) = CFL * min(convective, viscous) limit of the cell
+// (tstb3_impli.for:57-71, dtloc.for); cut0x = 1e-30 there, 1e-20 with the global time step.
+template <bool FULL, bool DTLOC>
+__global__ void __launch_bounds__(256) k_coe_implicit(FsZone z, double xid, double gam1, double gam2, double cfl,
                                                        const double *__restrict__ rop,
                                                        const double *__restrict__ xmut, double *__restrict__ coe)
 {
@@ -41,15 +43,15 @@ __global__ void __launch_bounds__(256) k_coe_implicit(FsZone z, double xid, doub
   const long long nd = z.nd;
   const long long l = si + (long long)sj * z.incj + (long long)sk * z.inck;
   const long long lt = FULL ? si + (long long)sj * z.mincj + (long long)sk * z.minck : 0;
-  const double cut0x = 1e-20;
-  const double coe1 = FULL ? z.dt / z.vol[lt] : z.coe;
+  const double cut0x = DTLOC ? 1e-30 : 1e-20;
+  double coe1 = FULL ? z.dt / z.vol[lt] : z.coe;
   const double r = rop[l], u = rop[l + nd], v = rop[l + 2 * nd], w = rop[l + 3 * nd];
   const double c = sqrt(gam2 * rop[l + 4 * nd]);
   const double detj = fs_max(FULL ? z.vol[lt] : z.vol0, cut0x);
   const double vmu = gam1 * xmut[l];
   const double volu = detj * r;
   const double xmvis = vmu / volu;
-  double cs[3];
+  double cs[3], t2[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     double qn, tc2;
@@ -69,6 +71,15 @@ __global__ void __launch_bounds__(256) k_coe_implicit(FsZone z, double xid, doub
     const double cn = c * tc2;
     const double vm = fabs(qn) + cn;
     cs[d] = vm * 2. + xmvis * tc2 * tc2 * 4.;
+    t2[d] = tc2;
+  }
+  if (DTLOC) {
+    const double gam1_1 = 1. / gam1;
+    const double dd = 1. / (t2[0] * t2[0] + t2[1] * t2[1] + t2[2] * t2[2]);
+    const double dtvis = 0.5 * detj * dd * gam1_1 / xmut[l] * r;
+    const double sp = sqrt(u * u + v * v + w * w) + c;
+    const double dtconv = sqrt(dd) / sp;
+    coe1 = cfl * fs_min(dtconv, dtvis);
   }
   coe[l] = coe1;
   coe[l + nd] = cs[0]; coe[l + 2 * nd] = cs[1]; coe[l + 3 * nd] = cs[2];
@@ -550,17 +561,19 @@ __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const d
 
 }  // namespace
 
-void fsk_coe_implicit(const FsZone &z, int first_it, double gamma, double prandtl, double rgp, const double *rop,
-                      const double *xmut, double *coe, hipStream_t s)
+void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, double gamma, double prandtl, double rgp,
+                      const double *rop, const double *xmut, double *coe, hipStream_t s)
 {
   double xid = 1.5;
-  if (first_it == 0) xid = 1.;
+  if (first_it == 0 || dtloc) xid = 1.;
   double gam1 = gamma / prandtl;
-  if (z.iflow == 1) gam1 = 0.;
+  if (z.iflow == 1) gam1 = dtloc ? 1e-30 : 0.;
   const double gam2 = gamma * rgp;
   dim3 g((z.ni + 255) / 256, z.nj, z.nk);
-  if (z.ityp == 0) hipLaunchKernelGGL((k_coe_implicit<true>), g, dim3(256), 0, s, z, xid, gam1, gam2, rop, xmut, coe);
-  else hipLaunchKernelGGL((k_coe_implicit<false>), g, dim3(256), 0, s, z, xid, gam1, gam2, rop, xmut, coe);
+#define FS_GO(F, D) hipLaunchKernelGGL((k_coe_implicit<F, D>), g, dim3(256), 0, s, z, xid, gam1, gam2, cfl, rop, xmut, coe)
+  if (z.ityp == 0) { if (dtloc) FS_GO(true, true); else FS_GO(true, false); }
+  else { if (dtloc) FS_GO(false, true); else FS_GO(false, false); }
+#undef FS_GO
 }
 
 // LU-SGS on the interior of the zone + Newton update.  rop = current iterate; the new iterate is

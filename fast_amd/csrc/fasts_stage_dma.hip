@@ -320,7 +320,8 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
 #pragma unroll
           for (int e = 0; e < 5; e++) qn[e] = ldg(P(bdf.ro_n, e, k - 1), ob);
         }
-        fs_bdf_residual(z, bdf, z.coe, qb, qn, qn1, d, r);
+        const double coe1 = bdf.coe1 ? ldg(P(bdf.coe1, 0, k - 1), ob) : z.coe;
+        fs_bdf_residual(z, bdf, coe1, qb, qn, qn1, d, r);
 #pragma unroll
         for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, r[e]);
       } else {
@@ -404,7 +405,7 @@ void launch(const FsZone &z, double coefH, double coefW, int first, const double
   // 16-byte DMA needs pairs of cells that are 16-byte aligned in every row and plane
   const bool wide = z.ni % 2 == 0 && z.nd % 2 == 0 && z.ific % 2 == 0 && ((uintptr_t)rop % 16 == 0) &&
                     (xmut == nullptr || (uintptr_t)xmut % 16 == 0);
-  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0};
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
 #define FS_LAUNCH(FIRST_, WIDE_, BDF_)                                                                       \
   hipLaunchKernelGGL((k_stage_dma<KFLU, IFLOW, FIRST_, WIDE_, BDF_>), dim3(nblk), dim3(NTHREADS), 0, s, z, coefH, coefW, \

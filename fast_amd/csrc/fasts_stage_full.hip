@@ -116,7 +116,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
 #pragma unroll
             for (int e = 0; e < 5; e++) qn[e] = bdf.ro_n[e * nd + lb];
           }
-          fs_bdf_residual(z, bdf, coe, qb, qn, qn1, d, o);
+          fs_bdf_residual(z, bdf, bdf.coe1 ? bdf.coe1[lb] : coe, qb, qn, qn1, d, o);
 #pragma unroll
           for (int e = 0; e < 5; e++) drodm[e * nd + lb] = o[e];
         } else {
@@ -180,7 +180,7 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
   }
   if (kchunk > z.kv) kchunk = z.kv;
   dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
-  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0};
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
 #define FS_GO(K, F, FIRST_, BDF_)                                                                             \
   hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, \

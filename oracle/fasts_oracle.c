@@ -1087,18 +1087,22 @@ void fo_residual(const i32 *p, const double *drodm, const double *coe, double *s
 /* dt/vol and the LU coefficients: coe(:,1) = dt/vol (Fast/FastS/FastS/Compute/tstb3_global.for:64-78),
  * coe(:,2..4) = spectral radii of the i, j, k directions (convective + viscous), coe(:,5) = diagonal
  * xid + coe1*(coe2+coe3+coe4)/2 (tstb3c.for:62-76,86-176,262-311).  Range = the whole zone,
- * ghost cells included (ind_coe of indice_boucle_ssdom.for:108-112 with one cache block). */
+ * ghost cells included (ind_coe of indice_boucle_ssdom.for:108-112 with one cache block).
+ * Local time step (DTLOC = 1, time_step_nature='local'): coe(:,1) = CFL * min(convective, viscous) limit of
+ * the cell, xid = 1 (tstb3_impli.for:57-71,86-176, dtloc.for). */
 void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *ind, const double *rop,
                        const double *xmut, double *coe, const double *ti, const double *tj, const double *tk,
                        const double *vol)
 {
   GEOM(p)
-  const double cut0x = 1e-20;
+  const int dtloc = p[DTLOC] == 1;
+  const double cut0x = dtloc ? 1e-30 : 1e-20;
   const double gamma = pr[GAMMA], rgp = pr[CVINF] * (gamma - 1.), prandt = pr[PRANDT];
   double xid = 1.5;
-  if (first_it == 0) xid = 1.;
+  if (first_it == 0 || dtloc) xid = 1.;
   double gam1 = gamma / prandt;
-  if (p[IFLOW] == 1) gam1 = 0.;
+  if (p[IFLOW] == 1) gam1 = dtloc ? cut0x : 0.;
+  const double gam1_1 = 1. / gam1;
   const double gam2 = gamma * rgp;
   const long ndm = p[NDIMDX_MTR];
   const long minc[3] = {p[NIJK_MTR], p[NIJK_MTR + 1], p[NIJK_MTR + 2]};
@@ -1117,6 +1121,7 @@ void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *
         const double u = rop[l + nd], v = rop[l + 2 * nd], w = rop[l + 3 * nd];
         const double c = sqrt(gam2 * rop[l + 4 * nd]);
         const double vmu = gam1 * xmut[l], volu = detj * r, xmvis = vmu / volu;
+        double tc2s[3];
         for (int d = 0; d < 3; d++) {
           double qn, tc2;
           if (full) {
@@ -1133,6 +1138,14 @@ void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *
           }
           const double cn = c * tc2, vm = fabs(qn) + cn;
           coe[l + (1 + d) * nd] = vm * 2. + xmvis * tc2 * tc2 * 4.;
+          tc2s[d] = tc2;
+        }
+        if (dtloc) {   /* dtloc.for */
+          const double dd = 1. / (tc2s[0] * tc2s[0] + tc2s[1] * tc2s[1] + tc2s[2] * tc2s[2]);
+          const double dtvis = 0.5 * detj * dd * gam1_1 / xmut[l] * r;
+          const double sp = sqrt(u * u + v * v + w * w) + c;
+          const double dtconv = sqrt(dd) / sp;
+          coe[l] = pr[15] * dmin(dtconv, dtvis);
         }
         coe[l + 4 * nd] = xid + coe[l] * (coe[l + nd] + coe[l + 2 * nd] + coe[l + 3 * nd]) * 0.5;
       }
@@ -1433,7 +1446,7 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   const int f = p[NIJK + 3], fk = p[NIJK + 4];
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
   const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
-  if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[DTLOC] != 0 || p[NEQ] != 5) return -1;
+  if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[NEQ] != 5) return -1;
   const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);

@@ -64,6 +64,30 @@ def test_implicit_bit_exact_vs_oracle(n, scheme, model, perturb, bcs, ssit, nit,
     assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4
 
 
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs", [
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', 0., None),
+    ((36, 9, 10), 'senseur', 'Euler', 0., None),
+    ((10, 9, 8), 'roe', 'NSLaminar', 0.15, None),
+    ((10, 9, 8), 'ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCWall'}),
+])
+def test_implicit_local_time_step(n, scheme, model, perturb, bcs):
+    """time_step_nature='local': per-cell dt from the CFL number, BDF1 at every step."""
+    extra = dict(SINGLE, time_step_nature='local', cfl=4.)
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[46]) == 1
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()
+    for it in range(1, 5):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+
+
 @pytest.mark.parametrize("blocks,nn,scheme,perturb", [
     ((2, 1, 2), (16, 9, 12), 'senseur', 0.),
     ((1, 2, 1), (10, 16, 8), 'ausmpred', 0.15),

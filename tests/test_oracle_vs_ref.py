@@ -133,6 +133,31 @@ def test_implicit_lusgs_bit_exact(scheme, model, perturb, bcs, blocks):
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
 
 
+@pytest.mark.parametrize("scheme,model,perturb,bcs", [
+    ('ausmpred', 'NSLaminar', 0., None),
+    ('senseur', 'Euler', 0., None),
+    ('roe', 'NSLaminar', 0.15, None),
+    ('ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCWall'}),
+])
+def test_implicit_local_time_step_bit_exact(scheme, model, perturb, bcs):
+    """time_step_nature='local': dt of every cell = CFL * min(convective, viscous limit) (tstb3_impli.for,
+    dtloc.for), BDF1 weights and unit diagonal shift at every step (core3as2.for:37-41)."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000,
+             'time_step_nature': 'local', 'cfl': 4.}
+    t = cases.tgv((10, 8, 7), scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb)
+    so, sr = _pair(t)
+    assert int(so.zones[0].pint[46]) == 1
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
+
+
 def test_roe_with_walls_is_refused_by_the_oracle():
     """The reference corrects the roe flux on wall faces (BC/bfl3.for); that correction is not
     restated, so the combination is refused rather than computed without it."""
