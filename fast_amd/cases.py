@@ -58,6 +58,27 @@ def tgv_fields(t, state, L0=1.):
     C._initVars(t, 'centers:Temperature', T0)
 
 
+def sa_fields(t, state, walls=(), L=2. * math.pi):
+    """Spalart-Allmaras inputs of a box test: a smooth positive nu_tilde of a few laminar viscosities and
+    the wall distance (distance to the nearest of the faces in `walls`, or a smooth positive field when the
+    box has no wall: only the value matters to the source term)."""
+    nu = state[15] / state[0]          # laminar kinematic viscosity of the reference state (Mus / rho)
+    C._initVars(t, 'centers:TurbulentSANuTilde',
+                lambda x, y, z: 3. * nu * (1.5 + numpy.sin(x) * numpy.cos(y) + 0.3 * numpy.cos(2. * z)))
+    h = 0.5 * L
+
+    def dist(x, y, z):
+        d = None
+        for f in walls:
+            c = {'i': x, 'j': y, 'k': z}[f[0]]
+            df = (c + h) if f.endswith('min') else (h - c)
+            d = df if d is None else numpy.minimum(d, df)
+        if d is None:
+            d = 1. + 0.3 * numpy.sin(x) * numpy.sin(y)
+        return numpy.abs(d) + 0. * x
+    C._initVars(t, 'centers:TurbulentDistance', dist)
+
+
 def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
         temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None, bcs=None,
         perturb=0., extra_numb=None):
@@ -99,6 +120,8 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
     C.addState(t, adim='adim2funk', MInf=0.1, ReInf=1600.)
     state = C.getState(Internal.getNodeFromName(t, 'ReferenceState'))
     tgv_fields(t, state)
+    if model in ('NSTurbulent', 'nsspalart'):
+        sa_fields(t, state, [f for f, b in (bcs or {}).items() if b.startswith('BCWall')], L1)
     if time_step is None:
         time_step = 0.003 * 32. / n          # tgvMpi.py:271 scaled with the mesh size
     numb = {'temporal_scheme': temporal_scheme, 'modulo_verif': modulo_verif}

@@ -97,7 +97,7 @@ void fo_init_rhs(const i32 *p, int nitcfg, const i32 *ind, double *drodm)
     for (int j = ind[2]; j <= ind[3]; j++)
       for (int i = ind[0]; i <= ind[1]; i++) {
         long l = INDDM(i, j, k);
-        for (int e = 0; e < 5; e++) drodm[l + e * nd] = zero ? 0. : drodm[l + e * nd] * coefH;
+        for (int e = 0; e < p[NEQ]; e++) drodm[l + e * nd] = zero ? 0. : drodm[l + e * nd] * coefH;
       }
 }
 
@@ -157,6 +157,8 @@ typedef struct {
   int kflu, iflow;
   double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
   double tcx, tcy, tcz, si, sj, sk, volinv;
+  /* Spalart-Allmaras (iflow 3): turbulent conductivity factor, Sutherland constants of mulam.for, 1/sigma */
+  double gam4, cmus1, temp01, coesut_sa, sigma_1;
   long nd, inc[3];
   /* curvilinear zones (zone type 0): metric arrays ti,tj,tk(NDIMDX_MTR,3), vol(NDIMDX_MTR) */
   int ityp;
@@ -193,7 +195,7 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
     qp[e] = c->c4 * q[nm] + c->c6 * q[nm2] + c->c5 * q[l];
   }
   const int vn = 1 + dir; /* normal velocity component */
-  double flu1, flu2, flu3, flu4, flu5;
+  double flu1, flu2, flu3, flu4, flu5, flu6 = 0., u_sa = 0., tdu_sa = 0.;
   if (c->kflu == 5) {
     const double gam = c->gam, rgp = c->rgp, gam1 = c->gam1, psiroe = c->psiroe;
     double r1 = qp[0], p1 = r1 * qp[4] * rgp;
@@ -293,9 +295,17 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
     if (dir == 2) flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tc * p1p2;
     else flu4 = u * (row1 + row2) - tdu * (row2 - row1);
     flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+    u_sa = u; tdu_sa = tdu;
+  }
+  if (c->iflow == 3) {   /* convective flux of rho*nu_tilde: AUSM/fluFaceSA.for, SENSOR/fluFaceSA.for */
+    const double *q6 = rop + 5 * nd;
+    const double qm_ = c->c4 * q6[l] + c->c5 * q6[nm] + c->c6 * q6[np];
+    const double qp_ = c->c4 * q6[nm] + c->c6 * q6[nm2] + c->c5 * q6[l];
+    const double qm6 = qm_ * qm[0], qp6 = qp_ * qp[0];
+    flu6 = u_sa * (qm6 + qp6) - tdu_sa * (qm6 - qp6);
   }
 
-  if (c->iflow == 2) {
+  if (c->iflow >= 2) {
     const long inci = c->inc[0], incj = c->inc[1], inck = c->inc[2];
     const double *U = rop + nd, *V = rop + 2 * nd, *W = rop + 3 * nd, *T = rop + 4 * nd;
     const double tcx = c->tcx, tcy = c->tcy, tcz = c->tcz;
@@ -303,6 +313,15 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
     double f1, f2, f3, f4, f5, f6, fv, fv5, div;
     double xmutvol = (xmut[ir] + xmut[il]) * c->volinv;
     double xktvol = xmutvol * c->gam3;
+    double xmulam = 0.;
+    if (c->iflow == 3) {   /* mut_prandtltb_interface.for: laminar and turbulent parts of the conductivity */
+      xmulam = c->coesut_sa * sqrt(T[il] * c->temp01) / (1. + c->cmus1 / T[il]);
+      xmulam = xmulam + c->coesut_sa * sqrt(T[ir] * c->temp01) / (1. + c->cmus1 / T[ir]);
+      const double xmutot = xmut[ir] + xmut[il];
+      const double xmutur = xmutot - xmulam;
+      xktvol = (xmulam * c->gam3 + xmutur * c->gam4) * c->volinv;
+      xmutvol = xmutot * c->volinv;
+    }
     if (dir == 0) {
       const long l220 = l - inci - incj, l020 = l - incj, l210 = l - inci + incj, l010 = l + incj;
       const long l202 = l - inci - inck, l002 = l - inck, l201 = l - inci + inck, l001 = l + inck;
@@ -370,8 +389,17 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
       fv = -2. * f6 * tcz * xmutvol; fv5 = fv5 + fv * (W[ir] + W[il]); flu4 = flu4 + fv;
       fv = fv5 * 0.5 - gradT_nz * tcz * xktvol; flu5 = flu5 + fv;
     }
+    if (c->iflow == 3) {   /* SA/fluvisq_SA_3dcart_{i,j,k}.for, SA/mut_interface.for */
+      const double *R = rop, *N = rop + 5 * nd;
+      const double g = (N[ir] - N[il]) * tc;
+      double xm = xmulam + N[il] * R[il] + N[ir] * R[ir];
+      xm = xm * c->volinv * c->sigma_1;
+      if (dir == 1) flu6 = flu6 - xm * (g * tc);
+      else flu6 = flu6 - xm * g * tc;
+    }
   }
   flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
+  if (c->iflow == 3) flu[5] = flu6;
 }
 
 /* Same face flux on a curvilinear zone (zone type 0): lt = metric index of cell l.
@@ -549,6 +577,10 @@ static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const doubl
   c->rgp = pr[CVINF] * (gam - 1.);
   c->gam1 = gam / (gam - 1.);
   c->gam3 = c->gam1 / pr[PRANDT] * c->rgp;
+  c->gam4 = c->gam1 / pr[38] * c->rgp;                 /* PRANDT_TUR */
+  c->cmus1 = pr[CS]; c->temp01 = 1. / pr[TEMP0];
+  c->coesut_sa = pr[XMUL0] * (1. + c->cmus1 * c->temp01);
+  c->sigma_1 = 1. / (2. / 3.);
   double roref = pr[ROINF], uref = pr[VINF];
   c->psiroe = pr[PSIROE];
   c->c1 = 0.02 * uref;
@@ -572,7 +604,8 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
   GEOM(p)
   fluxctx c;
   fluxctx_init(&c, p, pr, ti, tj, tk, vol);
-  double f[5];
+  double f[6];
+  const int neq = p[NEQ];
 #define FACE(l, i, j, k, dir)                                                                     \
   do {                                                                                            \
     if (c.ityp == 0) face_flux_full(&c, rop, wig, xmut, (l), INDMTR(p, i, j, k), (dir), f);       \
@@ -584,7 +617,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
         for (int i = ind[0]; i <= ind[1]; i++) {
           long l = INDDM(i, j, k), l0 = l - c.inc[dir];
           FACE(l, i, j, k, dir);
-          for (int e = 0; e < 5; e++) {
+          for (int e = 0; e < neq; e++) {
             drodm[l + e * nd] = drodm[l + e * nd] + f[e];
             drodm[l0 + e * nd] = drodm[l0 + e * nd] - f[e];
           }
@@ -592,7 +625,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
       {
         long l = INDDM(ind[1] + 1, j, k), ls = l - 1;
         FACE(l, ind[1] + 1, j, k, 0);
-        for (int e = 0; e < 5; e++) {
+        for (int e = 0; e < neq; e++) {
           drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
           drodm[l + e * nd] = drodm[l + e * nd] + f[e];
         }
@@ -601,7 +634,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
     for (int i = ind[0]; i <= ind[1]; i++) {
       long l = INDDM(i, ind[3] + 1, k), ls = l - c.inc[1];
       FACE(l, i, ind[3] + 1, k, 1);
-      for (int e = 0; e < 5; e++) {
+      for (int e = 0; e < neq; e++) {
         drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
         drodm[l + e * nd] = drodm[l + e * nd] + f[e];
       }
@@ -611,7 +644,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
     for (int i = ind[0]; i <= ind[1]; i++) {
       long l = INDDM(i, j, ind[5] + 1), ls = l - c.inc[2];
       FACE(l, i, j, ind[5] + 1, 2);
-      for (int e = 0; e < 5; e++) {
+      for (int e = 0; e < neq; e++) {
         drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
         drodm[l + e * nd] = drodm[l + e * nd] + f[e];
       }
@@ -648,6 +681,118 @@ void fo_core3ark3(const i32 *p, const double *pr, int nitcfg, const i32 *ind, do
         rop_1[l + nd] = un; rop_1[l + 2 * nd] = vn; rop_1[l + 3 * nd] = wn;
         double roe_old = ro_old * (cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
         rop_1[l + 4 * nd] = (roe_old + tab5) * r_1 * cvinv - cvinv2 * (un * un + vn * vn + wn * wn);
+        if (p[NEQ] == 6) {   /* core3ark3.for:196-236: nu_tilde clipped to [0, ratiom * nu_laminar] */
+          const double cmus1 = pr[CS], temp01 = 1. / pr[TEMP0], coesut = pr[XMUL0] * (1. + cmus1 * temp01);
+          const double tab6 = drodm[l + 5 * nd] * (coefW * coe[l]);
+          const double nu_old = rop[l + 5 * nd];
+          double anulam = coesut * sqrt(rop_1[l + 4 * nd] * temp01) / (1. + cmus1 / rop_1[l + 4 * nd]);
+          anulam = anulam * r_1 * pr[18];
+          double t6 = (ro_old * nu_old + tab6) * r_1;
+          t6 = dmin(t6, anulam);
+          rop_1[l + 5 * nd] = dmax(t6, 0.);
+        }
+      }
+}
+
+/* Spalart-Allmaras total viscosity mu + mu_t, limited to (1 + ratiom) mu
+ * (Fast/FastS/FastS/Compute/SA/vispalart.for, mulam.for, SA/chi.for, SA/xmut.for) */
+void fo_vispalart(const i32 *p, const double *pr, const i32 *ind, const double *rop, double *xmut)
+{
+  GEOM(p)
+  const double cmus1 = pr[CS], temp01 = 1. / pr[TEMP0], coesut = pr[XMUL0] * (1. + cmus1 * temp01);
+  const double SA_CV1 = 357.911;
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k);
+        const double T = rop[l + 4 * nd];
+        const double amulam = coesut * sqrt(T * temp01) / (1. + cmus1 / T);
+        const double anulam = rop[l] / amulam;
+        const double anutild = dmax(rop[l + 5 * nd], 1.e-27);
+        const double chi = dmax(anutild * anulam, 1.e-7);
+        const double fvv1 = 1. / (1. + SA_CV1 / (chi * chi * chi));
+        const double amut = rop[l] * anutild * fvv1;
+        const double xmuprov = dmax(amut, 0.);
+        xmut[l] = amulam + dmin(xmuprov, pr[18] * amulam);
+      }
+}
+
+/* Source term of the nu_tilde equation on a Cartesian zone: production - destruction + the
+ * cb2 gradient term, multiplied by the cell volume (Fast/FastS/FastS/Compute/SA/spsource_SA.for:185-232,
+ * SA/sourceSA_grad_3dcart.for, SA/sourceSA_prod_dest.for; SA_LOW_RE = SA_ROT_CORR = 0 are the switches
+ * read from Parameter_int).  With the implicit scheme, at the first sub-iteration, the diagonal of the
+ * 6th equation is stored in coe(:,6) (SA/sourceSA_LU.for). */
+void fo_spsource_SA(const i32 *p, const double *pr, int nitcfg, const i32 *ind, const double *rop, double *coe,
+                    const double *ti, const double *tj, const double *tk, const double *vol, const double *dlng,
+                    double *drodm)
+{
+  GEOM(p)
+  const double SA_CKARM = 0.41, SA_CB1 = 0.1355, SA_CB2 = 0.622, SA_CV1 = 357.911, SA_CW2 = 0.3, SA_CW3 = 64.;
+  const double SA_CW4 = 0.21, SA_CW5 = 1.5, SA_CROT = 2.0, SA_SIGMA = (2. / 3.);
+  const double sw_lre = (double)p[130], sw_rot = (double)p[131];
+  const double cmus1 = pr[CS], temp01 = 1. / pr[TEMP0], coesut = pr[XMUL0] * (1. + cmus1 * temp01);
+  const double c1 = SA_CB2 / SA_SIGMA;
+  const double cw1 = (SA_CB1 / SA_CKARM / SA_CKARM) + (1. + SA_CB2) / SA_SIGMA;
+  const long incj = ni, inck = ninj;
+  const double tix = ti[0], tjy = tj[0], tkz = tk[0];
+  const double xvol = 0.5 / vol[0];
+  const int store = p[ITYPCP] <= 1 && nitcfg <= 1;
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k);
+        const long l1 = l + 1, l2 = l - 1, l3 = l + incj, l4 = l - incj, l5 = l + inck, l6 = l - inck;
+        double g[3][3];   /* g[v][d]: d(u,v,w)/d(x,y,z) times 2*vol */
+        for (int v = 0; v < 3; v++) {
+          const double *q = rop + (1 + v) * nd;
+          const double u1 = (q[l] + q[l2]), u2 = (q[l] + q[l3]), u3 = (q[l] + q[l1]);
+          const double u4 = (q[l] + q[l4]), u5 = (q[l] + q[l5]), u6 = (q[l] + q[l6]);
+          g[v][0] = (u3 - u1) * tix; g[v][1] = (u2 - u4) * tjy; g[v][2] = (u5 - u6) * tkz;
+        }
+        const double rotx = g[2][1] - g[1][2], roty = g[0][2] - g[2][0], rotz = g[1][0] - g[0][1];
+        const double rot = sqrt(rotx * rotx + roty * roty + rotz * rotz) * xvol;
+        const double S11 = g[0][0], S22 = g[1][1], S33 = g[2][2];
+        const double S12 = 0.5 * (g[0][1] + g[1][0]), S13 = 0.5 * (g[0][2] + g[2][0]), S23 = 0.5 * (g[1][2] + g[2][1]);
+        double St = S11 * S11 + S22 * S22 + S33 * S33 + 2 * (S12 * S12) + 2 * (S13 * S13) + 2 * (S23 * S23);
+        St = sqrt(2 * St) * xvol;
+        const double *N = rop + 5 * nd, *R = rop;
+        double u1 = (N[l] + N[l2]), u2 = (N[l] + N[l3]), u3 = (N[l] + N[l1]);
+        double u4 = (N[l] + N[l4]), u5 = (N[l] + N[l5]), u6 = (N[l] + N[l6]);
+        double dudx = (u3 - u1) * tix, dudy = (u2 - u4) * tjy, dudz = (u5 - u6) * tkz;
+        u1 = N[l] * R[l] + N[l2] * R[l2]; u2 = N[l] * R[l] + N[l3] * R[l3]; u3 = N[l] * R[l] + N[l1] * R[l1];
+        u4 = N[l] * R[l] + N[l4] * R[l4]; u5 = N[l] * R[l] + N[l5] * R[l5]; u6 = N[l] * R[l] + N[l6] * R[l6];
+        dudx = dudx * (u3 - u1) * tix; dudy = dudy * (u2 - u4) * tjy; dudz = dudz * (u5 - u6) * tkz;
+        const double anvisc = c1 * (dudx + dudy + dudz) * xvol * xvol;
+        const double T = rop[l + 4 * nd];
+        const double amulam = coesut * sqrt(T * temp01) / (1. + cmus1 / T);
+        const double anulam = rop[l] / amulam;
+        const double anutild = dmax(N[l], 1.e-27);
+        const double chi = dmax(anutild * anulam, 1.e-7);
+        const double f1 = 1. / (1. + SA_CV1 / (chi * chi * chi));
+        const double f2 = 1. - chi / (1. + chi * f1);
+        const double dist = dmax(dlng[l], 1.e-27);
+        double stild = rot + (anutild * f2) / (SA_CKARM * SA_CKARM * dist * dist);
+        stild = stild + sw_rot * SA_CROT * dmin(0.00000000000000000001, St - rot);
+        const double prod = rop[l] * SA_CB1 * stild * anutild;
+        stild = dmax(stild, 0.00000000000000000001);
+        double r = anutild / (stild * SA_CKARM * SA_CKARM * dist * dist);
+        r = dmin(r, 10.);
+        const double r5 = r * r * r * r * r - 1.;
+        double gg = r * (1. + SA_CW2 * r5);
+        const double cw2_lre = SA_CW4 + SA_CW5 / ((1. + chi / 40.) * (1. + chi / 40.));
+        gg = sw_lre * r * (1. + cw2_lre * r5) + (1. - sw_lre) * gg;
+        const double g6 = gg * gg * gg * gg * gg * gg;   /* s**6 */
+        const double fwg = gg * pow((1. + SA_CW3) / (g6 + SA_CW3), 1. / 6.);
+        const double destruc = rop[l] * cw1 * fwg * (anutild / dist) * (anutild / dist);
+        const double tsource = (prod + anvisc - destruc);
+        if (store) {
+          const double tsourceb = prod - destruc;
+          double amutild = anutild * rop[l];
+          amutild = dmax(amutild, 0.0000000000000001);
+          const double tsourcenu = vol[0] * tsourceb / amutild;
+          coe[l + 5 * nd] = coe[l + 4 * nd] - dmin(tsourcenu, 0.) * coe[l];
+        }
+        drodm[l + 5 * nd] = drodm[l + 5 * nd] + vol[0] * tsource;
       }
 }
 
@@ -692,7 +837,7 @@ void fo_bc_periodic(const i32 *p, int idir, const i32 *cl, double *rop)
     for (int j = cl[2]; j <= cl[3]; j++)
       for (int i = cl[0]; i <= cl[1]; i++) {
         long l = INDDM(i, j, k);
-        for (int e = 0; e < 5; e++) rop[l + e * nd] = rop[l + incp + e * nd];
+        for (int e = 0; e < p[NEQ]; e++) rop[l + e * nd] = rop[l + incp + e * nd];
       }
 }
 
@@ -731,7 +876,7 @@ void fo_bc_extrapolate(const i32 *p, int idir, const i32 *cl, double *rop)
         int q[3] = {i, j, k};
         q[f.d] = f.first;
         long l = INDDM(i, j, k), l1 = INDDM(q[0], q[1], q[2]);
-        for (int e = 0; e < 5; e++) rop[l + e * nd] = dmax(vmax, rop[l1 + e * nd]) * c1;
+        for (int e = 0; e < p[NEQ]; e++) rop[l + e * nd] = dmax(vmax, rop[l1 + e * nd]) * c1;
       }
 }
 
@@ -754,6 +899,7 @@ void fo_bc_wall_viscous(const i32 *p, int idir, const i32 *cl, double *rop)
         rop[l + 2 * nd] = 0. - rop[lm + 2 * nd];
         rop[l + 3 * nd] = 0. - rop[lm + 3 * nd];
         rop[l + 4 * nd] = rop[lm + 4 * nd];
+        if (p[NEQ] == 6) rop[l + 5 * nd] = -rop[lm + 5 * nd];   /* BCWallViscous_SA.for */
       }
 }
 
@@ -810,6 +956,7 @@ void fo_bc_wall_inviscid(const i32 *p, int idir, const i32 *cl, double *rop, con
         rop[l + 2 * nd] = 0. + va;
         rop[l + 3 * nd] = 0. + wa;
         rop[l + 4 * nd] = rop[lm + 4 * nd];
+        if (p[NEQ] == 6) rop[l + 5 * nd] = rop[lm + 5 * nd];    /* BCWallInviscidSA_i.for */
       }
 }
 
@@ -896,15 +1043,20 @@ void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, dou
           u = u + r * svar2 * roinv; v = v + r * svar3 * roinv; w = w + r * svar4 * roinv;
           rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
           rop[l + 4 * nd] = (qvar5 * roinv - .5 * (u * u + v * v + w * w)) * cvinv;
+          if (p[NEQ] == 6)   /* BCFarfield_firstrank_SA.for, BCFarfield_init.for: nue = state(6)/state(1) */
+            rop[l + 5 * nd] = eigv1 < 0. ? pr[8] / roe : rop[l1 + 5 * nd];
         }
         for (int r = 2; r <= f.nr; r++) {   /* next ranks, outwards */
           l = l1 - r * inc;
           const long l0 = l + inc, l1b = l + 2 * inc, l2 = l + 3 * inc;
+          const int neq = p[NEQ];
           rop[l] = rop[l0] * c3 + rop[l1b] * c1 + rop[l2] * c2;
-          if (fabs(rop[l] / rop[l0] - 1.) >= 0.7) {
-            for (int e = 0; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd];
+          /* positivity guard: BC_nextrank.for (5 equations), BC_nextrankSA.for (6) */
+          const int guard = neq == 6 ? rop[l] <= 0.3 * rop[l0] : fabs(rop[l] / rop[l0] - 1.) >= 0.7;
+          if (guard) {
+            for (int e = 0; e < neq; e++) rop[l + e * nd] = rop[l0 + e * nd];
           } else {
-            for (int e = 1; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd] * c3 + rop[l1b + e * nd] * c1 + rop[l2 + e * nd] * c2;
+            for (int e = 1; e < neq; e++) rop[l + e * nd] = rop[l0 + e * nd] * c3 + rop[l1b + e * nd] * c1 + rop[l2 + e * nd] * c2;
           }
         }
       }
@@ -1023,6 +1175,11 @@ void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in
   const i32 grad[6] = {0, iv + 1, 0, jv + 1, 0, kv + 1};
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, grad, rop_in, xmut);
+    if (p[IFLOW] == 3) {   /* navier_stokes_struct.for:237-245: total viscosity on the whole zone */
+      const int f = p[NIJK + 3], fk = p[NIJK + 4];
+      const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
+      fo_vispalart(p, pr, all, rop_in, xmut);
+    }
     double volinv = pr[DTC] / vol[0]; /* Fast/FastS/FastS/Compute/tstb3_global.for:64-78 */
     GEOM(p)
     for (int k = 1; k <= kv; k++)
@@ -1031,6 +1188,8 @@ void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in
           coe[INDDM(i, j, k)] = p[ITYPZONE] != 2 ? pr[DTC] / vol[INDMTR(p, i, j, k)] : volinv;
   }
   fo_init_rhs(p, nitcfg, sdm, drodm);
+  if (p[IFLOW] == 3)   /* src_term.for:87-96: dist = second slot of the viscosity array */
+    fo_spsource_SA(p, pr, nitcfg, sdm, rop_in, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_in, wig);
   fo_flux(p, pr, sdm, rop_in, drodm, wig, xmut, ti, tj, tk, vol);
   fo_core3ark3(p, pr, nitcfg, sdm, rop_out, rop_in, drodm, coe);
@@ -1050,7 +1209,7 @@ int fo_step(const i32 *p, const double *pr, double *ro, double *ro_p1, double *d
     double *in = (nstep % 2 == 1) ? ro : ro_p1;
     double *out = (nstep % 2 == 1) ? ro_p1 : ro;
     fo_subiter(p, pr, nstep, in, out, drodm, coe, xmut, wig, ti, tj, tk, vol);
-    if (nstep == 1 && stage1_rhs) memcpy(stage1_rhs, drodm, sizeof(double) * 5 * (size_t)p[NDIMDX]);
+    if (nstep == 1 && stage1_rhs) memcpy(stage1_rhs, drodm, sizeof(double) * p[NEQ] * (size_t)p[NDIMDX]);
     if (fo_bczone(p, pr, out, ti, tj, tk)) return -1;
   }
   return 0;

@@ -41,7 +41,7 @@ def _p(a):
 class OracleZone:
     """One stand-alone zone (all boundaries local) advanced by the C restatement."""
 
-    def __init__(self, param_int, param_real, ro, mtr):
+    def __init__(self, param_int, param_real, ro, mtr, dist=None):
         self.pint = np.ascontiguousarray(param_int, dtype=np.int32).copy()
         self.preal = np.ascontiguousarray(param_real, dtype=np.float64).copy()
         p = self.pint
@@ -57,7 +57,11 @@ class OracleZone:
         self.implicit = int(p[ITYPCP]) == 1
         self.first_it = 0          # FIRST_IT of the reference: 0 until one time step is done (BDF1)
         self.drodm = np.zeros(n); self.coe = np.zeros(self.ndimdx * max(1, int(p[NEQ_COE])))
-        self.xmut = np.zeros(self.ndimdx); self.wig = np.zeros(3 * self.ndimdx)
+        # viscosity; the SA model keeps the wall distance in a second slot (src_term.for:93-96)
+        self.xmut = np.zeros(2 * self.ndimdx); self.wig = np.zeros(3 * self.ndimdx)
+        if dist is not None:
+            d = np.ascontiguousarray(np.asarray(dist).reshape(-1, order='F'), dtype=np.float64)
+            self.xmut[self.ndimdx:self.ndimdx + d.size] = d
         self.stage1_rhs = np.zeros(n)
 
     def fill_ghostcells(self):

@@ -62,7 +62,7 @@ DTC = 0; GAMMA = 1; ROINF = 3; PINF = 4; VXINF = 19; VYINF = 20; VZINF = 21; RON
 class RefZone:
     """Host arrays of one zone, laid out as the reference's pyTree + HOOK hold them."""
 
-    def __init__(self, param_int, param_real, x, y, z, ro, mtr):
+    def __init__(self, param_int, param_real, x, y, z, ro, mtr, dist=None):
         self.pint = np.ascontiguousarray(param_int, dtype=np.int32).copy()
         self.preal = np.ascontiguousarray(param_real, dtype=np.float64).copy()
         self.x = np.ascontiguousarray(x.reshape(-1, order='F'), dtype=np.float64)
@@ -84,6 +84,9 @@ class RefZone:
         self.drodm = np.zeros(n)
         self.coe = np.zeros(self.ndimdx * int(p[NEQ_COE]))
         self.xmut = np.zeros(self.ndimdx * 4)
+        if dist is not None:     # wall distance of the SA model: second slot of the viscosity array (src_term.for:93-96)
+            d = np.ascontiguousarray(dist.reshape(-1, order='F'), dtype=np.float64)
+            self.xmut[self.ndimdx:self.ndimdx + d.size] = d
         nwig = 3 * self.ndimdx * (2 if p[SLOPE] in (6, 7) and p[KFLUDOM] == 2 else 1)
         self.wig = np.zeros(nwig)
         self.cfl = np.zeros(3)

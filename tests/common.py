@@ -45,3 +45,10 @@ def rel_err(a, b, ndimdx, neq=5):
     s[1:4] = vs if vs > 0 else 1.
     s[s == 0] = 1.
     return d / s
+
+
+def wall_distance(z):
+    """TurbulentDistance of a zone (Fortran-ordered cell array) or None."""
+    sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+    n = Internal.getNodeFromName1(sol, 'TurbulentDistance') if sol is not None else None
+    return None if n is None else n[1]

@@ -6,7 +6,7 @@ import pytest
 from fast_amd import cases, connect, FastC, Internal
 from oracle import oracle as O
 from oracle import ref_harness as R
-from common import prepare, zone_arrays, make_case
+from common import prepare, zone_arrays, make_case, wall_distance
 
 pytestmark = [pytest.mark.ref,
               pytest.mark.skipif(not R.available(), reason="compiled reference not built")]
@@ -18,8 +18,8 @@ def _pair(t, blocks=None, nv=None):
     oz, rz = [], []
     for z, m in zip(zones, metrics):
         pint, preal, xyz = zone_arrays(z)
-        oz.append(O.OracleZone(pint, preal, FastC.level_buffer(z), m[0]))
-        rz.append(R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], FastC.level_buffer(z), m[0]))
+        oz.append(O.OracleZone(pint, preal, FastC.level_buffer(z), m[0], wall_distance(z)))
+        rz.append(R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], FastC.level_buffer(z), m[0], wall_distance(z)))
     joins = []
     if blocks is not None:
         joins = [(br, r, bd, d) for br, bd, r, d in connect.periodic_block_joins(blocks, nv)]
@@ -156,6 +156,33 @@ def test_implicit_local_time_step_bit_exact(scheme, model, perturb, bcs):
         so.step(); sr.step(it)
         assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
+
+
+@pytest.mark.parametrize("scheme,bcs,blocks", [
+    ('ausmpred', None, (1, 1, 1)),
+    ('senseur', None, (1, 1, 1)),
+    ('ausmpred', {'jmin': 'BCWall', 'jmax': 'BCWall'}, (1, 1, 1)),
+    ('senseur', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, (1, 1, 1)),
+    ('ausmpred', {'jmin': 'BCWall'}, (2, 1, 1)),
+])
+def test_spalart_allmaras_explicit_bit_exact(scheme, bcs, blocks):
+    """NSTurbulent on Cartesian zones: total viscosity (vispalart), source term (spsource_SA), convective and
+    diffusive flux of rho*nu_tilde, turbulent conductivity (mut_prandtltb_interface), clipped update
+    (core3ark3.for:196-236), 6-variable BCs."""
+    nn = (10, 8, 8)
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    t = cases.tgv(nn, scheme, model='NSTurbulent', extra_numz=extra, bcs=bcs, blocks=blocks)
+    nv = tuple(nn[d] // blocks[d] for d in range(3))
+    so, sr = _pair(t, blocks if blocks != (1, 1, 1) else None, nv)
+    assert so.zones[0].neq == 6
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        for a, b in zip(so.zones, sr.zones):
+            assert np.array_equal(a.ro, b.ro), "step %d" % it
+    d = np.abs(so.zones[0].ro - ro0).reshape(6, -1).max(axis=1)
+    assert np.isfinite(so.zones[0].ro).all() and d[5] > 1e-7 and d[1] > 1e-4
 
 
 def test_roe_with_walls_is_refused_by_the_oracle():
