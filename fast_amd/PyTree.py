@@ -98,6 +98,12 @@ def _new_context(zones, metrics, dtloc, device):
         preal = Internal.getNodeFromName1(o, 'Parameter_real')[1]
         ctx.zone_add(pint, preal, FastC.level_buffer(z, ''), FastC.level_buffer(z, '_M1'),
                      FastC.level_buffer(z, '_P1'), m[0])
+        if int(pint[27]) == 3:      # Spalart-Allmaras: wall distance (the reference compacts it behind ViscosityEddy)
+            sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+            dist = Internal.getNodeFromName1(sol, 'TurbulentDistance')
+            if dist is None:
+                raise ValueError("warmup: zone %s uses the Spalart-Allmaras model and has no TurbulentDistance field" % z[0])
+            ctx.zone_set_distance(nd, dist[1])
         names[z[0]] = nd
     return ctx, names
 

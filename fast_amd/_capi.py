@@ -14,7 +14,7 @@ FS_LEVEL_N, FS_LEVEL_M1, FS_LEVEL_P1 = 1, 2, 4
 
 SYMBOLS = [
     "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif", "fs_set_first_it",
-    "fs_zone_add", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
+    "fs_zone_add", "fs_zone_set_distance", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
@@ -96,6 +96,12 @@ class Context:
 
     def set_verif(self, modulo_verif):
         self._chk(lib().fs_set_verif(self._h, ctypes.c_int(int(modulo_verif))), "fs_set_verif")
+
+    def zone_set_distance(self, zone, dist):
+        d = numpy.ascontiguousarray(numpy.asarray(dist).reshape(-1, order='F'), dtype=numpy.float64)
+        self._keep.append(d)
+        self._chk(lib().fs_zone_set_distance(self._h, ctypes.c_int(int(zone)), _pd(d), ctypes.c_int(d.size)),
+                  "fs_zone_set_distance")
 
     def set_first_it(self, first_it):
         self._chk(lib().fs_set_first_it(self._h, ctypes.c_int(int(first_it))), "fs_set_first_it")

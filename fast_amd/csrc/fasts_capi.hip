@@ -15,9 +15,9 @@ namespace {
 // Parameter_int / Parameter_real slots (Fast/FastS/FastS/param_solver.h:77-306)
 enum { NIJK = 0, NIJK_MTR = 5, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
        NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
-       SLOPE = 64, PT_BC = 70, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
+       SLOPE = 64, PT_BC = 70, SA_LOW_RE = 130, SA_ROT_CORR = 131, SA_DIST = 132, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
 enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
-       CFL = 15, VXINF = 19, VYINF = 20, VZINF = 21,
+       RONUTILDEINF = 8, CFL = 15, SA_RATIOM_R = 18, PRANDT_TUR = 38, VXINF = 19, VYINF = 20, VZINF = 21,
        PSIROE = 34 };
 
 struct Zone {
@@ -30,6 +30,8 @@ struct Zone {
   double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]
   // implicit scheme: coe(nd,5) = dt/vol, spectral radii i/j/k, LU diagonal; one spare time level
   double *coe = nullptr, *scratch = nullptr;
+  double *dist = nullptr;      // SA model: wall distance of every cell (fs_zone_set_distance)
+  const double *dist_host = nullptr;
   // implicit scheme with wall BCs: windows applied to the Newton residual before the LU solve (whole-face
   // extrapolation first, then the BCs of the wall faces) and the LU range (one ghost layer over wall faces)
   std::vector<FsBcWin> rhs_face, rhs_bc;
@@ -143,7 +145,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
   }
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
@@ -164,6 +166,17 @@ extern "C" int fs_set_verif(fs_ctx *ctx, int modulo_verif)
 {
   if (!ctx || modulo_verif <= 0) return FS_ERR_ARG;
   ctx->modulo_verif = modulo_verif;
+  return FS_OK;
+}
+
+extern "C" int fs_zone_set_distance(fs_ctx *ctx, int zone, const double *dist, int n)
+{
+  if (!ctx || !dist) return ctx ? fail(ctx, FS_ERR_ARG, "fs_zone_set_distance: null argument") : FS_ERR_ARG;
+  if (zone < 0 || zone >= (int)ctx->zones.size()) return fail(ctx, FS_ERR_ARG, "fs_zone_set_distance: zone index out of range");
+  if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_zone_set_distance: call before fs_upload");
+  Zone &zn = ctx->zones[zone];
+  if ((long long)n != (long long)zn.z.ni * zn.z.nj * zn.z.nk) return fail(ctx, FS_ERR_ARG, "fs_zone_set_distance: one value per cell, ghost cells included");
+  zn.dist_host = dist;
   return FS_OK;
 }
 
@@ -217,7 +230,11 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme is LU-SGS with nb_relax = 1 and lu_match = 0 (no SSOR relaxation, no overlap, no GMRES)");
   if (implicit && !(ctx->dma_stage && !ctx->plain_stage))
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme needs the default stage kernel");
-  if (p[NEQ] != 5 || p[IFLOW] > 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Euler / NSLaminar (5 equations) are implemented");
+  const bool sa = p[IFLOW] == 3 && p[NEQ] == 6;
+  if (!sa && (p[NEQ] != 5 || p[IFLOW] > 2)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: governing equations must be Euler, NSLaminar or NSTurbulent (Spalart-Allmaras)");
+  if (sa && (p[ITYPZONE] != 2 || p[ITYPCP] != 2 || p[KFLUDOM] == 5 || p[47] > 1 || p[SA_DIST] != 1))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented for Cartesian zones, explicit scheme, "
+                "ausmpred / senseur fluxes, plain SA (no DES variant), with a TurbulentDistance field");
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
   if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
@@ -276,6 +293,11 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     z.tcx = z.tcy = z.tcz = z.si = z.sj = z.sk = z.volinv = z.coe = z.vol0 = 0.;
   }
   z.cv = r[CVINF]; z.cvinv = 1. / z.cv; z.cvinv2 = 0.5 * z.cvinv;  // core3ark3.for:44-46
+  z.gam4 = z.gam1 / r[PRANDT_TUR] * z.rgp;
+  z.temp01 = 1. / r[TEMP0];
+  z.sa_coesut = r[XMUL0] * (1. + r[CS] * z.temp01);
+  z.ratiom = r[SA_RATIOM_R];
+  z.sa_low_re = (double)p[SA_LOW_RE]; z.sa_rot_corr = (double)p[SA_ROT_CORR];
   {  // invist.for:49-51
     double cmus1 = r[CS], temp01 = 1. / r[TEMP0];
     z.cmus1 = cmus1;
@@ -313,6 +335,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     w.st[0] = r[ROINF]; w.st[1] = r[VXINF] * r[ROINF]; w.st[2] = r[VYINF] * r[ROINF]; w.st[3] = r[VZINF] * r[ROINF];
     w.st[4] = r[PINF] / (r[GAMMA] - 1.) + 0.5 * (r[VXINF] * w.st[1] + r[VYINF] * w.st[2] + r[VZINF] * w.st[3]);
     w.tcn = w.idir <= 2 ? mtr[0] : (w.idir <= 4 ? mtr[1] : mtr[2]);
+    w.nue = r[RONUTILDEINF] / w.st[0];
     switch (w.idir) {  // bvbs_periodique.for: incp = IJKV(dir) * stride, towards the interior
       case 1: w.shift = z.iv; break;
       case 2: w.shift = -(long long)z.iv; break;
@@ -375,7 +398,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     hipError_t e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
       return fail(ctx, FS_ERR_HIP, std::string("fs_zone_add: metric upload: ") + hipGetErrorString(e));
     }
     z.mt[0] = zn.mtr_dev; z.mt[1] = zn.mtr_dev + 3 * z.ndm; z.mt[2] = zn.mtr_dev + 6 * z.ndm;
@@ -457,6 +480,14 @@ extern "C" int fs_upload(fs_ctx *ctx)
         const size_t nw = (ctx->plain_stage && zn.z.ityp != 0 ? sizeof(double) : 1) * 3 * (size_t)zn.z.nd;
         HIPCHK(ctx, hipMalloc(&zn.wig, nw));
         HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, nw, ctx->stream));
+      }
+      if (zn.z.neq == 6) {
+        if (!zn.dist_host) return fail(ctx, FS_ERR_STATE, "fs_upload: a Spalart-Allmaras zone needs fs_zone_set_distance first");
+        const size_t nbd = sizeof(double) * (size_t)zn.z.nd;
+        HIPCHK(ctx, hipMalloc(&zn.dist, nbd));
+        HIPCHK(ctx, hipMemsetAsync(zn.dist, 0, nbd, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(zn.dist, zn.dist_host, sizeof(double) * (size_t)zn.z.ni * zn.z.nj * zn.z.nk,
+                                   hipMemcpyHostToDevice, ctx->stream));
       }
       if (ctx->implicit) {
         HIPCHK(ctx, hipMalloc(&zn.coe, nb));
@@ -549,7 +580,7 @@ static int build_shell_lists(fs_ctx *ctx)
     Zone &zn = ctx->zones[nz];
     const FsZone &z = zn.z;
     for (auto &s : ctx->sends) if (s.donor_zone == (int)nz) zn.has_sends = true;
-    if (z.ityp == 0 || ctx->implicit) continue;   // curvilinear / implicit zones run their stage in one piece
+    if (z.ityp == 0 || ctx->implicit || z.iflow == 3) continue;   // curvilinear / implicit / SA zones run their stage in one piece
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
     std::vector<char> mark((size_t)nblk, 0);
@@ -612,6 +643,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     const FsBdf *pbdf = ctx->implicit ? &bdf : nullptr;
     if (opens && nstep == 1) {
       if (z.iflow == 2) fsk_invist(z, ctx->implicit ? z.ific : 1, zn.dev[in], zn.xmut, ctx->stream);
+      if (z.iflow == 3) fsk_vispalart(z, zn.dev[in], zn.xmut, ctx->stream);
       if (ctx->implicit) {
         const double *r = zn.preal.data();
         fsk_coe_implicit(z, ctx->first_it, dtloc, r[CFL], r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in],
@@ -624,7 +656,10 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       HIPCHK(ctx, hipEventRecord(zn.ev_part, ctx->stream));
     }
     int krc = 0;
-    if (z.ityp == 0)
+    if (z.iflow == 3)
+      krc = fsk_stage_sa(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.dist,
+                         (unsigned char *)zn.wig, ctx->stream);
+    else if (z.ityp == 0)
       krc = fsk_stage_full(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
                            (unsigned char *)zn.wig, pbdf, ctx->stream);
     else if (ctx->plain_stage)

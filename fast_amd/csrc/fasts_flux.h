@@ -34,6 +34,9 @@ struct FsZone {
   double coe;              // dt/vol (constant on a Cartesian zone with a global time step)
   double vol0;             // cell volume of a Cartesian zone
   double dt, cv, cvinv, cvinv2, coesut, cmus1;
+  // Spalart-Allmaras (iflow 3): turbulent conductivity factor gam1/Pr_t*R, Sutherland constants in the form
+  // of mulam.for (mu = sa_coesut*sqrt(T*temp01)/(1+cmus1/T)), limiter ratio mu_t/mu, model switches
+  double gam4, sa_coesut, temp01, ratiom, sa_low_re, sa_rot_corr;
   // curvilinear zones (ityp 0): device arrays ti,tj,tk(ndm,3) and vol(ndm), dimensioned on the nodes;
   // metric index of cell (i,j,k) = (i+ific-1) + (j+ific-1)*mincj + (k+ifick-1)*minck
   int ityp;
@@ -68,9 +71,11 @@ template <class Q> FS_DEV double fs_wiggle(const Q &q)
 
 // Inviscid flux through the face between cell l-inc and cell l in direction DIR.
 // qm2..qp1[e] = variable e at l-2inc, l-inc, l, l+inc; wg = sensor of the face (senseur only).
+// sa (may be NULL): receives u, tdu and the right / left density states, the inputs of the rho*nu_tilde flux
+// (AUSM/fluFaceSA.for); ausmpred and senseur only.
 template <int KFLU, int DIR>
 FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *qm1_, const double *q0,
-                             const double *qp1_, double wg, double *flu)
+                             const double *qp1_, double wg, double *flu, double *sa = nullptr)
 {
   const double tc = DIR == 0 ? z.tcx : (DIR == 1 ? z.tcy : z.tcz);
   const double s = DIR == 0 ? z.si : (DIR == 1 ? z.sj : z.sk);
@@ -174,6 +179,7 @@ FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *q
     if (DIR == 2) flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tc * p1p2;
     else flu4 = u * (row1 + row2) - tdu * (row2 - row1);
     flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+    if (sa) { sa[0] = u; sa[1] = tdu; sa[2] = qm[0]; sa[3] = qp[0]; }
   }
   flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
 }
@@ -340,12 +346,12 @@ FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, doubl
 //   q(e, da, db, dn): variable e (1 u, 2 v, 3 w, 4 T) at offset dn along DIR (0 = ir, -1 = il)
 //   and (da, db) along the two transverse directions in the order (i,j,k) minus DIR.
 // mul/mur = viscosity at il / ir.
+// xmutvol / xktvol = face viscosity and conductivity over the volume (mut_interface.for,
+// mut_prandtltb_interface.for).
 template <int DIR, class Q>
-FS_DEV void fs_flux_viscous(const FsZone &z, const Q &q, double mul, double mur, double *flu)
+FS_DEV void fs_flux_viscous_x(const FsZone &z, const Q &q, double xmutvol, double xktvol, double *flu)
 {
   const double tcx = z.tcx, tcy = z.tcy, tcz = z.tcz;
-  double xmutvol = (mur + mul) * z.volinv;
-  double xktvol = xmutvol * z.gam3;
   double f1, f2, f3, f4, f5, f6, fv, fv5, div;
   const double Uil = q(1, 0, 0, -1), Uir = q(1, 0, 0, 0);
   const double Vil = q(2, 0, 0, -1), Vir = q(2, 0, 0, 0);
@@ -422,6 +428,17 @@ FS_DEV void fs_flux_viscous(const FsZone &z, const Q &q, double mul, double mur,
     fv = fv5 * 0.5 - gradT_nz * tcz * xktvol; flu[4] = flu[4] + fv;
   }
 }
+
+template <int DIR, class Q>
+FS_DEV void fs_flux_viscous(const FsZone &z, const Q &q, double mul, double mur, double *flu)
+{
+  double xmutvol = (mur + mul) * z.volinv;
+  double xktvol = xmutvol * z.gam3;
+  fs_flux_viscous_x<DIR>(z, q, xmutvol, xktvol, flu);
+}
+
+// laminar viscosity in the form the SA routines use (mulam.for)
+FS_DEV double fs_mulam_sa(const FsZone &z, double t) { return z.sa_coesut * sqrt(t * z.temp01) / (1. + z.cmus1 / t); }
 
 // Runge-Kutta stage update of one cell in conservative form, back to primitive variables
 // (core3ark3.for:108-154).  q = stage input, d = balance, out = stage output.

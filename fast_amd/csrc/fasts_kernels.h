@@ -15,6 +15,7 @@ struct FsBcWin {
   long long shift;   // periodic source offset (bvbs_periodique.for: incp)
   double st[5];      // conservative reference state (BCzone.cpp:26-38)
   double tcn;        // face metric along the normal (ti, tj or tk of the Cartesian zone)
+  double nue;        // reference nu_tilde of the SA model (BCFarfield_init.for: state(6)/state(1))
 };
 
 // depth = ghost layers covered besides the interior: 1 for the explicit scheme (navier_stokes_struct.for:223,
@@ -39,6 +40,10 @@ int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const 
 // stage kernel of curvilinear zones (zone type 0, fasts_stage_full.hip); sensors stored as bytes
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                    double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, hipStream_t s);
+// Spalart-Allmaras on Cartesian zones (fasts_stage_sa.hip): total viscosity on the whole zone, stage kernel
+void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s);
+int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                 double *drodm, const double *xmut, const double *dist, unsigned char *wig, hipStream_t s);
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop,
                     hipStream_t s);
 void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);

@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(256) k_stage_ref(FsZone z, double coefH, doubl
 // Characteristic far-field state in ghost cell l from the interior cell l1 and the reference state
 // (Fast/FastS/FastS/BC/BCFarfield.for, non_reflection.for:1-153; fixed mesh: qen = 0).
 // tc = face metric scaled by snorm (only the normal component is non zero on a Cartesian zone).
-FS_DEV void fs_bc_farfield_first(const FsZone &z, const double *st, double tcx, double tcy, double tcz,
+// Returns true when the first characteristic enters the domain (eigv1 < 0).
+FS_DEV bool fs_bc_farfield_first(const FsZone &z, const double *st, double tcx, double tcy, double tcz,
                                  double *rop, long long l, long long l1)
 {
   const long long nd = z.nd;
@@ -183,6 +184,7 @@ FS_DEV void fs_bc_farfield_first(const FsZone &z, const double *st, double tcx, 
   u = u + r * svar2 * roinv; v = v + r * svar3 * roinv; w = w + r * svar4 * roinv;
   rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
   rop[l + 4 * nd] = (qvar5 * roinv - .5 * (u * u + v * v + w * w)) * cvinv;
+  return eigv1 < 0.;
 }
 
 // Face metric seen by the BC routines for the column whose first interior cell is q
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
       for (int r = 1; r <= nr; r++) {
         const long long l = l1 - r * inc;
         const long long ls = w.type == FS_BC_PERIODIC ? l + w.shift : l1;
-        for (int e = 0; e < 5; e++) rop[e * nd + l] = rop[e * nd + ls];
+        for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls];
       }
     } else if (w.type == FS_BC_WALL_NOSLIP) {
       for (int r = 1; r <= nr; r++) {
@@ -243,6 +245,7 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         rop[l + 2 * nd] = 0. - rop[lm + 2 * nd];
         rop[l + 3 * nd] = 0. - rop[lm + 3 * nd];
         rop[l + 4 * nd] = rop[lm + 4 * nd];
+        if (z.neq == 6) rop[l + 5 * nd] = -rop[lm + 5 * nd];   // BCWallViscous_SA.for
       }
     } else if (w.type == FS_BC_WALL_SLIP) {
       double tc[3];
@@ -263,22 +266,26 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         rop[l + 2 * nd] = 0. + va;
         rop[l + 3 * nd] = 0. + wa;
         rop[l + 4 * nd] = rop[lm + 4 * nd];
+        if (z.neq == 6) rop[l + 5 * nd] = rop[lm + 5 * nd];    // BCWallInviscidSA_i.for
       }
     } else {  // FS_BC_FARFIELD
       const double snorm = (w.idir & 1) ? -1. : 1.;
       double tc[3];
       fs_bc_metric(z, w, d, q, tc);
-      fs_bc_farfield_first(z, w.st, tc[0] * snorm, tc[1] * snorm, tc[2] * snorm, rop, l1 - inc, l1);
+      const bool inflow = fs_bc_farfield_first(z, w.st, tc[0] * snorm, tc[1] * snorm, tc[2] * snorm, rop, l1 - inc, l1);
+      if (z.neq == 6) rop[l1 - inc + 5 * nd] = inflow ? w.nue : rop[l1 + 5 * nd];   // BCFarfield_firstrank_SA.for
       const double c4 = 5. / 6., c5 = 2. / 6., c6 = -1. / 6.;
       const double c0 = 1. / c6, c1 = -(c4 + c5) * c0, c2 = -c6 * c0, c3 = (2. - c5 - c4) * c0;
       for (int r = 2; r <= nr; r++) {   // BC_nextrank.for
         const long long l = l1 - r * inc, l0 = l + inc, l1b = l + 2 * inc, l2 = l + 3 * inc;
         const double ro = rop[l0] * c3 + rop[l1b] * c1 + rop[l2] * c2;
         rop[l] = ro;
-        if (fabs(ro / rop[l0] - 1.) >= 0.7) {
-          for (int e = 0; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd];
+        // positivity guard: BC_nextrank.for (5 equations), BC_nextrankSA.for (6)
+        const bool guard = z.neq == 6 ? ro <= 0.3 * rop[l0] : fabs(ro / rop[l0] - 1.) >= 0.7;
+        if (guard) {
+          for (int e = 0; e < z.neq; e++) rop[l + e * nd] = rop[l0 + e * nd];
         } else {
-          for (int e = 1; e < 5; e++) rop[l + e * nd] = rop[l0 + e * nd] * c3 + rop[l1b + e * nd] * c1 + rop[l2 + e * nd] * c2;
+          for (int e = 1; e < z.neq; e++) rop[l + e * nd] = rop[l0 + e * nd] * c3 + rop[l1b + e * nd] * c1 + rop[l2 + e * nd] * c2;
         }
       }
     }

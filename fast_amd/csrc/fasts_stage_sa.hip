@@ -1,0 +1,269 @@
+// One Runge-Kutta stage of the Spalart-Allmaras model (6 equations) on a Cartesian zone, gfx950.
+// Built with -ffp-contract=off; expressions keep the operand order of the reference fragments
+//   total viscosity     Fast/FastS/FastS/Compute/SA/vispalart.for, mulam.for, SA/chi.for, SA/xmut.for
+//   source term         SA/spsource_SA.for:185-232, SA/sourceSA_grad_3dcart.for, SA/sourceSA_prod_dest.for
+//   rho*nu_tilde flux   AUSM/fluFaceSA.for, SENSOR/fluFaceSA.for, SA/fluvisq_SA_3dcart_{i,j,k}.for, SA/mut_interface.for
+//   conductivity        mut_prandtltb_interface.for
+//   update              core3ark3.for:196-236 (nu_tilde clipped to [0, ratiom*nu])
+// The five mean-flow fluxes are those of the laminar path (fasts_flux.h).
+//
+// Work decomposition: the one of the curvilinear stage kernel.  32 x 8 thread patch marching in k, each
+// thread evaluates the three minus-faces of its cell, i+1/2 by shuffle, j+1/2 through double-buffered
+// LDS rows, k+1/2 carried to the next step; 31 x 7 cells owned per patch.  Accumulation order of a cell:
+//   drodm*coefH (+ vol*source for the 6th equation) + Fk- + Fj- + Fi- - Fi+ - Fj+ - Fk+
+// (src_term.for:59-96 before the flux loops of template_FluxAndBalance.for:192-271).
+// The fw function of the destruction term takes a 1/6 power: the device pow is not bit-identical to the
+// host one, so this kernel matches the CPU restatement to rounding, not bit for bit.
+#include "fasts_kernels.h"
+#include "fasts_flux.h"
+
+namespace {
+
+constexpr int TI = 32, TJ = 8, OI = TI - 1, OJ = TJ - 1, NQ = 6;
+
+template <int DIR> FS_DEV long long inc_of(const FsZone &z) { return DIR == 0 ? 1 : (DIR == 1 ? z.incj : z.inck); }
+
+// Face between cell l - inc(DIR) and cell l; qm2..qp1 = the four cells of the MUSCL stencil (6 variables).
+template <int KFLU, int DIR, bool FIRST>
+FS_DEV void face_sa(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
+                    unsigned char *__restrict__ wig, long long l, const double *qm2, const double *qm1,
+                    const double *q0, const double *qp1, double *flu)
+{
+  const long long nd = z.nd;
+  double wg = 0.;
+  if (KFLU == 2) {
+    if (FIRST) {
+      auto qs = [&](int e, int o) -> double { return o == -2 ? qm2[e] : (o == -1 ? qm1[e] : (o == 0 ? q0[e] : qp1[e])); };
+      wg = fs_wiggle(qs);
+      wig[DIR * nd + l] = wg != 0. ? 1 : 0;
+    } else {
+      wg = (double)wig[DIR * nd + l];
+    }
+  }
+  double sa[4];
+  fs_flux_inviscid<KFLU, DIR>(z, qm2, qm1, q0, qp1, wg, flu, sa);
+  {   // convective flux of rho*nu_tilde
+    const double qm = z.c4 * q0[5] + z.c5 * qm1[5] + z.c6 * qp1[5];
+    const double qp = z.c4 * qm1[5] + z.c6 * qm2[5] + z.c5 * q0[5];
+    const double qm6 = qm * sa[2], qp6 = qp * sa[3];
+    flu[5] = sa[0] * (qm6 + qp6) - sa[1] * (qm6 - qp6);
+  }
+  const long long inc = inc_of<DIR>(z);
+  const long long ia = DIR == 0 ? z.incj : 1;
+  const long long ib = DIR == 2 ? z.incj : z.inck;
+  auto q = [&](int e, int da, int db, int dn) -> double {
+    if (da == 0 && db == 0) return dn == 0 ? q0[e] : qm1[e];
+    return rop[e * nd + l + dn * inc + da * ia + db * ib];
+  };
+  const double Til = qm1[4], Tir = q0[4];
+  double xmulam = fs_mulam_sa(z, Til);
+  xmulam = xmulam + fs_mulam_sa(z, Tir);
+  const double xmutot = xmut[l] + xmut[l - inc];
+  const double xmutur = xmutot - xmulam;
+  const double xktvol = (xmulam * z.gam3 + xmutur * z.gam4) * z.volinv;
+  const double xmutvol = xmutot * z.volinv;
+  fs_flux_viscous_x<DIR>(z, q, xmutvol, xktvol, flu);
+  {   // diffusion of nu_tilde
+    const double tc = DIR == 0 ? z.tcx : (DIR == 1 ? z.tcy : z.tcz);
+    const double g = (q0[5] - qm1[5]) * tc;
+    double xm = xmulam + qm1[5] * qm1[0] + q0[5] * q0[0];
+    xm = xm * z.volinv * (1. / (2. / 3.));
+    if (DIR == 1) flu[5] = flu[5] - xm * (g * tc);
+    else flu[5] = flu[5] - xm * g * tc;
+  }
+}
+
+// vol * (production - destruction + cb2 term) of cell l; qc = state of the cell
+FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ dlng, long long l,
+                        const double *qc)
+{
+  const double SA_CKARM = 0.41, SA_CB1 = 0.1355, SA_CB2 = 0.622, SA_CV1 = 357.911, SA_CW2 = 0.3, SA_CW3 = 64.;
+  const double SA_CW4 = 0.21, SA_CW5 = 1.5, SA_CROT = 2.0, SA_SIGMA = (2. / 3.);
+  const double c1 = SA_CB2 / SA_SIGMA;
+  const double cw1 = (SA_CB1 / SA_CKARM / SA_CKARM) + (1. + SA_CB2) / SA_SIGMA;
+  const long long nd = z.nd, incj = z.incj, inck = z.inck;
+  const long long l1 = l + 1, l2 = l - 1, l3 = l + incj, l4 = l - incj, l5 = l + inck, l6 = l - inck;
+  const double tix = z.tcx, tjy = z.tcy, tkz = z.tcz;
+  const double xvol = z.volinv;   // 0.5/vol
+  double g[3][3];
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    const double *__restrict__ q = rop + (1 + v) * nd;
+    const double c = qc[1 + v];
+    const double u1 = (c + q[l2]), u2 = (c + q[l3]), u3 = (c + q[l1]);
+    const double u4 = (c + q[l4]), u5 = (c + q[l5]), u6 = (c + q[l6]);
+    g[v][0] = (u3 - u1) * tix; g[v][1] = (u2 - u4) * tjy; g[v][2] = (u5 - u6) * tkz;
+  }
+  const double rotx = g[2][1] - g[1][2], roty = g[0][2] - g[2][0], rotz = g[1][0] - g[0][1];
+  const double rot = sqrt(rotx * rotx + roty * roty + rotz * rotz) * xvol;
+  const double S11 = g[0][0], S22 = g[1][1], S33 = g[2][2];
+  const double S12 = 0.5 * (g[0][1] + g[1][0]), S13 = 0.5 * (g[0][2] + g[2][0]), S23 = 0.5 * (g[1][2] + g[2][1]);
+  double St = S11 * S11 + S22 * S22 + S33 * S33 + 2 * (S12 * S12) + 2 * (S13 * S13) + 2 * (S23 * S23);
+  St = sqrt(2 * St) * xvol;
+  const double *__restrict__ N = rop + 5 * nd, *__restrict__ R = rop;
+  const double nc = qc[5], rc = qc[0];
+  const double n1 = N[l1], n2 = N[l2], n3 = N[l3], n4 = N[l4], n5 = N[l5], n6 = N[l6];
+  double u1 = (nc + n2), u2 = (nc + n3), u3 = (nc + n1), u4 = (nc + n4), u5 = (nc + n5), u6 = (nc + n6);
+  double dudx = (u3 - u1) * tix, dudy = (u2 - u4) * tjy, dudz = (u5 - u6) * tkz;
+  u1 = nc * rc + n2 * R[l2]; u2 = nc * rc + n3 * R[l3]; u3 = nc * rc + n1 * R[l1];
+  u4 = nc * rc + n4 * R[l4]; u5 = nc * rc + n5 * R[l5]; u6 = nc * rc + n6 * R[l6];
+  dudx = dudx * (u3 - u1) * tix; dudy = dudy * (u2 - u4) * tjy; dudz = dudz * (u5 - u6) * tkz;
+  const double anvisc = c1 * (dudx + dudy + dudz) * xvol * xvol;
+  const double amulam = fs_mulam_sa(z, qc[4]);
+  const double anulam = rc / amulam;
+  const double anutild = fs_max(nc, 1.e-27);
+  const double chi = fs_max(anutild * anulam, 1.e-7);
+  const double f1 = 1. / (1. + SA_CV1 / (chi * chi * chi));
+  const double f2 = 1. - chi / (1. + chi * f1);
+  const double dist = fs_max(dlng[l], 1.e-27);
+  double stild = rot + (anutild * f2) / (SA_CKARM * SA_CKARM * dist * dist);
+  stild = stild + z.sa_rot_corr * SA_CROT * fs_min(0.00000000000000000001, St - rot);
+  const double prod = rc * SA_CB1 * stild * anutild;
+  stild = fs_max(stild, 0.00000000000000000001);
+  double r = anutild / (stild * SA_CKARM * SA_CKARM * dist * dist);
+  r = fs_min(r, 10.);
+  const double r5 = r * r * r * r * r - 1.;
+  double gg = r * (1. + SA_CW2 * r5);
+  const double cw2_lre = SA_CW4 + SA_CW5 / ((1. + chi / 40.) * (1. + chi / 40.));
+  gg = z.sa_low_re * r * (1. + cw2_lre * r5) + (1. - z.sa_low_re) * gg;
+  const double g6 = gg * gg * gg * gg * gg * gg;
+  const double fwg = gg * pow((1. + SA_CW3) / (g6 + SA_CW3), 1. / 6.);
+  const double destruc = rc * cw1 * fwg * (anutild / dist) * (anutild / dist);
+  const double tsource = (prod + anvisc - destruc);
+  return z.vol0 * tsource;
+}
+
+template <int KFLU, bool FIRST>
+__global__ void __launch_bounds__(256)
+k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
+           double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
+           const double *__restrict__ dlng, unsigned char *__restrict__ wig)
+{
+  __shared__ double sfj[2][NQ][TJ][TI];
+  const int ti = threadIdx.x & 31, tj = threadIdx.x >> 5;
+  const int i = 1 + blockIdx.x * OI + ti, j = 1 + blockIdx.y * OJ + tj;
+  const int k0 = 1 + blockIdx.z * kchunk;
+  const int k1 = k0 + kchunk - 1 < z.kv ? k0 + kchunk - 1 : z.kv;
+  const bool active = i <= z.iv + 1 && j <= z.jv + 1;
+  const bool own_i = ti < OI && i <= z.iv, own_j = tj < OJ && j <= z.jv;
+  const bool own = own_i && own_j;
+  const bool do_fi = active && own_j, do_fj = active && own_i;
+  const long long nd = z.nd;
+  const int ic = active ? i : 1, jc = active ? j : 1;
+  long long l = (long long)(ic + z.ific - 1) + (long long)(jc + z.ific - 1) * z.incj + (long long)(k0 + z.ifick - 1) * z.inck;
+  double qa[NQ], qb[NQ], qc[NQ], qd[NQ];
+#pragma unroll
+  for (int e = 0; e < NQ; e++) {
+    qa[e] = rop[e * nd + l - 2 * z.inck];
+    qb[e] = rop[e * nd + l - z.inck];
+    qc[e] = rop[e * nd + l];
+    qd[e] = 0.;
+  }
+  double part[NQ] = {0., 0., 0., 0., 0., 0.};
+  for (int k = k0; k <= k1 + 1; k++) {
+    const bool last = k > k1;
+#pragma unroll
+    for (int e = 0; e < NQ; e++) qd[e] = rop[e * nd + l + z.inck];
+    double fk[NQ] = {0., 0., 0., 0., 0., 0.};
+    if (own) {
+      face_sa<KFLU, 2, FIRST>(z, rop, xmut, wig, l, qa, qb, qc, qd, fk);
+      if (k > k0) {
+        const long long lb = l - z.inck;
+        double d[NQ], o[5];
+#pragma unroll
+        for (int e = 0; e < NQ; e++) { d[e] = part[e] - fk[e]; drodm[e * nd + lb] = d[e]; }
+        fs_rk_update(z, coefW, qb, d, o);
+#pragma unroll
+        for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
+        {   // nu_tilde: conservative update, clipped to [0, ratiom * nu_laminar] (core3ark3.for:196-236)
+          const double r_1 = 1. / o[0];
+          const double tab6 = d[5] * (coefW * z.coe);
+          double anulam = fs_mulam_sa(z, o[4]);
+          anulam = anulam * r_1 * z.ratiom;
+          double t6 = (qb[0] * qb[5] + tab6) * r_1;
+          t6 = fs_min(t6, anulam);
+          rop_out[5 * nd + lb] = fs_max(t6, 0.);
+        }
+      }
+    }
+    if (!last) {
+      double fim[NQ] = {0., 0., 0., 0., 0., 0.}, fjm[NQ] = {0., 0., 0., 0., 0., 0.};
+      if (do_fj) {
+        double m2[NQ], m1[NQ], p1[NQ];
+#pragma unroll
+        for (int e = 0; e < NQ; e++) {
+          m2[e] = rop[e * nd + l - 2 * z.incj]; m1[e] = rop[e * nd + l - z.incj]; p1[e] = rop[e * nd + l + z.incj];
+        }
+        face_sa<KFLU, 1, FIRST>(z, rop, xmut, wig, l, m2, m1, qc, p1, fjm);
+      }
+      const int buf = (k - k0) & 1;
+#pragma unroll
+      for (int e = 0; e < NQ; e++) sfj[buf][e][tj][ti] = fjm[e];
+      if (do_fi) {
+        double m2[NQ], m1[NQ], p1[NQ];
+#pragma unroll
+        for (int e = 0; e < NQ; e++) {
+          m2[e] = rop[e * nd + l - 2]; m1[e] = rop[e * nd + l - 1]; p1[e] = rop[e * nd + l + 1];
+        }
+        face_sa<KFLU, 0, FIRST>(z, rop, xmut, wig, l, m2, m1, qc, p1, fim);
+      }
+      double fip[NQ];
+#pragma unroll
+      for (int e = 0; e < NQ; e++) fip[e] = __shfl_down(fim[e], 1);
+      __syncthreads();
+      if (own) {
+        const double src = sa_source(z, rop, dlng, l, qc);
+#pragma unroll
+        for (int e = 0; e < NQ; e++) {
+          double dr = FIRST ? 0. : drodm[e * nd + l] * coefH;
+          if (e == 5) dr = dr + src;
+          part[e] = dr + fk[e] + fjm[e] + fim[e] - fip[e] - sfj[buf][e][tj + 1][ti];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NQ; e++) { qa[e] = qb[e]; qb[e] = qc[e]; qc[e] = qd[e]; }
+    l += z.inck;
+  }
+}
+
+// total viscosity mu + mu_t on the whole zone, ghost cells included
+__global__ void __launch_bounds__(256) k_vispalart(FsZone z, const double *__restrict__ rop, double *__restrict__ xmut)
+{
+  const int si = blockIdx.x * blockDim.x + threadIdx.x, sj = blockIdx.y, sk = blockIdx.z;
+  if (si >= z.ni) return;
+  const long long nd = z.nd, l = si + (long long)sj * z.incj + (long long)sk * z.inck;
+  const double SA_CV1 = 357.911;
+  const double amulam = fs_mulam_sa(z, rop[l + 4 * nd]);
+  const double anulam = rop[l] / amulam;
+  const double anutild = fs_max(rop[l + 5 * nd], 1.e-27);
+  const double chi = fs_max(anutild * anulam, 1.e-7);
+  const double fvv1 = 1. / (1. + SA_CV1 / (chi * chi * chi));
+  const double amut = rop[l] * anutild * fvv1;
+  const double xmuprov = fs_max(amut, 0.);
+  xmut[l] = amulam + fs_min(xmuprov, z.ratiom * amulam);
+}
+
+}  // namespace
+
+void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s)
+{
+  dim3 g((z.ni + 255) / 256, z.nj, z.nk);
+  hipLaunchKernelGGL(k_vispalart, g, dim3(256), 0, s, z, rop, xmut);
+}
+
+int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                 double *drodm, const double *xmut, const double *dist, unsigned char *wig, hipStream_t s)
+{
+  if (z.ityp != 2 || z.neq != 6 || z.iflow != 3 || !dist) return -1;
+  int kchunk = 32;
+  if (kchunk > z.kv) kchunk = z.kv;
+  dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
+#define FS_GO(K, FIRST_)                                                                                   \
+  hipLaunchKernelGGL((k_stage_sa<K, FIRST_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, drodm, \
+                     xmut, dist, wig)
+  if (z.kflu == 1) { if (first) FS_GO(1, true); else FS_GO(1, false); return 0; }
+  if (z.kflu == 2) { if (first) FS_GO(2, true); else FS_GO(2, false); return 0; }
+#undef FS_GO
+  return -1;
+}

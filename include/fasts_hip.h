@@ -89,6 +89,11 @@ int fs_zone_add(fs_ctx *ctx, const int32_t *param_int, int n_int, const double *
                 int n_real, double *ro, double *ro_m1, double *ro_p1, const double *mtr,
                 int n_mtr);
 
+/* Wall distance of a Spalart-Allmaras zone (IFLOW 3): one value per cell, ghost cells included, i fastest
+ * (the TurbulentDistance field, which the reference keeps in the second slot of its viscosity array,
+ * Fast/FastS/FastS/Compute/src_term.for:93-96).  The pointer must stay valid until fs_upload. */
+int fs_zone_set_distance(fs_ctx *ctx, int zone, const double *dist, int n);
+
 /* Match-join ghost transfer tables (one entry per join "rac"): receiver zone, donor zone and
  * the two index lists (0-based, ghost-inclusive linear cell indices i + j*ni + k*ni*nj), i.e.
  * the PointListDonor / PointList arrays of a 'direct' (type 0) ID join, as hand-built in

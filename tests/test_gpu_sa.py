@@ -1,0 +1,79 @@
+"""GPU parity of the Spalart-Allmaras model (NSTurbulent, 6 equations) on Cartesian zones against the CPU
+restatement, itself bit-exact against the compiled reference (test_oracle_vs_ref.py).  The destruction
+term takes a 1/6 power (fw function, SA/spsource_SA.for:75): the device pow and the host pow differ in
+the last bit, so fields are compared to 1e-12 relative (the tolerance of the path is 1e-11 after 100
+iterations); every other operation keeps the reference's order."""
+import numpy as np
+import pytest
+
+from fast_amd import cases, connect, FastC, Internal, _capi
+import fast_amd.pytree_lite as C
+import fast_amd.PyTree as FastS
+from oracle import oracle as O
+from common import zone_arrays, rel_err, SINGLE, prepare, wall_distance
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ((14, 12, 10), 'ausmpred', None, 6),
+    ((12, 10, 9), 'senseur', None, 6),
+    ((70, 17, 37), 'senseur', None, 3),
+    ((12, 9, 10), 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 6),
+    ((10, 9, 8), 'senseur', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, 5),
+]
+
+
+@pytest.mark.parametrize("n,scheme,bcs,nit", CASES)
+def test_sa_matches_oracle(n, scheme, bcs, nit):
+    t = cases.tgv(n, scheme, model='NSTurbulent', extra_numz=SINGLE, bcs=bcs)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[36]) == 6 and int(pint[27]) == 3
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z))
+    oz.fill_ghostcells()
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)        # 6-variable ghost fill: bit-exact
+    ro0 = oz.ro.copy()
+    for it in range(1, nit + 1):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        e = rel_err(got, oz.ro, int(pint[41]), neq=6)
+        assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+    d = np.abs(got - ro0).reshape(6, -1).max(axis=1)
+    assert np.isfinite(got).all() and d[5] > 1e-7
+
+
+def test_sa_blocks_with_joins():
+    blocks, nn = (2, 1, 2), (16, 9, 12)
+    nv = tuple(nn[d] // blocks[d] for d in range(3))
+    joins = connect.periodic_block_joins(blocks, nv)
+    kw = dict(model='NSTurbulent', blocks=blocks, extra_numz=SINGLE, bcs={'jmin': 'BCWall'})
+    to = cases.tgv(nn, 'senseur', **kw)
+    m = prepare(to)
+    zs = []
+    for z, mm in zip(Internal.getZones(to), m):
+        p, pr, _ = zone_arrays(z)
+        zs.append(O.OracleZone(p, pr, FastC.level_buffer(z), mm[0], wall_distance(z)))
+    s = O.OracleSolver(zs, [(br, r, bd, d) for br, bd, r, d in joins])
+    s.fill_ghostcells()
+    t = cases.tgv(nn, 'senseur', **kw)
+    tc = C.node2Center(t)
+    connect.add_joins_to_tc(tc, joins, [z[0] for z in Internal.getZones(t)])
+    (t, tc, metrics) = FastS.warmup(t, tc)
+    zones = Internal.getZones(t)
+    for it in range(1, 4):
+        FastS._compute(t, metrics, it, tc)
+        s.step()
+        for z, oz in zip(zones, s.zones):
+            e = rel_err(FastC.level_buffer(z), oz.ro, oz.ndimdx, neq=6)
+            assert e.max() < 1e-12, "step %d zone %s: %s" % (it, z[0], e)
+
+
+def test_sa_options_outside_the_device_path_are_refused():
+    t = cases.tgv(8, 'roe', model='NSTurbulent')
+    with pytest.raises(_capi.FastsHipError, match="Spalart-Allmaras"):
+        FastS.warmup(t, None)
+    t = cases.tgv(8, 'senseur', model='NSTurbulent', perturb=0.1)
+    with pytest.raises(_capi.FastsHipError, match="Spalart-Allmaras"):
+        FastS.warmup(t, None)
