@@ -94,6 +94,13 @@ static std::string g_create_err;
     }                                                                                       \
   } while (0)
 
+static int bc_kinds(const std::vector<FsBcWin> &v)
+{
+  int k = 0;
+  for (auto &w : v) k |= (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE) ? 1 : 2;
+  return k;
+}
+
 static int fail(fs_ctx *ctx, int code, const std::string &msg)
 {
   ctx->err = msg;
@@ -694,8 +701,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     }
     if (ctx->implicit) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:53-68,135-161)
       if (!zn.rhs_face.empty()) {   // wall faces: BCs on the residual, two ordered passes, then edges/corners
-        fsk_bc_windows(z, (int)zn.rhs_face.size(), zn.rhs_face_dev, zn.rhs_max_cells, zn.drodm, ctx->stream);
-        fsk_bc_windows(z, (int)zn.rhs_bc.size(), zn.rhs_bc_dev, zn.rhs_max_cells, zn.drodm, ctx->stream);
+        fsk_bc_windows(z, (int)zn.rhs_face.size(), zn.rhs_face_dev, bc_kinds(zn.rhs_face), zn.rhs_max_cells, zn.drodm, ctx->stream);
+        fsk_bc_windows(z, (int)zn.rhs_bc.size(), zn.rhs_bc_dev, bc_kinds(zn.rhs_bc), zn.rhs_max_cells, zn.drodm, ctx->stream);
         fsk_bc_edges(z, zn.drodm, ctx->stream);
       }
       if (fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ctx->stream))
@@ -762,7 +769,7 @@ extern "C" int fs_local_joins(fs_ctx *ctx, int nstep)
 static void bcs_on_role(fs_ctx *ctx, int role)
 {
   for (auto &zn : ctx->zones) {
-    fsk_bc_windows(zn.z, (int)zn.bc.size(), zn.bc_dev, zn.bc_max_cells, zn.dev[role], ctx->stream);
+    fsk_bc_windows(zn.z, (int)zn.bc.size(), zn.bc_dev, bc_kinds(zn.bc), zn.bc_max_cells, zn.dev[role], ctx->stream);
     fsk_bc_edges(zn.z, zn.dev[role], ctx->stream);
   }
 }

@@ -44,7 +44,9 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
 void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s);
 int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                  double *drodm, const double *xmut, const double *dist, unsigned char *wig, hipStream_t s);
-void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop,
+// kinds: bit 0 = the table holds periodic / extrapolation windows (copy kernel), bit 1 = walls / far field.
+// The windows of one table must not overlap: the two kernels are not ordered cell by cell.
+void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, int kinds, long long max_cells, double *rop,
                     hipStream_t s);
 void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);
 void fsk_join_copy(int npts, int neq, long long nd_r, long long nd_d, const int *rcv, const int *dnr,

@@ -206,6 +206,36 @@ FS_DEV void fs_bc_metric(const FsZone &z, const FsBcWin &w, int d, const int *q,
   tc[d] = w.tcn * 1.;
 }
 
+// Periodic and extrapolation windows are pure copies (source = periodic image, bvbs_periodique.for:150-171,
+// or first interior cell, BCExtrapolate.for with c1 = 1): one thread per ghost cell, i fastest.  A kernel of
+// its own, so that this latency-bound copy keeps a small register footprint and a high occupancy.
+__global__ void __launch_bounds__(256) k_bc_copy(FsZone z, int nwin, const FsBcWin *__restrict__ wins,
+                                                 double *__restrict__ rop)
+{
+  const FsBcWin *w = wins + blockIdx.y;
+  const int type = w->type;
+  if (type != FS_BC_PERIODIC && type != FS_BC_EXTRAPOLATE) return;
+  const int lo0 = w->lo[0], lo1 = w->lo[1], lo2 = w->lo[2];
+  const int n0 = w->hi[0] - lo0 + 1, n1 = w->hi[1] - lo1 + 1, n2 = w->hi[2] - lo2 + 1;
+  const int idir = w->idir;
+  const long long shift = w->shift, nd = z.nd;
+  const long long nc = (long long)n0 * n1 * n2;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nc; t += (long long)gridDim.x * blockDim.x) {
+    int i = lo0 + (int)(t % n0), j = lo1 + (int)((t / n0) % n1), k = lo2 + (int)(t / ((long long)n0 * n1));
+    const long long l = fs_inddm(z, i, j, k);
+    long long ls = l + shift;
+    if (type == FS_BC_EXTRAPOLATE) {
+      switch (idir) {
+        case 1: i = 1; break; case 2: i = z.iv; break;
+        case 3: j = 1; break; case 4: j = z.jv; break;
+        case 5: k = 1; break; default: k = z.kv; break;
+      }
+      ls = fs_inddm(z, i, j, k);
+    }
+    for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls];
+  }
+}
+
 // One block-row per window, one thread per face cell of the window; the thread walks the ghost
 // ranks outwards (rank 2 of the far field reads rank 1).
 //   BCautoperiod       ghost = rop(l + shift)                     bvbs_periodique.for:150-171
@@ -225,6 +255,7 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
   const long long inc = sgn * stride;                          // from a ghost cell towards the interior
   const long long nd = z.nd;
   const long long n = (long long)na * nb;
+  if (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE) return;   // k_bc_copy
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     int q[3];
     q[da] = w.lo[da] + (int)(t % na);
@@ -232,11 +263,7 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
     q[d] = first;
     const long long l1 = fs_inddm(z, q[0], q[1], q[2]);        // first interior cell
     if (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE) {
-      for (int r = 1; r <= nr; r++) {
-        const long long l = l1 - r * inc;
-        const long long ls = w.type == FS_BC_PERIODIC ? l + w.shift : l1;
-        for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls];
-      }
+      // handled above, one thread per ghost cell
     } else if (w.type == FS_BC_WALL_NOSLIP) {
       for (int r = 1; r <= nr; r++) {
         const long long l = l1 - r * inc, lm = l1 + (r - 1) * inc;
@@ -488,12 +515,14 @@ int fsk_stage(const FsZone &z, double coefH, double coefW, int first, const doub
   return -1;
 }
 
-void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, long long max_cells, double *rop, hipStream_t s)
+void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, int kinds, long long max_cells, double *rop,
+                    hipStream_t s)
 {
   if (nwin <= 0) return;
   unsigned gx = cdiv(max_cells, 256);
   if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(k_bc_windows, dim3(gx, nwin), dim3(256), 0, s, z, nwin, dev_wins, rop);
+  if (kinds & 1) hipLaunchKernelGGL(k_bc_copy, dim3(gx, nwin), dim3(256), 0, s, z, nwin, dev_wins, rop);
+  if (kinds & 2) hipLaunchKernelGGL(k_bc_windows, dim3(gx, nwin), dim3(256), 0, s, z, nwin, dev_wins, rop);
 }
 
 void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s)

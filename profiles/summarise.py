@@ -2,6 +2,7 @@
 """Condense rocprofv3 output directories into the small per-kernel tables kept under profiles/.
 
     python profiles/summarise.py stats  <dir> <out.csv>       kernel-trace --stats run
+    python profiles/summarise.py stats_db <dir> <out.csv>     the same from the rocpd database
     python profiles/summarise.py pmc    <dir> <out.csv>       one --pmc pass (per kernel, per counter:
                                                               launches, mean and total)
 """
@@ -38,6 +39,30 @@ def stats(d, out):
             w.writerow([short(r['Name']), r['Calls'], '%.3f' % (float(r['TotalDurationNs']) / 1e6),
                         '%.2f' % (float(r['AverageNs']) / 1e3), '%.2f' % (float(r['MinNs']) / 1e3),
                         '%.2f' % (float(r['MaxNs']) / 1e3), r['Percentage']])
+
+
+def stats_db(d, out):
+    """Same table from the rocpd database (*_results.db) that rocprofv3 writes when no CSV output is asked for."""
+    import sqlite3
+    db = sqlite3.connect(find(d, '_results.db')[0])
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith('rocpd_kernel_dispatch')][0]
+    ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
+    rows = list(db.execute('select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), '
+                           'max(d.end-d.start) from %s d join %s s on d.kernel_id=s.id group by 1 order by 3 desc' % (kd, ks)))
+    total = sum(r[2] for r in rows)
+    import subprocess
+    with open(out, 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['kernel', 'calls', 'total_ms', 'avg_us', 'min_us', 'max_us', 'percent'])
+        for r in rows:
+            name = r[0][:-3] if r[0].endswith('.kd') else r[0]
+            try:
+                name = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip() or name
+            except OSError:
+                pass
+            w.writerow([short(name), r[1], '%.3f' % (r[2] / 1e6), '%.2f' % (r[3] / 1e3), '%.2f' % (r[4] / 1e3),
+                        '%.2f' % (r[5] / 1e3), '%.2f' % (100. * r[2] / total)])
 
 
 def pmc(d, out):
@@ -87,4 +112,4 @@ def traffic(fetch_csv, write_csv, out, kernel='k_stage_'):
 
 
 if __name__ == '__main__':
-    {'stats': stats, 'pmc': pmc, 'traffic': traffic}[sys.argv[1]](*sys.argv[2:])
+    {'stats': stats, 'stats_db': stats_db, 'pmc': pmc, 'traffic': traffic}[sys.argv[1]](*sys.argv[2:])
