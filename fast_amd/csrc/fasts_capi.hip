@@ -239,9 +239,9 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme needs the default stage kernel");
   const bool sa = p[IFLOW] == 3 && p[NEQ] == 6;
   if (!sa && (p[NEQ] != 5 || p[IFLOW] > 2)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: governing equations must be Euler, NSLaminar or NSTurbulent (Spalart-Allmaras)");
-  if (sa && (p[ITYPZONE] != 2 || p[ITYPCP] != 2 || p[KFLUDOM] == 5 || p[47] > 1 || p[SA_DIST] != 1))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented for Cartesian zones, explicit scheme, "
-                "ausmpred / senseur fluxes, plain SA (no DES variant), with a TurbulentDistance field");
+  if (sa && (p[ITYPZONE] != 2 || p[47] > 1 || p[SA_DIST] != 1))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented for Cartesian zones, "
+                "plain SA (no DES variant), with a TurbulentDistance field");
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
   if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
@@ -655,6 +655,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
         const double *r = zn.preal.data();
         fsk_coe_implicit(z, ctx->first_it, dtloc, r[CFL], r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in],
                          zn.xmut, zn.coe, ctx->stream);
+        if (z.iflow == 3) fsk_sa_coe6(z, zn.dev[in], zn.dist, zn.coe, ctx->stream);
       }
       if (z.kflu == 2 && ctx->plain_stage && z.ityp != 0) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }
@@ -665,7 +666,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     int krc = 0;
     if (z.iflow == 3)
       krc = fsk_stage_sa(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.dist,
-                         (unsigned char *)zn.wig, ctx->stream);
+                         (unsigned char *)zn.wig, pbdf, ctx->stream);
     else if (z.ityp == 0)
       krc = fsk_stage_full(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
                            (unsigned char *)zn.wig, pbdf, ctx->stream);

@@ -43,7 +43,10 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
 // Spalart-Allmaras on Cartesian zones (fasts_stage_sa.hip): total viscosity on the whole zone, stage kernel
 void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s);
 int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                 double *drodm, const double *xmut, const double *dist, unsigned char *wig, hipStream_t s);
+                 double *drodm, const double *xmut, const double *dist, unsigned char *wig, const FsBdf *bdf,
+                 hipStream_t s);
+// coe(:,6), diagonal of the nu_tilde equation, interior + one ghost layer; needs coe(:,1) and coe(:,5)
+void fsk_sa_coe6(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
 // kinds: bit 0 = the table holds periodic / extrapolation windows (copy kernel), bit 1 = walls / far field.
 // The windows of one table must not overlap: the two kernels are not ordered cell by cell.
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, int kinds, long long max_cells, double *rop,

@@ -91,9 +91,11 @@ struct LuConst { double gam1, gamm1, gam2, cp, cvinv, cvinv2, cv; };
 // b = [A(q_m) + signe*rho_d(m) I] dW(m) for the neighbour m = l - SGN*inc(D) of cell l (SGN = +1 lower
 // sweep, -1 upper sweep), from the neighbour's state (u,v,w,t), its increment d1..d5 and its spectral
 // radius crad = coe(m, 2+D); lt = metric index of cell l.
-template <bool FULL, int D, int SGN>
+// NE = 6: Spalart-Allmaras, the 6th equation is a decoupled scalar, b6 = (qn + signe*rho_d) dW6
+// (LU/lu_{i,j,k}_3dcart_SA.for).
+template <bool FULL, int D, int SGN, int NE = 5>
 FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, double v, double w, double t,
-                    double d1, double d2, double d3, double d4, double d5, double crad, double *b)
+                    double d1, double d2, double d3, double d4, double d5, double crad, double *b, double d6 = 0.)
 {
   const double signe = SGN > 0 ? 0.5 : -0.5;
   const double gamm1 = c.gamm1, gam2 = c.gam2, gam1 = c.gam1, cp = c.cp;
@@ -124,6 +126,7 @@ FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, d
     b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
     b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    if (NE == 6) b[5] = (qn + cr) * d6;
     return;
   }
   const double tc = D == 0 ? z.tcx : (D == 1 ? z.tcy : z.tcz);
@@ -140,6 +143,7 @@ FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, d
     b[2] = b31 * d1 + b32 * d2 + b33 * d3;
     b[3] = b41 * d1 + b42 * d2 + b44 * d4;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    if (NE == 6) b[5] = (qn + cr) * d6;
   } else if (D == 1) {
     const double qn = tc * v;
     const double b11 = cr, b13 = tc, b21 = (-u * qn), b22 = qn + cr, b23 = tc * u;
@@ -153,6 +157,7 @@ FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, d
     b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
     b[3] = b41 * d1 + b43 * d3 + b44 * d4;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    if (NE == 6) b[5] = (qn + cr) * d6;
   } else {
     const double qn = tc * w;
     const double b11 = cr, b14 = tc, b21 = -u * qn, b22 = qn + cr, b24 = tc * u;
@@ -166,19 +171,21 @@ FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, d
     b[2] = b31 * d1 + b33 * d3 + b34 * d4;
     b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    if (NE == 6) b[5] = (qn + cr) * d6;
   }
 }
 
 // rs = state array the neighbour is read from, dw = increments, coe = coefficient array
-template <bool FULL, int D, int SGN>
+template <bool FULL, int D, int SGN, int NE = 5>
 FS_DEV void lu_neighbour(const FsZone &z, const LuConst &c, long long l, long long lt, const double *__restrict__ rs,
                          const double *__restrict__ dw, const double *__restrict__ coe, double *b)
 {
   const long long nd = z.nd;
   const long long inc = D == 0 ? 1 : (D == 1 ? z.incj : z.inck);
   const long long l1 = l - SGN * inc;
-  lu_term<FULL, D, SGN>(z, c, lt, rs[l1 + nd], rs[l1 + 2 * nd], rs[l1 + 3 * nd], rs[l1 + 4 * nd], dw[l1], dw[l1 + nd],
-                        dw[l1 + 2 * nd], dw[l1 + 3 * nd], dw[l1 + 4 * nd], coe[l1 + (1 + D) * nd], b);
+  lu_term<FULL, D, SGN, NE>(z, c, lt, rs[l1 + nd], rs[l1 + 2 * nd], rs[l1 + 3 * nd], rs[l1 + 4 * nd], dw[l1], dw[l1 + nd],
+                            dw[l1 + 2 * nd], dw[l1 + 3 * nd], dw[l1 + 4 * nd], coe[l1 + (1 + D) * nd], b,
+                            NE == 6 ? dw[l1 + 5 * nd] : 0.);
 }
 
 // cell of hyperplane h handled by this thread: threads run over j (x) and k (y, offset kbase)
@@ -414,7 +421,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_chunk(FsZone z, LuConst c, LuRa
 // every array); the i recurrence then runs in 8 steps, the increment of cell m-1 reaching cell m through
 // a shuffle inside each group of 8 lanes.
 // ------------------------------------------------------------------------------------------------------
-template <bool FULL>
+template <bool FULL, int NE>
 __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
                                                       const double *__restrict__ rop, double *__restrict__ dw,
                                                       const double *__restrict__ coe)
@@ -428,57 +435,59 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
   const bool has_prev = active && i > r.i0;
-  double A[5] = {0., 0., 0., 0., 0.}, P[5] = {0., 0., 0., 0., 0.}, S[4] = {0., 0., 0., 0.};
-  double CR = 0., XAL = 0., DG = 0.;
+  double A[NE] = {}, P[NE] = {}, S[4] = {0., 0., 0., 0.};
+  double CR = 0., XAL = 0., DG = 0., C6 = 1.;   // C6 = diagonal of the 6th equation, coe(:,6)
   if (active) {
     XAL = coe[l] * 0.5;
-    double b[5];
+    double b[NE];
 #pragma unroll
-    for (int e = 0; e < 5; e++) A[e] = dw[l + e * nd];
+    for (int e = 0; e < NE; e++) A[e] = dw[l + e * nd];
     const bool has_j = j > r.j0, has_k = k > r.k0;
     if (FULL) {
-      if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
-      if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+      if (has_k) { lu_neighbour<FULL, 2, 1, NE>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL; }
+      if (has_j) { lu_neighbour<FULL, 1, 1, NE>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL; }
     } else {
-      if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
-      if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+      if (has_j) { lu_neighbour<FULL, 1, 1, NE>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL; }
+      if (has_k) { lu_neighbour<FULL, 2, 1, NE>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL; }
     }
     DG = 1. / coe[l + 4 * nd];
+    if (NE == 6) C6 = coe[l + 5 * nd];
     if (has_prev) {
       S[0] = rop[l - 1 + nd]; S[1] = rop[l - 1 + 2 * nd]; S[2] = rop[l - 1 + 3 * nd]; S[3] = rop[l - 1 + 4 * nd];
       CR = coe[l - 1 + nd];
       if (m == 0) {   // the cell before the unit belongs to an earlier hyperplane: final
 #pragma unroll
-        for (int e = 0; e < 5; e++) P[e] = dw[l - 1 + e * nd];
+        for (int e = 0; e < NE; e++) P[e] = dw[l - 1 + e * nd];
       }
     }
   }
   // P of lane m holds: before its step, the increment of cell m-1 (lane 0: preloaded); after, its own
   for (int st = 0; st < 8; st++) {
-    double pin[5];
+    double pin[NE];
 #pragma unroll
-    for (int e = 0; e < 5; e++) {
+    for (int e = 0; e < NE; e++) {
       const double up = __shfl_up(P[e], 1, 8);
       pin[e] = m == 0 ? P[e] : up;
     }
     if (m == st && active) {
       if (has_prev) {
-        double b[5];
-        lu_term<FULL, 0, 1>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+        double b[NE];
+        lu_term<FULL, 0, 1, NE>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b, NE == 6 ? pin[NE - 1] : 0.);
 #pragma unroll
-        for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL;
+        for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
       }
 #pragma unroll
       for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
     }
   }
   if (active) {
 #pragma unroll
-    for (int e = 0; e < 5; e++) dw[l + e * nd] = P[e];
+    for (int e = 0; e < NE; e++) dw[l + e * nd] = P[e];
   }
 }
 
-template <bool FULL>
+template <bool FULL, int NE>
 __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
                                                       const double *__restrict__ rop, const double *rop_kn,
                                                       double *rop_new, double *__restrict__ dw,
@@ -494,48 +503,50 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
   const bool has_next = active && i < r.i1;
   const bool last_of_unit = m == 7 || i == r.i1;     // its i+1 neighbour lies outside the unit
-  double A[5] = {0., 0., 0., 0., 0.}, P[5] = {0., 0., 0., 0., 0.}, S[4] = {0., 0., 0., 0.};
-  double CR = 0., XAL = 0., DG = 0.;
-  double q[5] = {1., 0., 0., 0., 1.};
+  double A[NE] = {}, P[NE] = {}, S[4] = {0., 0., 0., 0.};
+  double CR = 0., XAL = 0., DG = 0., C6 = 1.;   // C6 = diagonal of the 6th equation, coe(:,6)
+  double q[NE] = {1., 0., 0., 0., 1.};
   if (active) {
     XAL = coe[l] * -0.5;
     const double c5 = coe[l + 4 * nd];
-    double b[5];
+    double b[NE];
 #pragma unroll
-    for (int e = 0; e < 5; e++) { A[e] = dw[l + e * nd] * c5; q[e] = rop[l + e * nd]; }
-    if (k < r.k1) { lu_neighbour<FULL, 2, -1>(z, c, l, lt, rop_kn, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
-    if (j < r.j1) { lu_neighbour<FULL, 1, -1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL; }
+    for (int e = 0; e < NE; e++) { A[e] = dw[l + e * nd] * c5; q[e] = rop[l + e * nd]; }
+    if (NE == 6) { C6 = coe[l + 5 * nd]; A[NE - 1] = dw[l + 5 * nd] * C6; }   // LU/lu_d_SA.for
+    if (k < r.k1) { lu_neighbour<FULL, 2, -1, NE>(z, c, l, lt, rop_kn, dw, coe, b); for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL; }
+    if (j < r.j1) { lu_neighbour<FULL, 1, -1, NE>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL; }
     DG = 1. / c5;
     if (has_next) {
       S[0] = rop[l + 1 + nd]; S[1] = rop[l + 1 + 2 * nd]; S[2] = rop[l + 1 + 3 * nd]; S[3] = rop[l + 1 + 4 * nd];
       CR = coe[l + 1 + nd];
       if (last_of_unit) {
 #pragma unroll
-        for (int e = 0; e < 5; e++) P[e] = dw[l + 1 + e * nd];
+        for (int e = 0; e < NE; e++) P[e] = dw[l + 1 + e * nd];
       }
     }
   }
   for (int st = 7; st >= 0; st--) {
-    double pin[5];
+    double pin[NE];
 #pragma unroll
-    for (int e = 0; e < 5; e++) {
+    for (int e = 0; e < NE; e++) {
       const double dn = __shfl_down(P[e], 1, 8);
       pin[e] = last_of_unit ? P[e] : dn;
     }
     if (m == st && active) {
       if (has_next) {
-        double b[5];
-        lu_term<FULL, 0, -1>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+        double b[NE];
+        lu_term<FULL, 0, -1, NE>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b, NE == 6 ? pin[NE - 1] : 0.);
 #pragma unroll
-        for (int e = 0; e < 5; e++) A[e] = A[e] + b[e] * XAL;
+        for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
       }
 #pragma unroll
       for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
     }
   }
   if (active) {
 #pragma unroll
-    for (int e = 0; e < 5; e++) dw[l + e * nd] = P[e];
+    for (int e = 0; e < NE; e++) dw[l + e * nd] = P[e];
     // Newton update (mjr_newton.for)
     const double ro_old = q[0], u_old = q[1], v_old = q[2], w_old = q[3], t_old = q[4];
     const double rn = ro_old + P[0];
@@ -545,7 +556,15 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
     const double wn = (ro_old * w_old + P[3]) * r_1;
     const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
     rop_new[l] = rn; rop_new[l + nd] = un; rop_new[l + 2 * nd] = vn; rop_new[l + 3 * nd] = wn;
-    rop_new[l + 4 * nd] = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+    const double tn = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+    rop_new[l + 4 * nd] = tn;
+    if (NE == 6) {   // LU/mjr_newton_SA.for: nu_tilde clipped to [0, ratiom * nu]
+      double anulam = fs_mulam_sa(z, tn);
+      anulam = anulam * r_1 * z.ratiom;
+      double t6 = (ro_old * q[NE - 1] + P[NE - 1]) * r_1;
+      t6 = fs_min(t6, anulam);
+      rop_new[l + 5 * nd] = fs_max(t6, 0.);
+    }
   }
 }
 
@@ -555,8 +574,7 @@ __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const d
   const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x, j = r.j0 + blockIdx.y, k = r.k0 + blockIdx.z;
   if (i > r.i1) return;
   const long long l = lcell(z, i, j, k);
-#pragma unroll
-  for (int e = 0; e < 5; e++) dst[l + e * z.nd] = src[l + e * z.nd];
+  for (int e = 0; e < z.neq; e++) dst[l + e * z.nd] = src[l + e * z.nd];
 }
 
 }  // namespace
@@ -598,7 +616,9 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
   // FASTS_HIP_LU = cell | chunk selects the simpler forms of the sweeps (debugging aids)
   static const bool per_cell = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "cell") == 0;
   static const bool per_chunk = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "chunk") == 0;
-  if (!per_cell && !per_chunk) {
+  const bool sa = z.neq == 6;
+  if (sa && full) return -1;
+  if (sa || (!per_cell && !per_chunk)) {
     const int nchunk = (ni + 7) / 8;
     const int nhc = nchunk + nj + nk - 2;
     const unsigned gx8 = (unsigned)((nj + 7) / 8);
@@ -609,11 +629,13 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
         int khi = h < nk - 1 ? h : nk - 1;
         dim3 g(gx8, (unsigned)(khi - klo + 1));
         if (pass == 0) {
-          if (full) hipLaunchKernelGGL((k_lu_lower_wave<true>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-          else hipLaunchKernelGGL((k_lu_lower_wave<false>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+          if (sa) hipLaunchKernelGGL((k_lu_lower_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+          else if (full) hipLaunchKernelGGL((k_lu_lower_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+          else hipLaunchKernelGGL((k_lu_lower_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
         } else {
-          if (full) hipLaunchKernelGGL((k_lu_upper_wave<true>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-          else hipLaunchKernelGGL((k_lu_upper_wave<false>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+          if (sa) hipLaunchKernelGGL((k_lu_upper_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+          else if (full) hipLaunchKernelGGL((k_lu_upper_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+          else hipLaunchKernelGGL((k_lu_upper_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
         }
       }
   } else if (per_cell) {

@@ -41,8 +41,23 @@ FS_DEV void face_sa(const FsZone &z, const double *__restrict__ rop, const doubl
     }
   }
   double sa[4];
-  fs_flux_inviscid<KFLU, DIR>(z, qm2, qm1, q0, qp1, wg, flu, sa);
-  {   // convective flux of rho*nu_tilde
+  fs_flux_inviscid<KFLU, DIR>(z, qm2, qm1, q0, qp1, wg, flu, KFLU == 5 ? nullptr : sa);
+  if (KFLU == 5) {
+    // roe: first-order upwinding with the Roe-averaged normal velocity (ROE/fluFaceSA.for,
+    // ROE/3dcart/fluFaceSA_o3_3dcart_{i,j,k}.for)
+    constexpr int VN = 1 + DIR;
+    const double tc = DIR == 0 ? z.tcx : (DIR == 1 ? z.tcy : z.tcz);
+    const double s = DIR == 0 ? z.si : (DIR == 1 ? z.sj : z.sk);
+    double qp1r = qm1[0], qm1r = q0[0];
+    const double qn1 = qm1[VN] * tc, qn2 = q0[VN] * tc;
+    const double qm6 = q0[5] * qm1r * qn2, qp6 = qm1[5] * qp1r * qn1;
+    qp1r = sqrt(qp1r); qm1r = sqrt(qm1r);
+    const double r_1 = 1. / (qp1r + qm1r);
+    const double vroe = r_1 * (qp1r * qm1[VN] + qm1r * q0[VN]);
+    const double s_1 = 1. / fs_max(s, 1.e-30);
+    const double tdu = fs_max(z.c1 / s_1, fabs(vroe * tc));
+    flu[5] = 0.5 * (qm6 + qp6 - tdu * (q0[5] * q0[0] - qm1[5] * qm1[0]));
+  } else {   // convective flux of rho*nu_tilde
     const double qm = z.c4 * q0[5] + z.c5 * qm1[5] + z.c6 * qp1[5];
     const double qp = z.c4 * qm1[5] + z.c6 * qm2[5] + z.c5 * q0[5];
     const double qm6 = qm * sa[2], qp6 = qp * sa[3];
@@ -74,8 +89,9 @@ FS_DEV void face_sa(const FsZone &z, const double *__restrict__ rop, const doubl
 }
 
 // vol * (production - destruction + cb2 term) of cell l; qc = state of the cell
+// tsb (may be null) receives production - destruction, amu the clipped rho*nu_tilde (SA/sourceSA_LU.for)
 FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ dlng, long long l,
-                        const double *qc)
+                        const double *qc, double *tsb = nullptr, double *amu = nullptr)
 {
   const double SA_CKARM = 0.41, SA_CB1 = 0.1355, SA_CB2 = 0.622, SA_CV1 = 357.911, SA_CW2 = 0.3, SA_CW3 = 64.;
   const double SA_CW4 = 0.21, SA_CW5 = 1.5, SA_CROT = 2.0, SA_SIGMA = (2. / 3.);
@@ -130,14 +146,17 @@ FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const d
   const double fwg = gg * pow((1. + SA_CW3) / (g6 + SA_CW3), 1. / 6.);
   const double destruc = rc * cw1 * fwg * (anutild / dist) * (anutild / dist);
   const double tsource = (prod + anvisc - destruc);
+  if (tsb) { *tsb = prod - destruc; *amu = fs_max(anutild * rc, 0.0000000000000001); }
   return z.vol0 * tsource;
 }
 
-template <int KFLU, bool FIRST>
+// BDF = false: Runge-Kutta stage.  BDF = true: Newton residual of the implicit scheme, 6 equations
+// (core3as2.for:49-231; rop_out unused).
+template <int KFLU, bool FIRST, bool BDF>
 __global__ void __launch_bounds__(256)
 k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
            double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
-           const double *__restrict__ dlng, unsigned char *__restrict__ wig)
+           const double *__restrict__ dlng, unsigned char *__restrict__ wig, FsBdf bdf)
 {
   __shared__ double sfj[2][NQ][TJ][TI];
   const int ti = threadIdx.x & 31, tj = threadIdx.x >> 5;
@@ -169,9 +188,31 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, const double *__res
       face_sa<KFLU, 2, FIRST>(z, rop, xmut, wig, l, qa, qb, qc, qd, fk);
       if (k > k0) {
         const long long lb = l - z.inck;
-        double d[NQ], o[5];
+        double d[NQ], o[NQ];
 #pragma unroll
-        for (int e = 0; e < NQ; e++) { d[e] = part[e] - fk[e]; drodm[e * nd + lb] = d[e]; }
+        for (int e = 0; e < NQ; e++) d[e] = part[e] - fk[e];
+        if (BDF) {
+          double qn[NQ] = {0., 0., 0., 0., 0., 0.}, qn1[NQ];
+#pragma unroll
+          for (int e = 0; e < NQ; e++) qn1[e] = bdf.ro_n1[e * nd + lb];
+          if (!bdf.nit1) {
+#pragma unroll
+            for (int e = 0; e < NQ; e++) qn[e] = bdf.ro_n[e * nd + lb];
+          }
+          const double coe = bdf.coe1 ? bdf.coe1[lb] : z.coe;
+          if (bdf.nit1 && bdf.coe1) {   // local time step, first sub-iteration: no BDF terms (core3as2.for:57-66)
+#pragma unroll
+            for (int e = 0; e < NQ; e++) o[e] = coe * d[e];
+          } else {
+            fs_bdf_residual(z, bdf, coe, qb, qn, qn1, d, o);
+            if (bdf.nit1) o[5] = coe * d[5] + (bdf.c1 + bdf.c2) * qb[5] * qb[0] + bdf.c3 * qn1[5] * qn1[0];
+            else o[5] = coe * d[5] + bdf.c1 * qb[5] * qb[0] + bdf.c2 * qn[5] * qn[0] + bdf.c3 * qn1[5] * qn1[0];
+          }
+#pragma unroll
+          for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = o[e];
+        } else {
+#pragma unroll
+        for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = d[e];
         fs_rk_update(z, coefW, qb, d, o);
 #pragma unroll
         for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
@@ -183,6 +224,7 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, const double *__res
           double t6 = (qb[0] * qb[5] + tab6) * r_1;
           t6 = fs_min(t6, anulam);
           rop_out[5 * nd + lb] = fs_max(t6, 0.);
+        }
         }
       }
     }
@@ -215,7 +257,7 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, const double *__res
         const double src = sa_source(z, rop, dlng, l, qc);
 #pragma unroll
         for (int e = 0; e < NQ; e++) {
-          double dr = FIRST ? 0. : drodm[e * nd + l] * coefH;
+          double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
           if (e == 5) dr = dr + src;
           part[e] = dr + fk[e] + fjm[e] + fim[e] - fip[e] - sfj[buf][e][tj + 1][ti];
         }
@@ -244,7 +286,32 @@ __global__ void __launch_bounds__(256) k_vispalart(FsZone z, const double *__res
   xmut[l] = amulam + fs_min(xmuprov, z.ratiom * amulam);
 }
 
+// Diagonal of the nu_tilde equation of the implicit scheme, coe(:,6) = coe(:,5) - min(vol*(P-D)/(rho nu_tilde), 0)*coe(:,1)
+// (SA/sourceSA_LU.for), on the interior plus one ghost layer (ind_ssa of indice_boucle_ssdom.for with one cache
+// block): the LU range reaches the first ghost layer on wall faces.
+__global__ void __launch_bounds__(256) k_sa_coe6(FsZone z, const double *__restrict__ rop, const double *__restrict__ dlng,
+                                                 double *__restrict__ coe)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;   // 0 .. iv+1
+  if (i > z.iv + 1) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  double qc[NQ];
+#pragma unroll
+  for (int e = 0; e < NQ; e++) qc[e] = rop[e * nd + l];
+  double tsb, amu;
+  sa_source(z, rop, dlng, l, qc, &tsb, &amu);
+  const double tsourcenu = z.vol0 * tsb / amu;
+  coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
+}
+
 }  // namespace
+
+void fsk_sa_coe6(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s)
+{
+  dim3 g((z.iv + 2 + 255) / 256, z.jv + 2, z.kv + 2);
+  hipLaunchKernelGGL(k_sa_coe6, g, dim3(256), 0, s, z, rop, dist, coe);
+}
 
 void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s)
 {
@@ -253,17 +320,26 @@ void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t
 }
 
 int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                 double *drodm, const double *xmut, const double *dist, unsigned char *wig, hipStream_t s)
+                 double *drodm, const double *xmut, const double *dist, unsigned char *wig, const FsBdf *bdf,
+                 hipStream_t s)
 {
   if (z.ityp != 2 || z.neq != 6 || z.iflow != 3 || !dist) return -1;
   int kchunk = 32;
   if (kchunk > z.kv) kchunk = z.kv;
   dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
-#define FS_GO(K, FIRST_)                                                                                   \
-  hipLaunchKernelGGL((k_stage_sa<K, FIRST_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, drodm, \
-                     xmut, dist, wig)
-  if (z.kflu == 1) { if (first) FS_GO(1, true); else FS_GO(1, false); return 0; }
-  if (z.kflu == 2) { if (first) FS_GO(2, true); else FS_GO(2, false); return 0; }
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
+  if (bdf) b = *bdf;
+#define FS_GO(K, FIRST_, BDF_)                                                                                  \
+  hipLaunchKernelGGL((k_stage_sa<K, FIRST_, BDF_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, drodm, \
+                     xmut, dist, wig, b)
+#define FS_CASE(K)                                                                                              \
+  if (z.kflu == K) {                                                                                            \
+    if (bdf) { if (first) FS_GO(K, true, true); else FS_GO(K, false, true); }                                   \
+    else { if (first) FS_GO(K, true, false); else FS_GO(K, false, false); }                                     \
+    return 0;                                                                                                   \
+  }
+  FS_CASE(1) FS_CASE(2) FS_CASE(5)
+#undef FS_CASE
 #undef FS_GO
   return -1;
 }

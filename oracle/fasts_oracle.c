@@ -297,7 +297,20 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
     flu5 = u * (h1 + h2) - tdu * (h2 - h1);
     u_sa = u; tdu_sa = tdu;
   }
-  if (c->iflow == 3) {   /* convective flux of rho*nu_tilde: AUSM/fluFaceSA.for, SENSOR/fluFaceSA.for */
+  if (c->iflow == 3 && c->kflu == 5) {
+    /* roe: first-order upwinding with the Roe-averaged normal velocity (ROE/fluFaceSA.for,
+     * ROE/3dcart/fluFaceSA_o3_3dcart_{i,j,k}.for, Vit_ent/qn_3dcart_i.for) */
+    const double *q6 = rop + 5 * nd;
+    double qp1 = rop[nm], qm1 = rop[l];
+    const double qn1 = rop[nm + vn * nd] * tc, qn2 = rop[l + vn * nd] * tc;
+    const double qm6 = q6[l] * qm1 * qn2, qp6 = q6[nm] * qp1 * qn1;
+    qp1 = sqrt(qp1); qm1 = sqrt(qm1);
+    const double r_1 = 1. / (qp1 + qm1);
+    const double vroe = r_1 * (qp1 * rop[nm + vn * nd] + qm1 * rop[l + vn * nd]);
+    const double s_1 = 1. / dmax(s, 1.e-30);
+    const double tdu = dmax(c->c1 / s_1, fabs(vroe * tc));
+    flu6 = 0.5 * (qm6 + qp6 - tdu * (q6[l] * rop[l] - q6[nm] * rop[nm]));
+  } else if (c->iflow == 3) {   /* convective flux of rho*nu_tilde: AUSM/fluFaceSA.for, SENSOR/fluFaceSA.for */
     const double *q6 = rop + 5 * nd;
     const double qm_ = c->c4 * q6[l] + c->c5 * q6[nm] + c->c6 * q6[np];
     const double qp_ = c->c4 * q6[nm] + c->c6 * q6[nm2] + c->c5 * q6[l];
@@ -1321,11 +1334,21 @@ void fo_core3as2(const i32 *p, const double *pr, int nitcfg, int first_it, const
   if (first_it == 0 || p[DTLOC] == 1) { c1 = -1.; c2 = 1.; c3 = 0.; }
   else { c1 = -1.5; c2 = 2.; c3 = -0.5; }
   const double c4 = c1 + c2;
+  const int neq = p[NEQ];
   for (int k = ind[4]; k <= ind[5]; k++)
     for (int j = ind[2]; j <= ind[3]; j++)
       for (int i = ind[0]; i <= ind[1]; i++) {
         const long l = INDDM(i, j, k);
 #define Q(a, e) (a)[l + (e) * nd]
+        if (neq == 6) {   /* core3as2.for:49-66,97-99,187-190: nu_tilde equation; local time step: no BDF terms */
+          if (nitcfg == 1 && p[DTLOC] == 1) {
+            for (int e = 0; e < 6; e++) Q(drodm, e) = coe[l] * Q(drodm, e);
+            continue;
+          }
+          if (nitcfg == 1) Q(drodm, 5) = coe[l] * Q(drodm, 5) + c4 * Q(rop, 5) * Q(rop, 0) + c3 * Q(rop_n1, 5) * Q(rop_n1, 0);
+          else Q(drodm, 5) = coe[l] * Q(drodm, 5) + c1 * Q(rop, 5) * Q(rop, 0) + c2 * Q(rop_n, 5) * Q(rop_n, 0) +
+                             c3 * Q(rop_n1, 5) * Q(rop_n1, 0);
+        }
         const double roe = Q(rop, 0) * (cv * Q(rop, 4) + 0.5 * (Q(rop, 1) * Q(rop, 1) + Q(rop, 2) * Q(rop, 2) + Q(rop, 3) * Q(rop, 3)));
         const double roe_n1 = Q(rop_n1, 0) * (cv * Q(rop_n1, 4) + 0.5 * (Q(rop_n1, 1) * Q(rop_n1, 1) + Q(rop_n1, 2) * Q(rop_n1, 2) + Q(rop_n1, 3) * Q(rop_n1, 3)));
         if (nitcfg == 1) {
@@ -1349,7 +1372,7 @@ typedef struct {
   const i32 *p;
   double gam1, gamm1, gam2, cp, signe;
   long nd, inc[3], ndm, minc[3];
-  int full, sgn;              /* sgn = +1 lower sweep (neighbour l - inc), -1 upper sweep (neighbour l + inc) */
+  int full, sgn, neq;         /* sgn = +1 lower sweep (neighbour l - inc), -1 upper sweep (neighbour l + inc) */
   const double *t[3];
   double tcc[3];
 } luctx;
@@ -1370,6 +1393,7 @@ static inline void lu_neighbour(const luctx *c, int d, long l, long lt, const do
   const double ph2 = gamm1 * q2;
   const double cr = coe[l1 + (1 + d) * nd] * signe;
   const double d1 = dw[l1], d2 = dw[l1 + nd], d3 = dw[l1 + 2 * nd], d4 = dw[l1 + 3 * nd], d5 = dw[l1 + 4 * nd];
+  const double d6 = c->neq == 6 ? dw[l1 + 5 * nd] : 0.;   /* scalar 6th equation: LU/lu_i_3dcart_SA.for:37 */
   if (c->full) {
     const double *tt = c->t[d];
     const long ndm = c->ndm;
@@ -1394,6 +1418,7 @@ static inline void lu_neighbour(const luctx *c, int d, long l, long lt, const do
     b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
     b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    b[5] = (qn + cr) * d6;
     return;
   }
   const double tc = c->tcc[d];
@@ -1410,6 +1435,7 @@ static inline void lu_neighbour(const luctx *c, int d, long l, long lt, const do
     b[2] = b31 * d1 + b32 * d2 + b33 * d3;
     b[3] = b41 * d1 + b42 * d2 + b44 * d4;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    b[5] = (qn + cr) * d6;
   } else if (d == 1) {
     const double qn = tc * v;
     const double b11 = cr, b13 = tc, b21 = (-u * qn), b22 = qn + cr, b23 = tc * u;
@@ -1423,6 +1449,7 @@ static inline void lu_neighbour(const luctx *c, int d, long l, long lt, const do
     b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
     b[3] = b41 * d1 + b43 * d3 + b44 * d4;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+    b[5] = (qn + cr) * d6;
   } else {
     const double qn = tc * w;
     const double b11 = cr, b14 = tc, b21 = -u * qn, b22 = qn + cr, b24 = tc * u;
@@ -1436,6 +1463,7 @@ static inline void lu_neighbour(const luctx *c, int d, long l, long lt, const do
     b[2] = b31 * d1 + b33 * d3 + b34 * d4;
     b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
     b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
+     b[5] = (qn + cr) * d6;
   }
 }
 
@@ -1450,6 +1478,7 @@ static void luctx_init(luctx *c, const i32 *p, const double *pr, const double *t
   c->ndm = p[NDIMDX_MTR];
   c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
   c->full = p[ITYPZONE] == 0;
+  c->neq = p[NEQ];
   c->t[0] = ti; c->t[1] = tj; c->t[2] = tk;
   c->tcc[0] = ti[0]; c->tcc[1] = tj[0]; c->tcc[2] = tk[0];
 }
@@ -1466,7 +1495,9 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
 {
   GEOM(p)
   luctx c;
-  double b[5];
+  double b[6];
+  const int neq = p[NEQ];
+  const double *coe6 = coe + 5 * nd;   /* diagonal of the nu_tilde equation (SA/sourceSA_LU.for) */
   const double cvinv = 1. / pr[CVINF], cvinv2 = 0.5 * cvinv;
   const double *coe5 = coe + 4 * nd;
   /* ---- lower ---- */
@@ -1481,7 +1512,7 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
           const int d = order_lo[s];
           if ((d == 1 && j == ind[2]) || (d == 2 && k == ind[4])) continue;
           lu_neighbour(&c, d, l, lt, rop, dw, coe, b);
-          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+          for (int e = 0; e < neq; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
         }
       }
       for (int i = ind[0]; i <= ind[1]; i++) {
@@ -1489,10 +1520,11 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
         if (i > ind[0]) {
           const double xal = coe[l] * c.signe;
           lu_neighbour(&c, 0, l, lt, rop, dw, coe, b);
-          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+          for (int e = 0; e < neq; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
         }
         const double diag = 1. / coe5[l];
         for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] * diag;
+        if (neq == 6) dw[l + 5 * nd] = dw[l + 5 * nd] / coe6[l];   /* LU/lu_dinv_SA.for */
       }
     }
   /* ---- upper + Newton update ---- */
@@ -1504,13 +1536,14 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
         const double xal = coe[l] * c.signe;
         const double diag = coe5[l];
         for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] * diag;
+        if (neq == 6) dw[l + 5 * nd] = dw[l + 5 * nd] * coe6[l];   /* LU/lu_d_SA.for */
         if (k < ind[5]) {
           lu_neighbour(&c, 2, l, lt, rop, dw, coe, b);
-          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+          for (int e = 0; e < neq; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
         }
         if (j < ind[3]) {
           lu_neighbour(&c, 1, l, lt, rop, dw, coe, b);
-          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+          for (int e = 0; e < neq; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
         }
       }
       for (int i = ind[1]; i >= ind[0]; i--) {
@@ -1518,10 +1551,11 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
         if (i < ind[1]) {
           const double xal = coe[l] * c.signe;
           lu_neighbour(&c, 0, l, lt, rop, dw, coe, b);
-          for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
+          for (int e = 0; e < neq; e++) dw[l + e * nd] = dw[l + e * nd] + b[e] * xal;
         }
         const double diag = 1. / coe5[l];
         for (int e = 0; e < 5; e++) dw[l + e * nd] = dw[l + e * nd] * diag;
+        if (neq == 6) dw[l + 5 * nd] = dw[l + 5 * nd] / coe6[l];
       }
     }
     for (int j = ind[2]; j <= ind[3]; j++)
@@ -1538,6 +1572,15 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
         rop_1[l + 4 * nd] = (roe_old + dw[l + 4 * nd]) * r_1 * cvinv -
                             cvinv2 * (rop_1[l + nd] * rop_1[l + nd] + rop_1[l + 2 * nd] * rop_1[l + 2 * nd] +
                                       rop_1[l + 3 * nd] * rop_1[l + 3 * nd]);
+        if (neq == 6) {   /* LU/mjr_newton_SA.for: nu_tilde clipped to [0, ratiom * nu] */
+          const double cmus1 = pr[CS], temp01 = 1. / pr[TEMP0], coesut = pr[XMUL0] * (1. + cmus1 * temp01);
+          const double nu_old = rop[l + 5 * nd];
+          double anulam = coesut * sqrt(rop_1[l + 4 * nd] * temp01) / (1. + cmus1 / rop_1[l + 4 * nd]);
+          anulam = anulam * r_1 * pr[18];
+          double t6 = (ro_old * nu_old + dw[l + 5 * nd]) * r_1;
+          t6 = dmin(t6, anulam);
+          rop_1[l + 5 * nd] = dmax(t6, 0.);
+        }
       }
   }
 }
@@ -1605,17 +1648,24 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   const int f = p[NIJK + 3], fk = p[NIJK + 4];
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
   const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
-  if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[NEQ] != 5) return -1;
+  if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0) return -1;
+  if (p[NEQ] != 5 && !(p[NEQ] == 6 && p[IFLOW] == 3 && p[ITYPZONE] == 2)) return -1;
   const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);
+    if (p[IFLOW] == 3) fo_vispalart(p, pr, all, rop_ss, xmut);
     fo_tstb3_implicit(p, pr, first_it, all, rop_ss, xmut, coe, ti, tj, tk, vol);
   }
   fo_init_rhs(p, nitcfg, sdm, drodm);
+  if (p[IFLOW] == 3) {   /* source term and, at the first sub-iteration, coe(:,6), on the interior plus one
+                          * ghost layer (ind_ssa of indice_boucle_ssdom.for:116-117,156 with one cache block) */
+    const i32 ssa[6] = {0, iv + 1, 0, jv + 1, 0, kv + 1};
+    fo_spsource_SA(p, pr, nitcfg, ssa, rop_ss, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
+  }
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_ss, wig);
   fo_flux(p, pr, sdm, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);
   fo_core3as2(p, pr, nitcfg, first_it, sdm, rop_ss, ro, ro_m1, drodm, coe);
-  if (newton_rhs) memcpy(newton_rhs, drodm, sizeof(double) * 5 * (size_t)p[NDIMDX]);
+  if (newton_rhs) memcpy(newton_rhs, drodm, sizeof(double) * p[NEQ] * (size_t)p[NDIMDX]);
   i32 lu[6];
   if (fo_bczone_rhs(p, drodm, ti, tj, tk, lu)) return -1;
   fo_invlu(p, pr, lu, drodm, rop_ss, ro_p1, ti, tj, tk, coe);

@@ -20,6 +20,7 @@ CASES = [
     ((70, 17, 37), 'senseur', None, 3),
     ((12, 9, 10), 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 6),
     ((10, 9, 8), 'senseur', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, 5),
+    ((12, 10, 9), 'roe', None, 6),
 ]
 
 
@@ -42,6 +43,43 @@ def test_sa_matches_oracle(n, scheme, bcs, nit):
         assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
     d = np.abs(got - ro0).reshape(6, -1).max(axis=1)
     assert np.isfinite(got).all() and d[5] > 1e-7
+
+
+IMPLICIT_CASES = [
+    ((14, 12, 10), 'ausmpred', None, False, 4),
+    ((12, 10, 9), 'senseur', None, False, 4),
+    ((12, 10, 9), 'roe', None, False, 4),
+    ((40, 11, 21), 'ausmpred', None, False, 3),                     # several 8-cell units per line, ragged last unit
+    ((12, 9, 10), 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, False, 4),
+    ((10, 9, 8), 'ausmpred', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, True, 4),
+]
+
+
+@pytest.mark.parametrize("n,scheme,bcs,local,nit", IMPLICIT_CASES)
+def test_sa_implicit_matches_oracle(n, scheme, bcs, local, nit):
+    """6-equation Newton residual, coe(:,6), LU-SGS sweeps with the scalar 6th equation and the clipped Newton
+    update; BDF1 at the first step then BDF2 (or local time step: BDF1 throughout)."""
+    extra = dict(SINGLE)
+    if local:
+        extra.update({'time_step_nature': 'local', 'cfl': 4.})
+    t = cases.tgv(n, scheme, model='NSTurbulent', extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[36]) == 6 and int(pint[29]) == 1
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z))
+    oz.fill_ghostcells()
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, nit + 1):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        e = rel_err(got, oz.ro, int(pint[41]), neq=6)
+        assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+    d = np.abs(got - ro0).reshape(6, -1).max(axis=1)
+    assert np.isfinite(got).all() and d[5] > 1e-7 and d[1] > 1e-4
 
 
 def test_sa_blocks_with_joins():
@@ -71,9 +109,6 @@ def test_sa_blocks_with_joins():
 
 
 def test_sa_options_outside_the_device_path_are_refused():
-    t = cases.tgv(8, 'roe', model='NSTurbulent')
-    with pytest.raises(_capi.FastsHipError, match="Spalart-Allmaras"):
-        FastS.warmup(t, None)
     t = cases.tgv(8, 'senseur', model='NSTurbulent', perturb=0.1)
     with pytest.raises(_capi.FastsHipError, match="Spalart-Allmaras"):
         FastS.warmup(t, None)

@@ -164,6 +164,7 @@ def test_implicit_local_time_step_bit_exact(scheme, model, perturb, bcs):
     ('ausmpred', {'jmin': 'BCWall', 'jmax': 'BCWall'}, (1, 1, 1)),
     ('senseur', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, (1, 1, 1)),
     ('ausmpred', {'jmin': 'BCWall'}, (2, 1, 1)),
+    ('roe', None, (1, 1, 1)),
 ])
 def test_spalart_allmaras_explicit_bit_exact(scheme, bcs, blocks):
     """NSTurbulent on Cartesian zones: total viscosity (vispalart), source term (spsource_SA), convective and
@@ -181,6 +182,39 @@ def test_spalart_allmaras_explicit_bit_exact(scheme, bcs, blocks):
         so.step(); sr.step(it)
         for a, b in zip(so.zones, sr.zones):
             assert np.array_equal(a.ro, b.ro), "step %d" % it
+    d = np.abs(so.zones[0].ro - ro0).reshape(6, -1).max(axis=1)
+    assert np.isfinite(so.zones[0].ro).all() and d[5] > 1e-7 and d[1] > 1e-4
+
+
+@pytest.mark.parametrize("scheme,bcs,blocks,local", [
+    ('ausmpred', None, (1, 1, 1), False),
+    ('senseur', None, (1, 1, 1), False),
+    ('ausmpred', {'jmin': 'BCWall', 'jmax': 'BCWall'}, (1, 1, 1), False),
+    ('roe', None, (1, 1, 1), False),
+    ('ausmpred', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, (1, 1, 1), True),
+    ('ausmpred', {'jmin': 'BCWall'}, (2, 1, 1), False),
+])
+def test_spalart_allmaras_implicit_bit_exact(scheme, bcs, blocks, local):
+    """NSTurbulent + implicit on Cartesian zones: 6-equation Newton residual (core3as2.for:49-231), diagonal of the
+    nu_tilde equation (SA/sourceSA_LU.for), scalar 6th equation of the sweeps (LU/lu_*_3dcart_SA.for,
+    lu_dinv_SA.for, lu_d_SA.for) and the clipped Newton update (LU/mjr_newton_SA.for)."""
+    nn = (10, 8, 8)
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    if local:
+        extra.update({'time_step_nature': 'local', 'cfl': 4.})
+    t = cases.tgv(nn, scheme, model='NSTurbulent', extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                  blocks=blocks, temporal_scheme='implicit', time_step=0.02)
+    nv = tuple(nn[d] // blocks[d] for d in range(3))
+    so, sr = _pair(t, blocks if blocks != (1, 1, 1) else None, nv)
+    assert so.zones[0].neq == 6 and so.zones[0].implicit
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        for a, b in zip(so.zones, sr.zones):
+            assert np.array_equal(a.ro, b.ro), "step %d: %s" % (it, np.abs(a.ro - b.ro).reshape(6, -1).max(axis=1))
     d = np.abs(so.zones[0].ro - ro0).reshape(6, -1).max(axis=1)
     assert np.isfinite(so.zones[0].ro).all() and d[5] > 1e-7 and d[1] > 1e-4
 
