@@ -135,6 +135,47 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
     return t
 
 
+def tgv2d(n=(16, 12), scheme='ausmpred', model='NSLaminar', time_step=None, temporal_scheme='explicit',
+          extra_numz=None, extra_numb=None, bcs=None, perturb=0.):
+    """Two-dimensional zone (one cell along k, no ghost layer along k: zone type 3) on [-pi,pi]^2 with the
+    Taylor-Green fields of the plane z = 0; faces without an entry in bcs are periodic.  perturb displaces the
+    nodes in the plane."""
+    L1 = 2. * math.pi
+    h = [L1 / n[0], L1 / n[1]]
+    z = C.cart((-0.5 * L1 - 2 * h[0], -0.5 * L1 - 2 * h[1], 0.), (h[0], h[1], min(h)), (n[0] + 5, n[1] + 5, 2), name='plane0')
+    if perturb:
+        g = Internal.getNodeFromName1(z, Internal.__GridCoordinates__)
+        xs = [Internal.getNodeFromName1(g, c)[1] for c in ('CoordinateX', 'CoordinateY')]
+        x, y = xs[0].copy(), xs[1].copy()
+        xs[0][...] = x + perturb * h[0] * numpy.sin(y + 0.3) * numpy.cos(x)
+        xs[1][...] = y + perturb * h[1] * numpy.sin(x + 0.7) * numpy.cos(y)
+    faces = ['imin', 'imax', 'jmin', 'jmax']
+    if bcs:
+        for f in [f for f in faces if f in bcs]:
+            C.addBC2Zone(z, bcs[f].lower() + ' ' + f, bcs[f], f)
+        faces = [f for f in faces if f not in bcs]
+    _periodic_faces(z, faces)
+    t = C.newPyTree(['Base', z])
+    C.addState(t, 'GoverningEquations', model)
+    C.addState(t, adim='adim2funk', MInf=0.1, ReInf=1600.)
+    state = C.getState(Internal.getNodeFromName(t, 'ReferenceState'))
+    tgv_fields(t, state)
+    C._initVars(t, 'centers:VelocityZ', 0.)
+    if model in ('NSTurbulent', 'nsspalart'):
+        sa_fields(t, state, [f for f, b in (bcs or {}).items() if b.startswith('BCWall')], L1)
+    if time_step is None:
+        time_step = 0.003 * 32. / max(n)
+    numb = {'temporal_scheme': temporal_scheme, 'modulo_verif': 50}
+    numz = {'time_step': time_step, 'scheme': scheme}
+    if extra_numz:
+        numz.update(extra_numz)
+    if extra_numb:
+        numb.update(extra_numb)
+    FastC._setNum2Zones(t, numz)
+    FastC._setNum2Base(t, numb)
+    return t
+
+
 def vortex(n=64, scheme='roe', time_step=None, extra_numz=None, extra_numb=None):
     """Isentropic vortex (strength beta=5, core radius 1) in a 10^3 periodic box, free
     stream along x at M=0.5, Euler, sound-speed scaling (rho_inf = c_inf = T_inf = 1)."""

@@ -124,12 +124,13 @@ void fo_wiggle(const i32 *p, const i32 *ind, const double *rop, double *wig)
 {
   GEOM(p)
   const long inci = 1, incj = ni, inck = ninj;
-  int icorr = ind[1] == p[IJKV], jcorr = ind[3] == p[IJKV + 1], kcorr = ind[5] == p[IJKV + 2];
+  const int twod = p[ITYPZONE] == 3;   /* wiggle2001.for:61-93: i and j faces only */
+  int icorr = ind[1] == p[IJKV], jcorr = ind[3] == p[IJKV + 1], kcorr = ind[5] == p[IJKV + 2] && !twod;
   for (int k = ind[4]; k <= ind[5]; k++)
     for (int j = ind[2]; j <= ind[3]; j++)
       for (int i = ind[0]; i <= ind[1]; i++) {
         long l = INDDM(i, j, k);
-        wig[l + 2 * nd] = wiggle1(rop, nd, l, inck);
+        if (!twod) wig[l + 2 * nd] = wiggle1(rop, nd, l, inck);
         wig[l + nd] = wiggle1(rop, nd, l, incj);
         wig[l] = wiggle1(rop, nd, l, inci);
       }
@@ -429,7 +430,11 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
   const long nd = c->nd, inc = c->inc[dir], ndm = c->ndm;
   const long nm = l - inc, nm2 = l - 2 * inc, np = l + inc;
   const double *Tn = c->t[dir];
-  const double tcx = Tn[lt], tcy = Tn[lt + ndm], tcz = Tn[lt + 2 * ndm];
+  /* two-dimensional zone (type 3): ti, tj carry 2 components, there is no k direction; its fragments
+   * (Normale/normale_2d_i.for, etat_GD_2d.for, Vit_ent/qn_2d_i.for, fluvector_2d_i.for, fluvisq_2d_i.for, ...)
+   * are the 3dfull ones without the z / w / k terms, i.e. with those terms equal to zero */
+  const int twod = c->ityp == 3;
+  const double tcx = Tn[lt], tcy = Tn[lt + ndm], tcz = twod ? 0. : Tn[lt + 2 * ndm];
   const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
   double qm[5], qp[5];
   for (int e = 0; e < 5; e++) {
@@ -473,7 +478,9 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
     f1 = qn + cc;
     f2 = 0.5 + dsign(0.5, fabs(f1) - f4);
     f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
-    f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
+    /* Vit_ent/fludiffer_2d_j.for:31 multiplies by f3 before the surface */
+    if (twod && dir == 1) f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * f3 * s;
+    else f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
     flu1 = flu1 + f1;
     flu2 = flu2 + f1 * (u + nx * cc);
     flu3 = flu3 + f1 * (v + ny * cc);
@@ -531,22 +538,29 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
     const double *Ta = c->t[a], *Tb = c->t[b];
     const long il = l - inc, ir = l;
     double tn[3], tn1[3], ta[3], ta1[3], tb[3], tb1[3];
+    const int has_a = !(twod && a == 2), has_b = !(twod && b == 2);
     for (int m = 0; m < 3; m++) {
+      tn[m] = tn1[m] = ta[m] = ta1[m] = tb[m] = tb1[m] = 0.;
+      if (twod && m == 2) continue;
       tn[m] = .5 * (Tn[lt + m * ndm] + Tn[lt - md + m * ndm]);
       tn1[m] = .5 * (Tn[lt + m * ndm] + Tn[lt + md + m * ndm]);
-      ta[m] = .125 * (Ta[lt + m * ndm] + Ta[lt - md + m * ndm]);
-      ta1[m] = .125 * (Ta[lt + ma + m * ndm] + Ta[lt - md + ma + m * ndm]);
-      tb[m] = .125 * (Tb[lt + m * ndm] + Tb[lt - md + m * ndm]);
-      tb1[m] = .125 * (Tb[lt + mb + m * ndm] + Tb[lt - md + mb + m * ndm]);
+      if (has_a) {
+        ta[m] = .125 * (Ta[lt + m * ndm] + Ta[lt - md + m * ndm]);
+        ta1[m] = .125 * (Ta[lt + ma + m * ndm] + Ta[lt - md + ma + m * ndm]);
+      }
+      if (has_b) {
+        tb[m] = .125 * (Tb[lt + m * ndm] + Tb[lt - md + m * ndm]);
+        tb1[m] = .125 * (Tb[lt + mb + m * ndm] + Tb[lt - md + mb + m * ndm]);
+      }
     }
     double g[4][3];   /* gradients of u, v, w, T */
     for (int e = 1; e <= 4; e++) {
       const double *q = rop + e * nd;
       double f1 = q[il], f2 = q[ir];
-      double f3 = q[ir] + q[il] + q[il - ia] + q[ir - ia];
-      double f4 = q[ir] + q[il] + q[il + ia] + q[ir + ia];
-      double f5 = q[ir] + q[il] + q[il - ib] + q[ir - ib];
-      double f6 = q[ir] + q[il] + q[il + ib] + q[ir + ib];
+      double f3 = has_a ? q[ir] + q[il] + q[il - ia] + q[ir - ia] : 0.;
+      double f4 = has_a ? q[ir] + q[il] + q[il + ia] + q[ir + ia] : 0.;
+      double f5 = has_b ? q[ir] + q[il] + q[il - ib] + q[ir - ib] : 0.;
+      double f6 = has_b ? q[ir] + q[il] + q[il + ib] + q[ir + ib] : 0.;
       for (int m = 0; m < 3; m++)
         g[e - 1][m] = (f2 * tn1[m] - f1 * tn[m]) + (f4 * ta1[m] - f3 * ta[m]) + (f6 * tb1[m] - f5 * tb[m]);
     }
@@ -582,7 +596,7 @@ static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const doubl
   c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
   /* constants: Fast/FastS/FastS/Compute/template_FluxAndBalance.for:108-156 */
   c->kflu = p[KFLUDOM]; c->iflow = p[IFLOW];
-  c->tcx = ti[0]; c->tcy = tj[0]; c->tcz = tk[0];
+  c->tcx = ti[0]; c->tcy = tj[0]; c->tcz = p[ITYPZONE] == 3 ? 0. : tk[0];
   c->si = fabs(c->tcx); c->sj = fabs(c->tcy); c->sk = fabs(c->tcz);
   c->volinv = 0.5 / vol[0];
   double gam = pr[GAMMA];
@@ -621,12 +635,13 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
   const int neq = p[NEQ];
 #define FACE(l, i, j, k, dir)                                                                     \
   do {                                                                                            \
-    if (c.ityp == 0) face_flux_full(&c, rop, wig, xmut, (l), INDMTR(p, i, j, k), (dir), f);       \
+    if (c.ityp == 0 || c.ityp == 3) face_flux_full(&c, rop, wig, xmut, (l), INDMTR(p, i, j, k), (dir), f); \
     else face_flux(&c, rop, wig, xmut, (l), (dir), f);                                            \
   } while (0)
+  const int twod = c.ityp == 3;
   for (int k = ind[4]; k <= ind[5]; k++) {
     for (int j = ind[2]; j <= ind[3]; j++) {
-      for (int dir = 2; dir >= 0; dir--)
+      for (int dir = twod ? 1 : 2; dir >= 0; dir--)
         for (int i = ind[0]; i <= ind[1]; i++) {
           long l = INDDM(i, j, k), l0 = l - c.inc[dir];
           FACE(l, i, j, k, dir);
@@ -653,7 +668,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
       }
     }
   }
-  for (int j = ind[2]; j <= ind[3]; j++)
+  for (int j = ind[2]; j <= ind[3] && !twod; j++)
     for (int i = ind[0]; i <= ind[1]; i++) {
       long l = INDDM(i, j, ind[5] + 1), ls = l - c.inc[2];
       FACE(l, i, j, ind[5] + 1, 2);
@@ -691,6 +706,7 @@ void fo_core3ark3(const i32 *p, const double *pr, int nitcfg, const i32 *ind, do
         double un = (ro_old * u_old + tab2) * r_1;
         double vn = (ro_old * v_old + tab3) * r_1;
         double wn = (ro_old * w_old + tab4) * r_1;
+        if (p[ITYPZONE] == 3) wn = 0.;   /* core3ark3.for:156-183 */
         rop_1[l + nd] = un; rop_1[l + 2 * nd] = vn; rop_1[l + 3 * nd] = wn;
         double roe_old = ro_old * (cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
         rop_1[l + 4 * nd] = (roe_old + tab5) * r_1 * cvinv - cvinv2 * (un * un + vn * vn + wn * wn);
@@ -924,12 +940,13 @@ void fo_bc_wall_viscous(const i32 *p, int idir, const i32 *cl, double *rop)
 static void fo_bc_metric(const i32 *p, int idir, int i, int j, int k, const double *ti, const double *tj,
                          const double *tk, double *tc)
 {
-  if (p[ITYPZONE] == 0) {
+  if (p[ITYPZONE] == 0 || p[ITYPZONE] == 3) {
     const double *t = idir <= 2 ? ti : (idir <= 4 ? tj : tk);
     int q[3] = {i, j, k};
     if (idir % 2 == 0) q[(idir - 1) / 2] += 1;
     const long lm = INDMTR(p, q[0], q[1], q[2]), ndm = p[NDIMDX_MTR];
-    tc[0] = t[lm] * 1.; tc[1] = t[lm + ndm] * 1.; tc[2] = t[lm + 2 * ndm] * 1.;
+    tc[0] = t[lm] * 1.; tc[1] = t[lm + ndm] * 1.;
+    tc[2] = p[ITYPZONE] == 3 ? t[lm + ndm] * 0. : t[lm + 2 * ndm] * 1.;   /* neq_mtr = 2: kc = 2, ck_mtr = 0 */
     return;
   }
   if (idir <= 2) { tc[0] = ti[0] * 1.; tc[1] = ti[0] * 0.; tc[2] = ti[0] * 0.; }
@@ -1185,7 +1202,8 @@ void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in
 {
   const int iv = p[IJKV], jv = p[IJKV + 1], kv = p[IJKV + 2];
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
-  const i32 grad[6] = {0, iv + 1, 0, jv + 1, 0, kv + 1};
+  const int gk = p[NIJK + 4] > 0;   /* no ghost layer along k on a two-dimensional zone */
+  const i32 grad[6] = {0, iv + 1, 0, jv + 1, 1 - gk, kv + gk};
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, grad, rop_in, xmut);
     if (p[IFLOW] == 3) {   /* navier_stokes_struct.for:237-245: total viscosity on the whole zone */
@@ -1278,9 +1296,10 @@ void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *
   const double gam2 = gamma * rgp;
   const long ndm = p[NDIMDX_MTR];
   const long minc[3] = {p[NIJK_MTR], p[NIJK_MTR + 1], p[NIJK_MTR + 2]};
-  const int full = p[ITYPZONE] == 0;
+  const int twod = p[ITYPZONE] == 3;   /* tstb3_impli.for:315-380: the general formulas without z / w / k terms */
+  const int full = p[ITYPZONE] == 0 || twod;
   const double *T[3] = {ti, tj, tk};
-  double tcc[3] = {ti[0], tj[0], tk[0]}, tc2c[3];
+  double tcc[3] = {ti[0], tj[0], twod ? 0. : tk[0]}, tc2c[3];
   for (int d = 0; d < 3; d++) tc2c[d] = sqrt(tcc[d] * tcc[d]);
   const double volinv = pr[DTC] / vol[0];
   for (int k = ind[4]; k <= ind[5]; k++)
@@ -1293,10 +1312,16 @@ void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *
         const double u = rop[l + nd], v = rop[l + 2 * nd], w = rop[l + 3 * nd];
         const double c = sqrt(gam2 * rop[l + 4 * nd]);
         const double vmu = gam1 * xmut[l], volu = detj * r, xmvis = vmu / volu;
-        double tc2s[3];
-        for (int d = 0; d < 3; d++) {
+        double tc2s[3] = {0., 0., 0.};
+        for (int d = 0; d < (twod ? 2 : 3); d++) {
           double qn, tc2;
-          if (full) {
+          if (twod) {
+            const double *t = T[d];
+            const long lp = lt + minc[d];
+            const double tcx = .5 * (t[lt] + t[lp]), tcy = .5 * (t[lt + ndm] + t[lp + ndm]);
+            tc2 = .5 * (sqrt(t[lt] * t[lt] + t[lt + ndm] * t[lt + ndm]) + sqrt(t[lp] * t[lp] + t[lp + ndm] * t[lp + ndm]));
+            qn = tcx * u + tcy * v;
+          } else if (full) {
             const double *t = T[d];
             const long lp = lt + minc[d];
             const double tcx = .5 * (t[lt] + t[lp]), tcy = .5 * (t[lt + ndm] + t[lp + ndm]);
@@ -1319,7 +1344,8 @@ void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *
           const double dtconv = sqrt(dd) / sp;
           coe[l] = pr[15] * dmin(dtconv, dtvis);
         }
-        coe[l + 4 * nd] = xid + coe[l] * (coe[l + nd] + coe[l + 2 * nd] + coe[l + 3 * nd]) * 0.5;
+        if (twod) coe[l + 4 * nd] = xid + coe[l] * (coe[l + nd] + coe[l + 2 * nd]) * 0.5;
+        else coe[l + 4 * nd] = xid + coe[l] * (coe[l + nd] + coe[l + 2 * nd] + coe[l + 3 * nd]) * 0.5;
       }
 }
 
@@ -1372,7 +1398,7 @@ typedef struct {
   const i32 *p;
   double gam1, gamm1, gam2, cp, signe;
   long nd, inc[3], ndm, minc[3];
-  int full, sgn, neq;         /* sgn = +1 lower sweep (neighbour l - inc), -1 upper sweep (neighbour l + inc) */
+  int full, twod, sgn, neq;   /* sgn = +1 lower sweep (neighbour l - inc), -1 upper sweep (neighbour l + inc) */
   const double *t[3];
   double tcc[3];
 } luctx;
@@ -1402,7 +1428,8 @@ static inline void lu_neighbour(const luctx *c, int d, long l, long lt, const do
     else { lt1 = lt + c->minc[d]; lt2 = lt + 2 * c->minc[d]; }
     const double tcx = 0.5 * (tt[lt2] + tt[lt1]);
     const double tcy = 0.5 * (tt[lt2 + ndm] + tt[lt1 + ndm]);
-    const double tcz = 0.5 * (tt[lt2 + 2 * ndm] + tt[lt1 + 2 * ndm]);
+    /* two-dimensional zone: LU/lu_i_2d.for, lu_j_2d.for = the general terms with tcz = 0, w = 0, dW4 = 0 */
+    const double tcz = c->twod ? 0. : 0.5 * (tt[lt2 + 2 * ndm] + tt[lt1 + 2 * ndm]);
     const double qn = tcx * u + tcy * v + tcz * w;
     const double b11 = cr, b12 = tcx, b13 = tcy, b14 = tcz;
     const double b21 = (tcx * ph2 - u * qn), b22 = (qn - tcx * gam2 * u) + cr;
@@ -1477,10 +1504,11 @@ static void luctx_init(luctx *c, const i32 *p, const double *pr, const double *t
   c->inc[0] = 1; c->inc[1] = p[NIJK]; c->inc[2] = (long)p[NIJK] * p[NIJK + 1];
   c->ndm = p[NDIMDX_MTR];
   c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
-  c->full = p[ITYPZONE] == 0;
+  c->twod = p[ITYPZONE] == 3;
+  c->full = p[ITYPZONE] == 0 || c->twod;
   c->neq = p[NEQ];
   c->t[0] = ti; c->t[1] = tj; c->t[2] = tk;
-  c->tcc[0] = ti[0]; c->tcc[1] = tj[0]; c->tcc[2] = tk[0];
+  c->tcc[0] = ti[0]; c->tcc[1] = tj[0]; c->tcc[2] = c->twod ? 0. : tk[0];
 }
 
 /* LU-SGS on the range ind, in place in dw (the reference's drodm_in and drodm_out are the same array
@@ -1659,7 +1687,8 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   fo_init_rhs(p, nitcfg, sdm, drodm);
   if (p[IFLOW] == 3) {   /* source term and, at the first sub-iteration, coe(:,6), on the interior plus one
                           * ghost layer (ind_ssa of indice_boucle_ssdom.for:116-117,156 with one cache block) */
-    const i32 ssa[6] = {0, iv + 1, 0, jv + 1, 0, kv + 1};
+    const int gk = fk > 0;
+    const i32 ssa[6] = {0, iv + 1, 0, jv + 1, 1 - gk, kv + gk};
     fo_spsource_SA(p, pr, nitcfg, ssa, rop_ss, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
   }
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_ss, wig);

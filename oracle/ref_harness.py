@@ -100,7 +100,7 @@ def ref_metrics(param_int, param_real, x, y, z):
     (loop range (1,1,1,1,1,1), Fast/FastC/FastC/Metric/indice_omp1.h:24-28)."""
     L = lib()
     p = np.ascontiguousarray(param_int, dtype=np.int32)
-    assert p[ITYPZONE] in (0, 2), "ref_metrics: Cartesian and curvilinear zones only"
+    assert p[ITYPZONE] in (0, 2, 3), "ref_metrics: Cartesian, curvilinear and two-dimensional zones only"
     nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
     mtr = np.zeros(nm * (2 * nij + nk + 1))
     ti = mtr[0:nm * nij]; tj = mtr[nm * nij:2 * nm * nij]

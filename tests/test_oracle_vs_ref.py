@@ -219,6 +219,43 @@ def test_spalart_allmaras_implicit_bit_exact(scheme, bcs, blocks, local):
     assert np.isfinite(so.zones[0].ro).all() and d[5] > 1e-7 and d[1] > 1e-4
 
 
+@pytest.mark.parametrize("scheme,model,perturb,bcs,implicit", [
+    ('ausmpred', 'NSLaminar', 0.15, None, False),
+    ('senseur', 'NSLaminar', 0.15, None, False),
+    ('roe', 'Euler', 0.15, None, False),
+    ('senseur', 'Euler', 0., None, False),
+    ('ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, False),
+    ('senseur', 'Euler', 0.15, {'jmin': 'BCWallInviscid', 'imax': 'BCExtrapolate', 'imin': 'BCFarfield'}, False),
+    ('ausmpred', 'NSLaminar', 0.15, None, True),
+    ('roe', 'NSLaminar', 0.15, None, True),
+    ('senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, True),
+    ('ausmpred', 'Euler', 0., {'jmin': 'BCWallInviscid', 'jmax': 'BCFarfield'}, 'local'),
+])
+def test_two_dimensional_zone_bit_exact(scheme, model, perturb, bcs, implicit):
+    """Zone type 3 (one cell along k, ti/tj with two components): 2d flux fragments (fluFaceEuler_o3_2d_*,
+    fluvisq_2d_*), update without w (core3ark3.for:156-183), sensor on i/j faces, and with the implicit scheme
+    tstb3_impli.for:315-380, LU/lu_{i,j}_2d.for, mjr_newton_2d.for."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    kw = {}
+    if implicit:
+        kw = dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})
+        if implicit == 'local':
+            extra.update({'time_step_nature': 'local', 'cfl': 4.})
+    t = cases.tgv2d((10, 8), scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **kw)
+    so, sr = _pair(t)
+    assert int(so.zones[0].pint[25]) == 3
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(5, -1).max(axis=1)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
+
+
 def test_roe_with_walls_is_refused_by_the_oracle():
     """The reference corrects the roe flux on wall faces (BC/bfl3.for); that correction is not
     restated, so the combination is refused rather than computed without it."""
