@@ -227,8 +227,10 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (n_int < 137 || n_real < 41) return fail(ctx, FS_ERR_ARG, "fs_zone_add: Parameter_int/real too short");
   if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_zone_add: zones must be registered before fs_upload");
   const int32_t *p = pint;
-  if (p[ITYPZONE] != 2 && p[ITYPZONE] != 0)
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only Cartesian (zone type 2) and curvilinear (zone type 0) zones are implemented");
+  if (p[ITYPZONE] != 2 && p[ITYPZONE] != 0 && p[ITYPZONE] != 3)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Cartesian (zone type 2), curvilinear (0) and two-dimensional (3) zones are implemented; "
+                "k-homogeneous zones (1) are not");
+  const bool twod = p[ITYPZONE] == 3;
   if (p[ITYPCP] != 2 && p[ITYPCP] != 1) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: temporal scheme must be explicit or implicit");
   const bool implicit = p[ITYPCP] == 1;
   if (!ctx->zones.empty() && implicit != ctx->implicit)
@@ -239,6 +241,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme needs the default stage kernel");
   const bool sa = p[IFLOW] == 3 && p[NEQ] == 6;
   if (!sa && (p[NEQ] != 5 || p[IFLOW] > 2)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: governing equations must be Euler, NSLaminar or NSTurbulent (Spalart-Allmaras)");
+  if (twod && ctx->plain_stage) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two-dimensional zones need the default stage kernels");
   if (sa && (p[ITYPZONE] != 2 || p[47] > 1 || p[SA_DIST] != 1))
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented for Cartesian zones, "
                 "plain SA (no DES variant), with a TurbulentDistance field");
@@ -249,7 +252,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: a local time step (time_step_nature='local') needs the implicit scheme");
   if (!implicit && (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK])) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
   if (implicit && p[NSSITER] < 2) return fail(ctx, FS_ERR_ARG, "fs_zone_add: an implicit step needs at least one Newton sub-iteration (NSSITER >= 2)");
-  if (p[NIJK + 3] != 2 || p[NIJK + 4] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two ghost layers in every direction are required");
+  if (p[NIJK + 3] != 2 || p[NIJK + 4] != (twod ? 0 : 2))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two ghost layers in every direction are required (none along k on a two-dimensional zone)");
   if (n_mtr < 4) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short");
   if (p[ITYPZONE] == 0) {
     // metric arrays dimensioned on the nodes, strides (1, ni+1, (ni+1)(nj+1)) (nature_geom_dom.for:186-503)
@@ -259,8 +263,16 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric layout of a curvilinear zone must be node-dimensioned with 3 components per direction");
     if ((long long)n_mtr < 10 * nn) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short for a curvilinear zone");
   }
+  if (twod) {
+    // ti, tj(NDIMDX_MTR, 2) and vol on the nodes of one k-plane, no tk (nature_geom_dom.for:186-198)
+    const long long nn = (long long)(p[NIJK] + 1) * (p[NIJK + 1] + 1);
+    if (p[NIJK + 2] != 1 || p[IJKV + 2] != 1 || p[NDIMDX_MTR] != nn || p[NEQ_IJ] != 2 || p[NEQ_K] != 0 || p[NIJK_MTR] != 1 ||
+        p[NIJK_MTR + 1] != p[NIJK] + 1 || p[NIJK_MTR + 2] != 0 || p[NIJK_MTR + 3] != 2 || p[NIJK_MTR + 4] != 0)
+      return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric layout of a two-dimensional zone must be node-dimensioned with 2 components per direction");
+    if ((long long)n_mtr < 5 * nn) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short for a two-dimensional zone");
+  }
   if ((long long)p[NIJK] * p[NIJK + 1] * p[NIJK + 2] > p[NDIMDX]) return fail(ctx, FS_ERR_ARG, "fs_zone_add: NDIMDX smaller than the zone");
-  if (p[IJKV] < 4 || p[IJKV + 1] < 4 || p[IJKV + 2] < 4) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: at least 4 interior cells per direction");
+  if (p[IJKV] < 4 || p[IJKV + 1] < 4 || (!twod && p[IJKV + 2] < 4)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: at least 4 interior cells per direction");
 
   Zone zn;
   zn.pint.assign(pint, pint + n_int);
@@ -292,7 +304,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   z.dt = r[DTC];
   z.coe = r[DTC] / mtr[3];  // tstb3_global.for:72-78
   z.vol0 = mtr[3];
-  z.ityp = p[ITYPZONE]; z.ndm = 0; z.mincj = z.minck = 0;
+  // a two-dimensional zone runs through the curvilinear kernels: same formulas with zero z metrics and no k faces
+  z.ityp = twod ? 0 : p[ITYPZONE]; z.twod = twod ? 1 : 0; z.ndm = 0; z.mincj = z.minck = 0;
   z.mt[0] = z.mt[1] = z.mt[2] = z.vol = nullptr;
   if (z.ityp == 0) {
     z.ndm = p[NDIMDX_MTR]; z.mincj = p[NIJK_MTR + 1]; z.minck = p[NIJK_MTR + 2];
@@ -402,7 +415,16 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     (void)hipSetDevice(ctx->device);
     const size_t nb = sizeof(double) * 10 * (size_t)z.ndm;
     HIPCHK(ctx, hipMalloc(&zn.mtr_dev, nb));
-    hipError_t e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
+    hipError_t e;
+    if (twod) {   // expand [ti(2) | tj(2) | vol] to [ti(3) | tj(3) | tk(3) | vol] with zero z components and zero tk
+      std::vector<double> full(10 * (size_t)z.ndm, 0.);
+      const size_t n = (size_t)z.ndm;
+      memcpy(&full[0], mtr, sizeof(double) * 2 * n);
+      memcpy(&full[3 * n], mtr + 2 * n, sizeof(double) * 2 * n);
+      memcpy(&full[9 * n], mtr + 4 * n, sizeof(double) * n);
+      e = hipMemcpy(zn.mtr_dev, full.data(), nb, hipMemcpyHostToDevice);
+    } else
+      e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);

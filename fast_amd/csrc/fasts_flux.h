@@ -40,6 +40,8 @@ struct FsZone {
   // curvilinear zones (ityp 0): device arrays ti,tj,tk(ndm,3) and vol(ndm), dimensioned on the nodes;
   // metric index of cell (i,j,k) = (i+ific-1) + (j+ific-1)*mincj + (k+ifick-1)*minck
   int ityp;
+  int twod;                // two-dimensional zone (one cell along k, no k faces); handled as a curvilinear zone
+                           // whose surface vectors have a zero z component and whose tk is zero
   long long ndm, mincj, minck;
   const double *mt[3];
   const double *vol;
@@ -186,9 +188,11 @@ FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *q
 
 // Inviscid flux of a curvilinear zone: (tcx,tcy,tcz) = surface vector of the face between the cells
 // of qm1_ and q0.  Same expressions for the three directions.
+// f3_first: operand order of the j faces of a two-dimensional zone (Vit_ent/fludiffer_2d_j.for:31).
 template <int KFLU>
 FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, double tcz, const double *qm2,
-                                  const double *qm1_, const double *q0, const double *qp1_, double wg, double *flu)
+                                  const double *qm1_, const double *q0, const double *qp1_, double wg, double *flu,
+                                  bool f3_first = false)
 {
   const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
   double qm[5], qp[5];
@@ -233,7 +237,8 @@ FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, doubl
     f1 = qn + cc;
     f2 = .5 + fs_sign(.5, fabs(f1) - f4);
     f3 = (f2 - 1.) * (f1 * f1 / f4 + f4) * 0.5 - f2 * fabs(f1);
-    f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
+    if (f3_first) f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * f3 * s;
+    else f1 = (dp + r * cc * dqn * s_1) / (2. * cc * cc) * s * f3;
     flu1 = flu1 + f1;
     flu2 = flu2 + f1 * (u + nx * cc);
     flu3 = flu3 + f1 * (v + ny * cc);

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_invist(FsZone z, int depth, const doubl
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x + 1 - depth;  // 1-depth .. iv+depth
   const int j = blockIdx.y + 1 - depth;
-  const int k = blockIdx.z + 1 - depth;
+  const int k = blockIdx.z + 1 - (depth < z.ifick ? depth : z.ifick);   // no ghost layer along k on a 2-D zone
   if (i > z.iv + depth) return;
   long long l = fs_inddm(z, i, j, k);
   xmut[l] = fs_sutherland(z, rop[4 * z.nd + l]);
@@ -482,7 +482,7 @@ static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b
 
 void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s)
 {
-  dim3 g(cdiv(z.iv + 2 * depth, 256), z.jv + 2 * depth, z.kv + 2 * depth);
+  dim3 g(cdiv(z.iv + 2 * depth, 256), z.jv + 2 * depth, z.kv + 2 * (depth < z.ifick ? depth : z.ifick));
   hipLaunchKernelGGL(k_invist, g, dim3(256), 0, s, z, depth, rop, xmut);
 }
 

@@ -27,7 +27,9 @@ template <int DIR> FS_DEV long long minc_of(const FsZone &z) { return DIR == 0 ?
 
 // Face between cell l - inc(DIR) and cell l.  qm2..qp1 = the four cells of the MUSCL stencil.
 // FIRST: the sensor of the face is evaluated from the stencil and stored (0/1 byte); later stages read it.
-template <int KFLU, int IFLOW, int DIR, bool FIRST>
+// TWOD: two-dimensional zone; the k stride of the field is taken as 0 (the cross terms along k then read the
+// cell itself and meet zero metrics: they vanish exactly, as in the reference's 2d fragments fluvisq_2d_{i,j}.for).
+template <int KFLU, int IFLOW, int DIR, bool FIRST, bool TWOD>
 FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
                       unsigned char *__restrict__ wig, long long l, long long lt, const double *qm2,
                       const double *qm1, const double *q0, const double *qp1, double *flu)
@@ -45,10 +47,10 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
       wg = (double)wig[DIR * nd + l];
     }
   }
-  fs_flux_inviscid_full<KFLU>(z, tcx, tcy, tcz, qm2, qm1, q0, qp1, wg, flu);
+  fs_flux_inviscid_full<KFLU>(z, tcx, tcy, tcz, qm2, qm1, q0, qp1, wg, flu, TWOD && DIR == 1);
   if (IFLOW == 2) {
     constexpr int A = (DIR + 1) % 3, B = (DIR + 2) % 3;
-    const long long inc = inc_of<DIR>(z), ia = inc_of<A>(z), ib = inc_of<B>(z);
+    const long long inc = inc_of<DIR>(z), ia = (TWOD && A == 2) ? 0 : inc_of<A>(z), ib = (TWOD && B == 2) ? 0 : inc_of<B>(z);
     const long long md = minc_of<DIR>(z), ma = minc_of<A>(z), mb = minc_of<B>(z);
     auto q = [&](int e, int da, int db, int dn) -> double {
       if (da == 0 && db == 0) return dn == 0 ? q0[e] : qm1[e];
@@ -65,7 +67,8 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
 }
 
 // BDF = false: Runge-Kutta stage.  BDF = true: Newton residual of the implicit scheme (rop_out unused).
-template <int KFLU, int IFLOW, bool FIRST, bool BDF>
+// TWOD: one plane, no k faces: the cell is finished in the same step (+Fj- +Fi- -Fi+ -Fj+).
+template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD>
 __global__ void __launch_bounds__(256)
 k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
@@ -89,25 +92,23 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
   double qa[5], qb[5], qc[5], qd[5];   // own column at k-2, k-1, k, k+1
 #pragma unroll
   for (int e = 0; e < 5; e++) {
-    qa[e] = rop[e * nd + l - 2 * z.inck];
-    qb[e] = rop[e * nd + l - z.inck];
+    qa[e] = TWOD ? 0. : rop[e * nd + l - 2 * z.inck];
+    qb[e] = TWOD ? 0. : rop[e * nd + l - z.inck];
     qc[e] = rop[e * nd + l];
     qd[e] = 0.;
   }
   double part[5] = {0., 0., 0., 0., 0.};
-  for (int k = k0; k <= k1 + 1; k++) {
-    const bool last = k > k1;
+  for (int k = k0; k <= (TWOD ? k0 : k1 + 1); k++) {
+    const bool last = !TWOD && k > k1;
+    if (!TWOD) {
 #pragma unroll
-    for (int e = 0; e < 5; e++) qd[e] = rop[e * nd + l + z.inck];
+      for (int e = 0; e < 5; e++) qd[e] = rop[e * nd + l + z.inck];
+    }
     double fk[5] = {0., 0., 0., 0., 0.};
-    if (own) {
-      face_full<KFLU, IFLOW, 2, FIRST>(z, rop, xmut, wig, l, lt, qa, qb, qc, qd, fk);
-      if (k > k0) {   // the cell below is complete
-        const long long lb = l - z.inck;
-        double d[5], o[5];
-#pragma unroll
-        for (int e = 0; e < 5; e++) d[e] = part[e] - fk[e];
-        const double coe = z.dt / z.vol[lt - z.minck];
+    // finish: the balance of a cell is complete (3-D: cell k-1 once its k+1/2 face is known; 2-D: the cell itself)
+    auto finish = [&](long long lb, long long ltb, const double *qcell, const double *d) {
+        double o[5];
+        const double coe = z.dt / z.vol[ltb];
         if (BDF) {
           double qn[5] = {0., 0., 0., 0., 0.}, qn1[5];
 #pragma unroll
@@ -116,16 +117,25 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
 #pragma unroll
             for (int e = 0; e < 5; e++) qn[e] = bdf.ro_n[e * nd + lb];
           }
-          fs_bdf_residual(z, bdf, bdf.coe1 ? bdf.coe1[lb] : coe, qb, qn, qn1, d, o);
+          fs_bdf_residual(z, bdf, bdf.coe1 ? bdf.coe1[lb] : coe, qcell, qn, qn1, d, o);
 #pragma unroll
           for (int e = 0; e < 5; e++) drodm[e * nd + lb] = o[e];
         } else {
 #pragma unroll
           for (int e = 0; e < 5; e++) drodm[e * nd + lb] = d[e];
-          fs_rk_update_c(z, coefW, coe, qb, d, o);
+          fs_rk_update_c(z, coefW, coe, qcell, d, o);
+          if (TWOD) o[3] = 0.;   // core3ark3.for:156-183
 #pragma unroll
           for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
         }
+    };
+    if (own && !TWOD) {
+      face_full<KFLU, IFLOW, 2, FIRST, TWOD>(z, rop, xmut, wig, l, lt, qa, qb, qc, qd, fk);
+      if (k > k0) {   // the cell below is complete
+        double d[5];
+#pragma unroll
+        for (int e = 0; e < 5; e++) d[e] = part[e] - fk[e];
+        finish(l - z.inck, lt - z.minck, qb, d);
       }
     }
     if (!last) {
@@ -136,7 +146,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
         for (int e = 0; e < 5; e++) {
           m2[e] = rop[e * nd + l - 2 * z.incj]; m1[e] = rop[e * nd + l - z.incj]; p1[e] = rop[e * nd + l + z.incj];
         }
-        face_full<KFLU, IFLOW, 1, FIRST>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
+        face_full<KFLU, IFLOW, 1, FIRST, TWOD>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
       }
       const int buf = (k - k0) & 1;
 #pragma unroll
@@ -147,7 +157,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
         for (int e = 0; e < 5; e++) {
           m2[e] = rop[e * nd + l - 2]; m1[e] = rop[e * nd + l - 1]; p1[e] = rop[e * nd + l + 1];
         }
-        face_full<KFLU, IFLOW, 0, FIRST>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fim);
+        face_full<KFLU, IFLOW, 0, FIRST, TWOD>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fim);
       }
       double fip[5];
 #pragma unroll
@@ -159,6 +169,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
           const double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
           part[e] = dr + fk[e] + fjm[e] + fim[e] - fip[e] - sfj[buf][e][tj + 1][ti];
         }
+        if (TWOD) finish(l, lt, qc, part);
       }
     }
 #pragma unroll
@@ -183,8 +194,14 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
 #define FS_GO(K, F, FIRST_, BDF_)                                                                             \
-  hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, \
-                     drodm, xmut, wig, b)
+  do {                                                                                                        \
+    if (z.twod)                                                                                               \
+      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop,  \
+                         rop_out, drodm, xmut, wig, b);                                                       \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, \
+                         rop_out, drodm, xmut, wig, b);                                                       \
+  } while (0)
 #define FS_CASE(K, F)                                                                                         \
   if (z.kflu == K && z.iflow == F) {                                                                          \
     if (bdf) { if (first) FS_GO(K, F, true, true); else FS_GO(K, F, false, true); }                           \
