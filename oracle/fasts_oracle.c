@@ -442,7 +442,7 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
     qm[e] = c->c4 * q[l] + c->c5 * q[nm] + c->c6 * q[np];
     qp[e] = c->c4 * q[nm] + c->c6 * q[nm2] + c->c5 * q[l];
   }
-  double flu1, flu2, flu3, flu4, flu5;
+  double flu1, flu2, flu3, flu4, flu5, flu6 = 0., u_sa = 0., tdu_sa = 0.;
   if (c->kflu == 5) {
     const double gam = c->gam, rgp = c->rgp, gam1 = c->gam1, psiroe = c->psiroe;
     double r1 = qp[0], p1 = r1 * qp[4] * rgp;
@@ -530,8 +530,32 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
     flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1) + tcy * p1p2;
     flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tcz * p1p2;
     flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+    u_sa = u; tdu_sa = tdu;
   }
-  if (c->iflow == 2) {
+  if (c->iflow == 3 && c->kflu == 5) {
+    /* ROE/fluFaceSA.for with Vit_ent/qn_3dfull_i.for: first-order states, Roe-averaged normal velocity */
+    const double *q6 = rop + 5 * nd;
+    double qp1 = rop[nm], qm1 = rop[l];
+    double qp2 = rop[nm + nd], qp3 = rop[nm + 2 * nd], qp4 = rop[nm + 3 * nd];
+    const double qm2 = rop[l + nd], qm3 = rop[l + 2 * nd], qm4 = rop[l + 3 * nd];
+    double qn1 = qp2 * tcx + qp3 * tcy + qp4 * tcz;
+    const double qn2 = qm2 * tcx + qm3 * tcy + qm4 * tcz;
+    const double qm6 = q6[l] * qm1 * qn2, qp6 = q6[nm] * qp1 * qn1;
+    qp1 = sqrt(qp1); qm1 = sqrt(qm1);
+    const double r_1 = 1. / (qp1 + qm1);
+    qp2 = r_1 * (qp1 * qp2 + qm1 * qm2); qp3 = r_1 * (qp1 * qp3 + qm1 * qm3); qp4 = r_1 * (qp1 * qp4 + qm1 * qm4);
+    qn1 = qp2 * tcx + qp3 * tcy + qp4 * tcz;
+    const double s_1 = 1. / dmax(s, 1.e-30);
+    const double tdu = dmax(c->c1 / s_1, fabs(qn1));
+    flu6 = 0.5 * (qm6 + qp6 - tdu * (q6[l] * rop[l] - q6[nm] * rop[nm]));
+  } else if (c->iflow == 3) {   /* AUSM/fluFaceSA.for, SENSOR/fluFaceSA.for */
+    const double *q6 = rop + 5 * nd;
+    const double qm_ = c->c4 * q6[l] + c->c5 * q6[nm] + c->c6 * q6[np];
+    const double qp_ = c->c4 * q6[nm] + c->c6 * q6[nm2] + c->c5 * q6[l];
+    const double qm6 = qm_ * qm[0], qp6 = qp_ * qp[0];
+    flu6 = u_sa * (qm6 + qp6) - tdu_sa * (qm6 - qp6);
+  }
+  if (c->iflow >= 2) {
     const int a = (dir + 1) % 3, b = (dir + 2) % 3;
     const long ia = c->inc[a], ib = c->inc[b];
     const long md = c->minc[dir], ma = c->minc[a], mb = c->minc[b];
@@ -553,8 +577,8 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
         tb1[m] = .125 * (Tb[lt + mb + m * ndm] + Tb[lt - md + mb + m * ndm]);
       }
     }
-    double g[4][3];   /* gradients of u, v, w, T */
-    for (int e = 1; e <= 4; e++) {
+    double g[5][3];   /* gradients of u, v, w, T (and nu_tilde: SA/fluvisq_SA_3dfull_i.for) */
+    for (int e = 1; e <= (c->iflow == 3 ? 5 : 4); e++) {
       const double *q = rop + e * nd;
       double f1 = q[il], f2 = q[ir];
       double f3 = has_a ? q[ir] + q[il] + q[il - ia] + q[ir - ia] : 0.;
@@ -571,6 +595,16 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
     double volinv = 1. / (c->vol[lt] + c->vol[lt - md]);
     double xmutvol = (xmut[ir] + xmut[il]) * volinv;
     double xktvol = xmutvol * c->gam3;
+    double xmulam = 0.;
+    if (c->iflow == 3) {   /* mut_prandtltb_interface.for */
+      const double *T = rop + 4 * nd;
+      xmulam = c->coesut_sa * sqrt(T[il] * c->temp01) / (1. + c->cmus1 / T[il]);
+      xmulam = xmulam + c->coesut_sa * sqrt(T[ir] * c->temp01) / (1. + c->cmus1 / T[ir]);
+      const double xmutot = xmut[ir] + xmut[il];
+      const double xmutur = xmutot - xmulam;
+      xktvol = (xmulam * c->gam3 + xmutur * c->gam4) * volinv;
+      xmutvol = xmutot * volinv;
+    }
     double fv, fv5;
     fv = -(2. * f1 * tcx + f2 * tcy + f3 * tcz) * xmutvol;
     fv5 = fv * (U[ir] + U[il]);
@@ -583,8 +617,15 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
     flu4 = flu4 + fv;
     fv = fv5 * 0.5 - (g[3][0] * tcx + g[3][1] * tcy + g[3][2] * tcz) * xktvol;
     flu5 = flu5 + fv;
+    if (c->iflow == 3) {   /* SA/mut_interface.for, SA/assemble_tauij_3dfull.for, SA/fluvisq_SA_2d_i.for */
+      const double *R = rop, *N = rop + 5 * nd;
+      double xm = xmulam + N[il] * R[il] + N[ir] * R[ir];
+      xm = xm * volinv * c->sigma_1;
+      flu6 = flu6 - xm * (g[4][0] * tcx + g[4][1] * tcy + g[4][2] * tcz);
+    }
   }
   flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
+  if (c->iflow == 3) flu[5] = flu6;
 }
 
 static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const double *ti,
@@ -763,35 +804,65 @@ void fo_spsource_SA(const i32 *p, const double *pr, int nitcfg, const i32 *ind, 
   const double c1 = SA_CB2 / SA_SIGMA;
   const double cw1 = (SA_CB1 / SA_CKARM / SA_CKARM) + (1. + SA_CB2) / SA_SIGMA;
   const long incj = ni, inck = ninj;
-  const double tix = ti[0], tjy = tj[0], tkz = tk[0];
-  const double xvol = 0.5 / vol[0];
+  const int cart = p[ITYPZONE] == 2, twod = p[ITYPZONE] == 3;
+  const double tix = ti[0], tjy = tj[0], tkz = cart ? tk[0] : 0.;
+  double xvol = 0.5 / vol[0];
+  const long ndm = p[NDIMDX_MTR];
+  const long minc[3] = {p[NIJK_MTR], p[NIJK_MTR + 1], p[NIJK_MTR + 2]};
+  const double *T[3] = {ti, tj, tk};
   const int store = p[ITYPCP] <= 1 && nitcfg <= 1;
   for (int k = ind[4]; k <= ind[5]; k++)
     for (int j = ind[2]; j <= ind[3]; j++)
       for (int i = ind[0]; i <= ind[1]; i++) {
         const long l = INDDM(i, j, k);
-        const long l1 = l + 1, l2 = l - 1, l3 = l + incj, l4 = l - incj, l5 = l + inck, l6 = l - inck;
+        const long l1 = l + 1, l2 = l - 1, l3 = l + incj, l4 = l - incj;
+        const long l5 = twod ? l : l + inck, l6 = twod ? l : l - inck;   /* no k neighbours on a 2-D zone */
+        const long lt = cart ? 0 : INDMTR(p, i, j, k);
+        /* surface vectors of the six faces of the cell: t0[d][m] at lt, t1[d][m] at lt + inc_mtr(d)
+         * (SA/sourceSA_grad_3d.for:2-21, sourceSA_grad_2d.for: no z component, no k faces) */
+        double t0[3][3], t1[3][3];
+        if (!cart) {
+          for (int d = 0; d < 3; d++)
+            for (int m = 0; m < 3; m++) {
+              const int have = twod ? (d < 2 && m < 2) : 1;
+              t0[d][m] = have ? T[d][lt + m * ndm] : 0.;
+              t1[d][m] = have ? T[d][lt + minc[d] + m * ndm] : 0.;
+            }
+          xvol = 0.5 / vol[lt];
+        }
+#define GRAD(u1, u2, u3, u4, u5, u6, m) \
+  (twod ? ((u3) * t1[0][m] - (u1) * t0[0][m] + (u2) * t1[1][m] - (u4) * t0[1][m])    \
+        : ((u3) * t1[0][m] - (u1) * t0[0][m] + (u2) * t1[1][m] - (u4) * t0[1][m] + (u5) * t1[2][m] - (u6) * t0[2][m]))
         double g[3][3];   /* g[v][d]: d(u,v,w)/d(x,y,z) times 2*vol */
         for (int v = 0; v < 3; v++) {
           const double *q = rop + (1 + v) * nd;
           const double u1 = (q[l] + q[l2]), u2 = (q[l] + q[l3]), u3 = (q[l] + q[l1]);
           const double u4 = (q[l] + q[l4]), u5 = (q[l] + q[l5]), u6 = (q[l] + q[l6]);
-          g[v][0] = (u3 - u1) * tix; g[v][1] = (u2 - u4) * tjy; g[v][2] = (u5 - u6) * tkz;
+          if (cart) { g[v][0] = (u3 - u1) * tix; g[v][1] = (u2 - u4) * tjy; g[v][2] = (u5 - u6) * tkz; }
+          else if (twod && v == 2) { g[v][0] = g[v][1] = g[v][2] = 0.; }
+          else for (int m = 0; m < 3; m++) g[v][m] = (twod && m == 2) ? 0. : GRAD(u1, u2, u3, u4, u5, u6, m);
         }
         const double rotx = g[2][1] - g[1][2], roty = g[0][2] - g[2][0], rotz = g[1][0] - g[0][1];
-        const double rot = sqrt(rotx * rotx + roty * roty + rotz * rotz) * xvol;
+        const double rot = (twod ? fabs(rotz) : sqrt(rotx * rotx + roty * roty + rotz * rotz)) * xvol;
         const double S11 = g[0][0], S22 = g[1][1], S33 = g[2][2];
         const double S12 = 0.5 * (g[0][1] + g[1][0]), S13 = 0.5 * (g[0][2] + g[2][0]), S23 = 0.5 * (g[1][2] + g[2][1]);
-        double St = S11 * S11 + S22 * S22 + S33 * S33 + 2 * (S12 * S12) + 2 * (S13 * S13) + 2 * (S23 * S23);
+        double St = twod ? S11 * S11 + S22 * S22 + 2 * (S12 * S12)
+                         : S11 * S11 + S22 * S22 + S33 * S33 + 2 * (S12 * S12) + 2 * (S13 * S13) + 2 * (S23 * S23);
         St = sqrt(2 * St) * xvol;
         const double *N = rop + 5 * nd, *R = rop;
         double u1 = (N[l] + N[l2]), u2 = (N[l] + N[l3]), u3 = (N[l] + N[l1]);
         double u4 = (N[l] + N[l4]), u5 = (N[l] + N[l5]), u6 = (N[l] + N[l6]);
-        double dudx = (u3 - u1) * tix, dudy = (u2 - u4) * tjy, dudz = (u5 - u6) * tkz;
+        double dudx, dudy, dudz;
+        if (cart) { dudx = (u3 - u1) * tix; dudy = (u2 - u4) * tjy; dudz = (u5 - u6) * tkz; }
+        else { dudx = GRAD(u1, u2, u3, u4, u5, u6, 0); dudy = GRAD(u1, u2, u3, u4, u5, u6, 1); dudz = twod ? 0. : GRAD(u1, u2, u3, u4, u5, u6, 2); }
         u1 = N[l] * R[l] + N[l2] * R[l2]; u2 = N[l] * R[l] + N[l3] * R[l3]; u3 = N[l] * R[l] + N[l1] * R[l1];
         u4 = N[l] * R[l] + N[l4] * R[l4]; u5 = N[l] * R[l] + N[l5] * R[l5]; u6 = N[l] * R[l] + N[l6] * R[l6];
-        dudx = dudx * (u3 - u1) * tix; dudy = dudy * (u2 - u4) * tjy; dudz = dudz * (u5 - u6) * tkz;
-        const double anvisc = c1 * (dudx + dudy + dudz) * xvol * xvol;
+        if (cart) { dudx = dudx * (u3 - u1) * tix; dudy = dudy * (u2 - u4) * tjy; dudz = dudz * (u5 - u6) * tkz; }
+        else {
+          dudx = dudx * GRAD(u1, u2, u3, u4, u5, u6, 0); dudy = dudy * GRAD(u1, u2, u3, u4, u5, u6, 1);
+          dudz = twod ? 0. : dudz * GRAD(u1, u2, u3, u4, u5, u6, 2);
+        }
+        const double anvisc = twod ? c1 * (dudx + dudy) * xvol * xvol : c1 * (dudx + dudy + dudz) * xvol * xvol;
         const double T = rop[l + 4 * nd];
         const double amulam = coesut * sqrt(T * temp01) / (1. + cmus1 / T);
         const double anulam = rop[l] / amulam;
@@ -818,11 +889,12 @@ void fo_spsource_SA(const i32 *p, const double *pr, int nitcfg, const i32 *ind, 
           const double tsourceb = prod - destruc;
           double amutild = anutild * rop[l];
           amutild = dmax(amutild, 0.0000000000000001);
-          const double tsourcenu = vol[0] * tsourceb / amutild;
+          const double tsourcenu = vol[lt] * tsourceb / amutild;
           coe[l + 5 * nd] = coe[l + 4 * nd] - dmin(tsourcenu, 0.) * coe[l];
         }
-        drodm[l + 5 * nd] = drodm[l + 5 * nd] + vol[0] * tsource;
+        drodm[l + 5 * nd] = drodm[l + 5 * nd] + vol[lt] * tsource;
       }
+#undef GRAD
 }
 
 /* Ghost range of a BC window, no corner overflow (npass = 0)
@@ -1677,7 +1749,7 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
   const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
   if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0) return -1;
-  if (p[NEQ] != 5 && !(p[NEQ] == 6 && p[IFLOW] == 3 && p[ITYPZONE] == 2)) return -1;
+  if (p[NEQ] != 5 && !(p[NEQ] == 6 && p[IFLOW] == 3)) return -1;
   const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);

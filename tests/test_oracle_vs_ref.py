@@ -256,6 +256,51 @@ def test_two_dimensional_zone_bit_exact(scheme, model, perturb, bcs, implicit):
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
 
 
+@pytest.mark.parametrize("dim,scheme,bcs,implicit", [
+    (3, 'ausmpred', None, False),
+    (3, 'senseur', None, False),
+    (3, 'roe', None, False),
+    (3, 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, False),
+    (3, 'ausmpred', None, True),
+    (3, 'roe', None, True),
+    (3, 'senseur', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, True),
+    (2, 'ausmpred', None, False),
+    (2, 'senseur', None, False),
+    (2, 'roe', None, False),
+    (2, 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, False),
+    (2, 'ausmpred', None, True),
+    (2, 'roe', None, True),
+    (2, 'senseur', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, True),
+    (2, 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 'local'),
+])
+def test_spalart_allmaras_general_mesh_bit_exact(dim, scheme, bcs, implicit):
+    """NSTurbulent on curvilinear (type 0) and two-dimensional (type 3) zones: SA/sourceSA_grad_3d.for /
+    sourceSA_grad_2d.for, SA/fluvisq_3dfull_*.for + fluvisq_SA_3dfull_*.for (2d: fluvisq_SA_2d_*.for),
+    ROE|AUSM|SENSOR/fluFaceSA.for, and with the implicit scheme the 6-equation LU-SGS."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    kw = {}
+    if implicit:
+        kw = dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})
+        if implicit == 'local':
+            extra.update({'time_step_nature': 'local', 'cfl': 4.})
+    if dim == 3:
+        t = cases.tgv((10, 8, 8), scheme, model='NSTurbulent', extra_numz=extra, bcs=bcs, perturb=0.15, **kw)
+    else:
+        t = cases.tgv2d((10, 8), scheme, model='NSTurbulent', extra_numz=extra, bcs=bcs, perturb=0.15, **kw)
+    so, sr = _pair(t)
+    assert so.zones[0].neq == 6 and int(so.zones[0].pint[25]) == (0 if dim == 3 else 3)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(6, -1).max(axis=1)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
+    d = np.abs(so.zones[0].ro - ro0).reshape(6, -1).max(axis=1)
+    assert np.isfinite(so.zones[0].ro).all() and d[5] > 1e-7 and d[1] > 1e-4
+
+
 def test_roe_with_walls_is_refused_by_the_oracle():
     """The reference corrects the roe flux on wall faces (BC/bfl3.for); that correction is not
     restated, so the combination is refused rather than computed without it."""
