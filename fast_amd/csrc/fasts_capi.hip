@@ -242,9 +242,9 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   const bool sa = p[IFLOW] == 3 && p[NEQ] == 6;
   if (!sa && (p[NEQ] != 5 || p[IFLOW] > 2)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: governing equations must be Euler, NSLaminar or NSTurbulent (Spalart-Allmaras)");
   if (twod && ctx->plain_stage) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two-dimensional zones need the default stage kernels");
-  if (sa && (p[ITYPZONE] != 2 || p[47] > 1 || p[SA_DIST] != 1))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented for Cartesian zones, "
-                "plain SA (no DES variant), with a TurbulentDistance field");
+  if (sa && (p[47] > 1 || p[SA_DIST] != 1))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented as plain SA (no DES variant), "
+                "with a TurbulentDistance field");
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
   if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
@@ -677,7 +677,10 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
         const double *r = zn.preal.data();
         fsk_coe_implicit(z, ctx->first_it, dtloc, r[CFL], r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in],
                          zn.xmut, zn.coe, ctx->stream);
-        if (z.iflow == 3) fsk_sa_coe6(z, zn.dev[in], zn.dist, zn.coe, ctx->stream);
+        if (z.iflow == 3) {
+          if (z.ityp == 0) fsk_sa_coe6_full(z, zn.dev[in], zn.dist, zn.coe, ctx->stream);
+          else fsk_sa_coe6(z, zn.dev[in], zn.dist, zn.coe, ctx->stream);
+        }
       }
       if (z.kflu == 2 && ctx->plain_stage && z.ityp != 0) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }
@@ -686,12 +689,12 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       HIPCHK(ctx, hipEventRecord(zn.ev_part, ctx->stream));
     }
     int krc = 0;
-    if (z.iflow == 3)
+    if (z.iflow == 3 && z.ityp != 0)
       krc = fsk_stage_sa(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.dist,
                          (unsigned char *)zn.wig, pbdf, ctx->stream);
     else if (z.ityp == 0)
       krc = fsk_stage_full(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
-                           (unsigned char *)zn.wig, pbdf, ctx->stream);
+                           (unsigned char *)zn.wig, pbdf, zn.dist, ctx->stream);
     else if (ctx->plain_stage)
       krc = fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
     else if (!ctx->dma_stage)

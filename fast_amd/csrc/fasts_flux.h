@@ -192,7 +192,7 @@ FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *q
 template <int KFLU>
 FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, double tcz, const double *qm2,
                                   const double *qm1_, const double *q0, const double *qp1_, double wg, double *flu,
-                                  bool f3_first = false)
+                                  bool f3_first = false, double *sa = nullptr)
 {
   const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
   double qm[5], qp[5];
@@ -287,6 +287,7 @@ FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, doubl
     flu3 = u * (rov1 + rov2) - tdu * (rov2 - rov1) + tcy * p1p2;
     flu4 = u * (row1 + row2) - tdu * (row2 - row1) + tcz * p1p2;
     flu5 = u * (h1 + h2) - tdu * (h2 - h1);
+    if (sa) { sa[0] = u; sa[1] = tdu; sa[2] = qm[0]; sa[3] = qp[0]; }
   }
   flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
 }
@@ -298,7 +299,10 @@ FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, doubl
 //   T(c, m, o)        component m of the surface vector of direction c (0 = DIR, 1 = a, 2 = b) at
 //                     metric offset o: 0 = lt, 1 = lt - md, 2 = lt + md, 3 = lt + m(c), 4 = lt - md + m(c)
 //   vol_r, vol_l      volumes of ir and il;  (tcx,tcy,tcz) = surface vector of the face
-template <class Q, class TT>
+// SA = true (Spalart-Allmaras): conductivity with the turbulent Prandtl number (mut_prandtltb_interface.for) and
+// the diffusion of nu_tilde added to flu[5] (SA/fluvisq_SA_3dfull_i.for, SA/assemble_tauij_3dfull.for,
+// SA/mut_interface.for); q(5, ...) = nu_tilde, q(0, 0, 0, dn) = density, q(4, 0, 0, dn) = temperature.
+template <bool SA = false, class Q, class TT>
 FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, double vol_r, double vol_l, double mul,
                                  double mur, double tcx, double tcy, double tcz, double *flu)
 {
@@ -312,10 +316,10 @@ FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, doubl
     tb[m] = .125 * (T(2, m, 0) + T(2, m, 1));
     tb1[m] = .125 * (T(2, m, 3) + T(2, m, 4));
   }
-  double g[4][3];
-  double sum_lr[4];
+  double g[SA ? 5 : 4][3];
+  double sum_lr[SA ? 5 : 4];
 #pragma unroll
-  for (int e = 1; e <= 4; e++) {
+  for (int e = 1; e <= (SA ? 5 : 4); e++) {
     const double qr = q(e, 0, 0, 0), ql = q(e, 0, 0, -1);
     double f1 = ql, f2 = qr;
     double f3 = qr + ql + q(e, -1, 0, -1) + q(e, -1, 0, 0);
@@ -333,6 +337,15 @@ FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, doubl
   double volinv = 1. / (vol_r + vol_l);
   double xmutvol = (mur + mul) * volinv;
   double xktvol = xmutvol * z.gam3;
+  double xmulam = 0.;
+  if (SA) {
+    xmulam = z.sa_coesut * sqrt(q(4, 0, 0, -1) * z.temp01) / (1. + z.cmus1 / q(4, 0, 0, -1));
+    xmulam = xmulam + z.sa_coesut * sqrt(q(4, 0, 0, 0) * z.temp01) / (1. + z.cmus1 / q(4, 0, 0, 0));
+    const double xmutot = mur + mul;
+    const double xmutur = xmutot - xmulam;
+    xktvol = (xmulam * z.gam3 + xmutur * z.gam4) * volinv;
+    xmutvol = xmutot * volinv;
+  }
   double fv, fv5;
   fv = -(2. * f1 * tcx + f2 * tcy + f3 * tcz) * xmutvol;
   fv5 = fv * sum_lr[0];
@@ -345,6 +358,11 @@ FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, doubl
   flu[3] = flu[3] + fv;
   fv = fv5 * 0.5 - (g[3][0] * tcx + g[3][1] * tcy + g[3][2] * tcz) * xktvol;
   flu[4] = flu[4] + fv;
+  if (SA) {
+    double xm = xmulam + q(5, 0, 0, -1) * q(0, 0, 0, -1) + q(5, 0, 0, 0) * q(0, 0, 0, 0);
+    xm = xm * volinv * (1. / (2. / 3.));
+    flu[5] = flu[5] - xm * (g[4][0] * tcx + g[4][1] * tcy + g[4][2] * tcz);
+  }
 }
 
 // Viscous part added to flu[1..4].  il = l - inc(DIR), ir = l.  The accessor gives

@@ -39,7 +39,9 @@ int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const 
                   hipStream_t s);
 // stage kernel of curvilinear zones (zone type 0, fasts_stage_full.hip); sensors stored as bytes
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                   double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, hipStream_t s);
+                   double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, const double *dist,
+                   hipStream_t s);
+void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
 // Spalart-Allmaras on Cartesian zones (fasts_stage_sa.hip): total viscosity on the whole zone, stage kernel
 void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s);
 int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,

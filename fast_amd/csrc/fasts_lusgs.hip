@@ -617,7 +617,6 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
   static const bool per_cell = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "cell") == 0;
   static const bool per_chunk = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "chunk") == 0;
   const bool sa = z.neq == 6;
-  if (sa && full) return -1;
   if (sa || (!per_cell && !per_chunk)) {
     const int nchunk = (ni + 7) / 8;
     const int nhc = nchunk + nj + nk - 2;
@@ -629,11 +628,13 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
         int khi = h < nk - 1 ? h : nk - 1;
         dim3 g(gx8, (unsigned)(khi - klo + 1));
         if (pass == 0) {
-          if (sa) hipLaunchKernelGGL((k_lu_lower_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+          if (sa && full) hipLaunchKernelGGL((k_lu_lower_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+          else if (sa) hipLaunchKernelGGL((k_lu_lower_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
           else if (full) hipLaunchKernelGGL((k_lu_lower_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
           else hipLaunchKernelGGL((k_lu_lower_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
         } else {
-          if (sa) hipLaunchKernelGGL((k_lu_upper_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+          if (sa && full) hipLaunchKernelGGL((k_lu_upper_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+          else if (sa) hipLaunchKernelGGL((k_lu_upper_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
           else if (full) hipLaunchKernelGGL((k_lu_upper_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
           else hipLaunchKernelGGL((k_lu_upper_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
         }

@@ -47,8 +47,31 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
       wg = (double)wig[DIR * nd + l];
     }
   }
-  fs_flux_inviscid_full<KFLU>(z, tcx, tcy, tcz, qm2, qm1, q0, qp1, wg, flu, TWOD && DIR == 1);
-  if (IFLOW == 2) {
+  double sa[4];
+  fs_flux_inviscid_full<KFLU>(z, tcx, tcy, tcz, qm2, qm1, q0, qp1, wg, flu, TWOD && DIR == 1,
+                              (IFLOW == 3 && KFLU != 5) ? sa : nullptr);
+  if (IFLOW == 3 && KFLU == 5) {
+    // roe: first-order upwinding with the Roe-averaged normal velocity (ROE/fluFaceSA.for, Vit_ent/qn_3dfull_i.for)
+    double qp1r = qm1[0], qm1r = q0[0];
+    double qp2 = qm1[1], qp3 = qm1[2], qp4 = qm1[3];
+    double qn1 = qp2 * tcx + qp3 * tcy + qp4 * tcz;
+    const double qn2 = q0[1] * tcx + q0[2] * tcy + q0[3] * tcz;
+    const double qm6 = q0[5] * qm1r * qn2, qp6 = qm1[5] * qp1r * qn1;
+    qp1r = sqrt(qp1r); qm1r = sqrt(qm1r);
+    const double r_1 = 1. / (qp1r + qm1r);
+    qp2 = r_1 * (qp1r * qp2 + qm1r * q0[1]); qp3 = r_1 * (qp1r * qp3 + qm1r * q0[2]); qp4 = r_1 * (qp1r * qp4 + qm1r * q0[3]);
+    qn1 = qp2 * tcx + qp3 * tcy + qp4 * tcz;
+    const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+    const double s_1 = 1. / fs_max(s, 1.e-30);
+    const double tdu = fs_max(z.c1 / s_1, fabs(qn1));
+    flu[5] = 0.5 * (qm6 + qp6 - tdu * (q0[5] * q0[0] - qm1[5] * qm1[0]));
+  } else if (IFLOW == 3) {   // AUSM/fluFaceSA.for, SENSOR/fluFaceSA.for
+    const double qm = z.c4 * q0[5] + z.c5 * qm1[5] + z.c6 * qp1[5];
+    const double qp = z.c4 * qm1[5] + z.c6 * qm2[5] + z.c5 * q0[5];
+    const double qm6 = qm * sa[2], qp6 = qp * sa[3];
+    flu[5] = sa[0] * (qm6 + qp6) - sa[1] * (qm6 - qp6);
+  }
+  if (IFLOW >= 2) {
     constexpr int A = (DIR + 1) % 3, B = (DIR + 2) % 3;
     const long long inc = inc_of<DIR>(z), ia = (TWOD && A == 2) ? 0 : inc_of<A>(z), ib = (TWOD && B == 2) ? 0 : inc_of<B>(z);
     const long long md = minc_of<DIR>(z), ma = minc_of<A>(z), mb = minc_of<B>(z);
@@ -62,8 +85,91 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
       const long long off = o == 0 ? 0 : (o == 1 ? -md : (o == 2 ? md : (o == 3 ? mc : mc - md)));
       return t[lt + off + m * ndm];
     };
-    fs_flux_viscous_full(z, q, T, z.vol[lt], z.vol[lt - md], xmut[l - inc], xmut[l], tcx, tcy, tcz, flu);
+    fs_flux_viscous_full<IFLOW == 3>(z, q, T, z.vol[lt], z.vol[lt - md], xmut[l - inc], xmut[l], tcx, tcy, tcz, flu);
   }
+}
+
+// Spalart-Allmaras source term of cell l on a curvilinear / two-dimensional zone: vol * (production - destruction
+// + cb2 term) (SA/spsource_SA.for:100-130, SA/sourceSA_grad_3d.for, sourceSA_grad_2d.for, sourceSA_prod_dest.for).
+// qc = state of the cell; tsb / amu (may be null): production - destruction and the clipped rho*nu_tilde
+// (SA/sourceSA_LU.for).
+template <bool TWOD>
+FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ dlng, long long l,
+                             long long lt, const double *qc, double *tsb = nullptr, double *amu = nullptr)
+{
+  const double SA_CKARM = 0.41, SA_CB1 = 0.1355, SA_CB2 = 0.622, SA_CV1 = 357.911, SA_CW2 = 0.3, SA_CW3 = 64.;
+  const double SA_CW4 = 0.21, SA_CW5 = 1.5, SA_CROT = 2.0, SA_SIGMA = (2. / 3.);
+  const double c1 = SA_CB2 / SA_SIGMA;
+  const double cw1 = (SA_CB1 / SA_CKARM / SA_CKARM) + (1. + SA_CB2) / SA_SIGMA;
+  const long long nd = z.nd, incj = z.incj, inck = TWOD ? 0 : z.inck, ndm = z.ndm;
+  const long long l1 = l + 1, l2 = l - 1, l3 = l + incj, l4 = l - incj, l5 = l + inck, l6 = l - inck;
+  double t0[3][3], t1[3][3];   // surface vectors of the faces at lt and at lt + inc_mtr(d)
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const long long md = d == 0 ? 1 : (d == 1 ? z.mincj : z.minck);
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      const bool have = !(TWOD && (d == 2 || m == 2));
+      t0[d][m] = have ? z.mt[d][lt + m * ndm] : 0.;
+      t1[d][m] = have ? z.mt[d][lt + md + m * ndm] : 0.;
+    }
+  }
+  auto grad = [&](double u1, double u2, double u3, double u4, double u5, double u6, int m) -> double {
+    if (TWOD) return u3 * t1[0][m] - u1 * t0[0][m] + u2 * t1[1][m] - u4 * t0[1][m];
+    return u3 * t1[0][m] - u1 * t0[0][m] + u2 * t1[1][m] - u4 * t0[1][m] + u5 * t1[2][m] - u6 * t0[2][m];
+  };
+  const double xvol = 0.5 / z.vol[lt];
+  double g[3][3];
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    const double *__restrict__ q = rop + (1 + v) * nd;
+    const double c = qc[1 + v];
+    const double u1 = (c + q[l2]), u2 = (c + q[l3]), u3 = (c + q[l1]);
+    const double u4 = (c + q[l4]), u5 = (c + q[l5]), u6 = (c + q[l6]);
+#pragma unroll
+    for (int m = 0; m < 3; m++) g[v][m] = (TWOD && (m == 2 || v == 2)) ? 0. : grad(u1, u2, u3, u4, u5, u6, m);
+  }
+  const double rotx = g[2][1] - g[1][2], roty = g[0][2] - g[2][0], rotz = g[1][0] - g[0][1];
+  const double rot = (TWOD ? fabs(rotz) : sqrt(rotx * rotx + roty * roty + rotz * rotz)) * xvol;
+  const double S11 = g[0][0], S22 = g[1][1], S33 = g[2][2];
+  const double S12 = 0.5 * (g[0][1] + g[1][0]), S13 = 0.5 * (g[0][2] + g[2][0]), S23 = 0.5 * (g[1][2] + g[2][1]);
+  double St = TWOD ? S11 * S11 + S22 * S22 + 2 * (S12 * S12)
+                   : S11 * S11 + S22 * S22 + S33 * S33 + 2 * (S12 * S12) + 2 * (S13 * S13) + 2 * (S23 * S23);
+  St = sqrt(2 * St) * xvol;
+  const double *__restrict__ N = rop + 5 * nd, *__restrict__ R = rop;
+  const double nc = qc[5], rc = qc[0];
+  const double n1 = N[l1], n2 = N[l2], n3 = N[l3], n4 = N[l4], n5 = N[l5], n6 = N[l6];
+  double u1 = (nc + n2), u2 = (nc + n3), u3 = (nc + n1), u4 = (nc + n4), u5 = (nc + n5), u6 = (nc + n6);
+  double dudx = grad(u1, u2, u3, u4, u5, u6, 0), dudy = grad(u1, u2, u3, u4, u5, u6, 1);
+  double dudz = TWOD ? 0. : grad(u1, u2, u3, u4, u5, u6, 2);
+  u1 = nc * rc + n2 * R[l2]; u2 = nc * rc + n3 * R[l3]; u3 = nc * rc + n1 * R[l1];
+  u4 = nc * rc + n4 * R[l4]; u5 = nc * rc + n5 * R[l5]; u6 = nc * rc + n6 * R[l6];
+  dudx = dudx * grad(u1, u2, u3, u4, u5, u6, 0); dudy = dudy * grad(u1, u2, u3, u4, u5, u6, 1);
+  dudz = TWOD ? 0. : dudz * grad(u1, u2, u3, u4, u5, u6, 2);
+  const double anvisc = TWOD ? c1 * (dudx + dudy) * xvol * xvol : c1 * (dudx + dudy + dudz) * xvol * xvol;
+  const double amulam = fs_mulam_sa(z, qc[4]);
+  const double anulam = rc / amulam;
+  const double anutild = fs_max(nc, 1.e-27);
+  const double chi = fs_max(anutild * anulam, 1.e-7);
+  const double f1 = 1. / (1. + SA_CV1 / (chi * chi * chi));
+  const double f2 = 1. - chi / (1. + chi * f1);
+  const double dist = fs_max(dlng[l], 1.e-27);
+  double stild = rot + (anutild * f2) / (SA_CKARM * SA_CKARM * dist * dist);
+  stild = stild + z.sa_rot_corr * SA_CROT * fs_min(0.00000000000000000001, St - rot);
+  const double prod = rc * SA_CB1 * stild * anutild;
+  stild = fs_max(stild, 0.00000000000000000001);
+  double r = anutild / (stild * SA_CKARM * SA_CKARM * dist * dist);
+  r = fs_min(r, 10.);
+  const double r5 = r * r * r * r * r - 1.;
+  double gg = r * (1. + SA_CW2 * r5);
+  const double cw2_lre = SA_CW4 + SA_CW5 / ((1. + chi / 40.) * (1. + chi / 40.));
+  gg = z.sa_low_re * r * (1. + cw2_lre * r5) + (1. - z.sa_low_re) * gg;
+  const double g6 = gg * gg * gg * gg * gg * gg;
+  const double fwg = gg * pow((1. + SA_CW3) / (g6 + SA_CW3), 1. / 6.);
+  const double destruc = rc * cw1 * fwg * (anutild / dist) * (anutild / dist);
+  const double tsource = (prod + anvisc - destruc);
+  if (tsb) { *tsb = prod - destruc; *amu = fs_max(anutild * rc, 0.0000000000000001); }
+  return z.vol[lt] * tsource;
 }
 
 // BDF = false: Runge-Kutta stage.  BDF = true: Newton residual of the implicit scheme (rop_out unused).
@@ -72,9 +178,10 @@ template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD>
 __global__ void __launch_bounds__(256)
 k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
-             unsigned char *__restrict__ wig, FsBdf bdf)
+             unsigned char *__restrict__ wig, FsBdf bdf, const double *__restrict__ dlng)
 {
-  __shared__ double sfj[2][5][TJ][TI];
+  constexpr int NQ = IFLOW == 3 ? 6 : 5;   // Spalart-Allmaras: 6th variable nu_tilde
+  __shared__ double sfj[2][NQ][TJ][TI];
   const int ti = threadIdx.x & 31, tj = threadIdx.x >> 5;
   const int i = 1 + blockIdx.x * OI + ti, j = 1 + blockIdx.y * OJ + tj;
   const int k0 = 1 + blockIdx.z * kchunk;
@@ -89,101 +196,155 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
   const int ic = active ? i : 1, jc = active ? j : 1;
   long long l = (long long)(ic + z.ific - 1) + (long long)(jc + z.ific - 1) * z.incj + (long long)(k0 + z.ifick - 1) * z.inck;
   long long lt = (long long)(ic + z.ific - 1) + (long long)(jc + z.ific - 1) * z.mincj + (long long)(k0 + z.ifick - 1) * z.minck;
-  double qa[5], qb[5], qc[5], qd[5];   // own column at k-2, k-1, k, k+1
+  double qa[NQ], qb[NQ], qc[NQ], qd[NQ];   // own column at k-2, k-1, k, k+1
 #pragma unroll
-  for (int e = 0; e < 5; e++) {
+  for (int e = 0; e < NQ; e++) {
     qa[e] = TWOD ? 0. : rop[e * nd + l - 2 * z.inck];
     qb[e] = TWOD ? 0. : rop[e * nd + l - z.inck];
     qc[e] = rop[e * nd + l];
     qd[e] = 0.;
   }
-  double part[5] = {0., 0., 0., 0., 0.};
+  double part[NQ] = {};
   for (int k = k0; k <= (TWOD ? k0 : k1 + 1); k++) {
     const bool last = !TWOD && k > k1;
     if (!TWOD) {
 #pragma unroll
-      for (int e = 0; e < 5; e++) qd[e] = rop[e * nd + l + z.inck];
+      for (int e = 0; e < NQ; e++) qd[e] = rop[e * nd + l + z.inck];
     }
-    double fk[5] = {0., 0., 0., 0., 0.};
+    double fk[NQ] = {};
     // finish: the balance of a cell is complete (3-D: cell k-1 once its k+1/2 face is known; 2-D: the cell itself)
     auto finish = [&](long long lb, long long ltb, const double *qcell, const double *d) {
-        double o[5];
+        double o[NQ];
         const double coe = z.dt / z.vol[ltb];
         if (BDF) {
-          double qn[5] = {0., 0., 0., 0., 0.}, qn1[5];
+          double qn[NQ] = {}, qn1[NQ];
 #pragma unroll
-          for (int e = 0; e < 5; e++) qn1[e] = bdf.ro_n1[e * nd + lb];
+          for (int e = 0; e < NQ; e++) qn1[e] = bdf.ro_n1[e * nd + lb];
           if (!bdf.nit1) {
 #pragma unroll
-            for (int e = 0; e < 5; e++) qn[e] = bdf.ro_n[e * nd + lb];
+            for (int e = 0; e < NQ; e++) qn[e] = bdf.ro_n[e * nd + lb];
           }
-          fs_bdf_residual(z, bdf, bdf.coe1 ? bdf.coe1[lb] : coe, qcell, qn, qn1, d, o);
+          const double coeb = bdf.coe1 ? bdf.coe1[lb] : coe;
+          if (NQ == 6 && bdf.nit1 && bdf.coe1) {   // local time step, first sub-iteration (core3as2.for:57-66)
 #pragma unroll
-          for (int e = 0; e < 5; e++) drodm[e * nd + lb] = o[e];
+            for (int e = 0; e < NQ; e++) o[e] = coeb * d[e];
+          } else {
+            fs_bdf_residual(z, bdf, coeb, qcell, qn, qn1, d, o);
+            if (NQ == 6) {
+              if (bdf.nit1) o[NQ - 1] = coeb * d[NQ - 1] + (bdf.c1 + bdf.c2) * qcell[NQ - 1] * qcell[0] + bdf.c3 * qn1[NQ - 1] * qn1[0];
+              else o[NQ - 1] = coeb * d[NQ - 1] + bdf.c1 * qcell[NQ - 1] * qcell[0] + bdf.c2 * qn[NQ - 1] * qn[0] +
+                               bdf.c3 * qn1[NQ - 1] * qn1[0];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = o[e];
         } else {
 #pragma unroll
-          for (int e = 0; e < 5; e++) drodm[e * nd + lb] = d[e];
+          for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = d[e];
           fs_rk_update_c(z, coefW, coe, qcell, d, o);
           if (TWOD) o[3] = 0.;   // core3ark3.for:156-183
+          if (NQ == 6) {   // nu_tilde clipped to [0, ratiom * nu_laminar] (core3ark3.for:196-236)
+            const double r_1 = 1. / o[0];
+            const double tab6 = d[NQ - 1] * (coefW * coe);
+            double anulam = fs_mulam_sa(z, o[4]);
+            anulam = anulam * r_1 * z.ratiom;
+            double t6 = (qcell[0] * qcell[NQ - 1] + tab6) * r_1;
+            t6 = fs_min(t6, anulam);
+            o[NQ - 1] = fs_max(t6, 0.);
+          }
 #pragma unroll
-          for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
+          for (int e = 0; e < NQ; e++) rop_out[e * nd + lb] = o[e];
         }
     };
     if (own && !TWOD) {
       face_full<KFLU, IFLOW, 2, FIRST, TWOD>(z, rop, xmut, wig, l, lt, qa, qb, qc, qd, fk);
       if (k > k0) {   // the cell below is complete
-        double d[5];
+        double d[NQ];
 #pragma unroll
-        for (int e = 0; e < 5; e++) d[e] = part[e] - fk[e];
+        for (int e = 0; e < NQ; e++) d[e] = part[e] - fk[e];
         finish(l - z.inck, lt - z.minck, qb, d);
       }
     }
     if (!last) {
-      double fim[5] = {0., 0., 0., 0., 0.}, fjm[5] = {0., 0., 0., 0., 0.};
+      double fim[NQ] = {}, fjm[NQ] = {};
       if (do_fj) {
-        double m2[5], m1[5], p1[5];
+        double m2[NQ], m1[NQ], p1[NQ];
 #pragma unroll
-        for (int e = 0; e < 5; e++) {
+        for (int e = 0; e < NQ; e++) {
           m2[e] = rop[e * nd + l - 2 * z.incj]; m1[e] = rop[e * nd + l - z.incj]; p1[e] = rop[e * nd + l + z.incj];
         }
         face_full<KFLU, IFLOW, 1, FIRST, TWOD>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
       }
       const int buf = (k - k0) & 1;
 #pragma unroll
-      for (int e = 0; e < 5; e++) sfj[buf][e][tj][ti] = fjm[e];
+      for (int e = 0; e < NQ; e++) sfj[buf][e][tj][ti] = fjm[e];
       if (do_fi) {
-        double m2[5], m1[5], p1[5];
+        double m2[NQ], m1[NQ], p1[NQ];
 #pragma unroll
-        for (int e = 0; e < 5; e++) {
+        for (int e = 0; e < NQ; e++) {
           m2[e] = rop[e * nd + l - 2]; m1[e] = rop[e * nd + l - 1]; p1[e] = rop[e * nd + l + 1];
         }
         face_full<KFLU, IFLOW, 0, FIRST, TWOD>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fim);
       }
-      double fip[5];
+      double fip[NQ];
 #pragma unroll
-      for (int e = 0; e < 5; e++) fip[e] = __shfl_down(fim[e], 1);
+      for (int e = 0; e < NQ; e++) fip[e] = __shfl_down(fim[e], 1);
       __syncthreads();
       if (own) {
+        double src = 0.;
+        if (NQ == 6) src = sa_source_full<TWOD>(z, rop, dlng, l, lt, qc);
 #pragma unroll
-        for (int e = 0; e < 5; e++) {
-          const double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
+        for (int e = 0; e < NQ; e++) {
+          double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
+          if (NQ == 6 && e == 5) dr = dr + src;
           part[e] = dr + fk[e] + fjm[e] + fim[e] - fip[e] - sfj[buf][e][tj + 1][ti];
         }
         if (TWOD) finish(l, lt, qc, part);
       }
     }
 #pragma unroll
-    for (int e = 0; e < 5; e++) { qa[e] = qb[e]; qb[e] = qc[e]; qc[e] = qd[e]; }
+    for (int e = 0; e < NQ; e++) { qa[e] = qb[e]; qb[e] = qc[e]; qc[e] = qd[e]; }
     l += z.inck; lt += z.minck;
   }
 }
 
+// coe(:,6) of the implicit Spalart-Allmaras scheme on a curvilinear / two-dimensional zone (SA/sourceSA_LU.for),
+// interior plus one ghost layer (none along k on a two-dimensional zone)
+template <bool TWOD>
+__global__ void __launch_bounds__(256) k_sa_coe6_full(FsZone z, const double *__restrict__ rop,
+                                                      const double *__restrict__ dlng, double *__restrict__ coe)
+{
+  const int gk = TWOD ? 0 : 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z + 1 - gk;
+  if (i > z.iv + 1) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  const long long lt = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck;
+  double qc[6];
+#pragma unroll
+  for (int e = 0; e < 6; e++) qc[e] = rop[e * nd + l];
+  double tsb, amu;
+  sa_source_full<TWOD>(z, rop, dlng, l, lt, qc, &tsb, &amu);
+  const double tsourcenu = z.vol[lt] * tsb / amu;
+  coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
+}
+
 }  // namespace
 
+void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s)
+{
+  const int gk = z.twod ? 0 : 1;
+  dim3 g((z.iv + 2 + 255) / 256, z.jv + 2, z.kv + 2 * gk);
+  if (z.twod) hipLaunchKernelGGL(k_sa_coe6_full<true>, g, dim3(256), 0, s, z, rop, dist, coe);
+  else hipLaunchKernelGGL(k_sa_coe6_full<false>, g, dim3(256), 0, s, z, rop, dist, coe);
+}
+
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                   double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, hipStream_t s)
+                   double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, const double *dist,
+                   hipStream_t s)
 {
   if (z.ityp != 0 || !z.vol || !z.mt[0] || !z.mt[1] || !z.mt[2]) return -1;
+  if (z.iflow == 3 && (z.neq != 6 || !dist)) return -1;
   int kchunk = 32;
   if (const char *ev = getenv("FASTS_HIP_KCHUNK_FULL")) {
     int v = atoi(ev);
@@ -197,10 +358,10 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
   do {                                                                                                        \
     if (z.twod)                                                                                               \
       hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop,  \
-                         rop_out, drodm, xmut, wig, b);                                                       \
+                         rop_out, drodm, xmut, wig, b, dist);                                                 \
     else                                                                                                      \
       hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, \
-                         rop_out, drodm, xmut, wig, b);                                                       \
+                         rop_out, drodm, xmut, wig, b, dist);                                                 \
   } while (0)
 #define FS_CASE(K, F)                                                                                         \
   if (z.kflu == K && z.iflow == F) {                                                                          \
@@ -209,6 +370,7 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
     return 0;                                                                                                 \
   }
   FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)
+  FS_CASE(1, 3) FS_CASE(2, 3) FS_CASE(5, 3)
 #undef FS_CASE
 #undef FS_GO
   return -1;

@@ -82,6 +82,57 @@ def test_sa_implicit_matches_oracle(n, scheme, bcs, local, nit):
     assert np.isfinite(got).all() and d[5] > 1e-7 and d[1] > 1e-4
 
 
+GENERAL_CASES = [
+    (3, (14, 12, 10), 'ausmpred', None, False),
+    (3, (12, 10, 9), 'senseur', None, False),
+    (3, (12, 10, 9), 'roe', None, False),
+    (3, (40, 11, 12), 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, False),
+    (3, (14, 12, 10), 'ausmpred', None, True),
+    (3, (12, 10, 9), 'roe', None, True),
+    (3, (12, 10, 9), 'senseur', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, True),
+    (2, (14, 12), 'ausmpred', None, False),
+    (2, (12, 10), 'senseur', None, False),
+    (2, (12, 10), 'roe', None, False),
+    (2, (70, 17), 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, False),
+    (2, (14, 12), 'ausmpred', None, True),
+    (2, (12, 10), 'roe', None, True),
+    (2, (40, 11), 'senseur', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, True),
+    (2, (40, 11), 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 'local'),
+]
+
+
+@pytest.mark.parametrize("dim,n,scheme,bcs,implicit", GENERAL_CASES)
+def test_sa_general_mesh_matches_oracle(dim, n, scheme, bcs, implicit):
+    """NSTurbulent on curvilinear (zone type 0) and two-dimensional (type 3) zones, explicit and implicit."""
+    extra = dict(SINGLE)
+    kw = {}
+    if implicit:
+        kw = dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})
+        if implicit == 'local':
+            extra.update({'time_step_nature': 'local', 'cfl': 4.})
+    if dim == 3:
+        t = cases.tgv(n, scheme, model='NSTurbulent', extra_numz=extra, bcs=bcs, perturb=0.15, **kw)
+    else:
+        t = cases.tgv2d(n, scheme, model='NSTurbulent', extra_numz=extra, bcs=bcs, perturb=0.15, **kw)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[36]) == 6 and int(pint[25]) == (0 if dim == 3 else 3)
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z))
+    oz.fill_ghostcells()
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, 5):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        e = rel_err(got, oz.ro, int(pint[41]), neq=6)
+        assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+    d = np.abs(got - ro0).reshape(6, -1).max(axis=1)
+    assert np.isfinite(got).all() and d[5] > 1e-7 and d[1] > 1e-4
+
+
 def test_sa_blocks_with_joins():
     blocks, nn = (2, 1, 2), (16, 9, 12)
     nv = tuple(nn[d] // blocks[d] for d in range(3))
@@ -109,6 +160,9 @@ def test_sa_blocks_with_joins():
 
 
 def test_sa_options_outside_the_device_path_are_refused():
-    t = cases.tgv(8, 'senseur', model='NSTurbulent', perturb=0.1)
-    with pytest.raises(_capi.FastsHipError, match="Spalart-Allmaras"):
+    t = cases.tgv(8, 'senseur', model='NSTurbulent')
+    for zz in Internal.getZones(t):      # no wall distance
+        sol = Internal.getNodeFromName1(zz, 'FlowSolution#Centers')
+        sol[2] = [n for n in sol[2] if n[0] != 'TurbulentDistance']
+    with pytest.raises(Exception):
         FastS.warmup(t, None)
