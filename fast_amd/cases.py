@@ -176,6 +176,106 @@ def tgv2d(n=(16, 12), scheme='ausmpred', model='NSLaminar', time_step=None, temp
     return t
 
 
+def _naca0012_y(x):
+    """Half thickness of the NACA0012 section with a closed trailing edge, chord 1."""
+    x = numpy.clip(x, 0., 1.)
+    return 0.6 * (0.2969 * numpy.sqrt(x) - 0.126 * x - 0.3516 * x ** 2 + 0.2843 * x ** 3 - 0.1036 * x ** 4)
+
+
+def naca_cmesh(nfoil=32, nwake=12, nj=16, radius=8., wall_step=2.e-3, scheme='ausmpred', model='NSTurbulent',
+               temporal_scheme='implicit', ss_iteration=3, cfl=5., mach=0.3, reynolds=1.e5, extra_numz=None,
+               extra_numb=None):
+    """Two-dimensional C-mesh around a NACA0012 section, built analytically (no mesh file): i runs from the
+    downstream end of the lower wake line, around the section (lower side, leading edge, upper side) to the
+    downstream end of the upper wake line; j from the section / wake cut to a C-shaped outer boundary of the
+    given radius centred on the trailing edge.  2*nwake + 2*nfoil cells along i, nj along j, one along k
+    (zone type 3).  jmin carries a wall on the section and a match join between the two sides of the wake cut
+    (see connect.cmesh_wake_join); the other faces are far field.  Steady-RANS set-up of the reference
+    (implicit, local time step, Spalart-Allmaras) by default.  Returns t."""
+    ni = 2 * nwake + 2 * nfoil
+    # inner line: nodes 0..ni
+    xw = 1. + (radius - 1.) * (numpy.linspace(0., 1., nwake + 1) ** 2)        # wake abscissa, clustered at the TE
+    th = numpy.linspace(0., math.pi, nfoil + 1)
+    xf = 0.5 * (1. + numpy.cos(th))                                          # TE -> LE, cosine clustering
+    xin = numpy.concatenate([xw[::-1], xf[1:], xf[::-1][1:], xw[1:]])
+    yin = numpy.concatenate([numpy.zeros(nwake + 1), -_naca0012_y(xf[1:]), _naca0012_y(xf[::-1][1:]), numpy.zeros(nwake)])
+    yin[nwake + nfoil] = 0.
+    # outer line: straight above/below the wake, half circle of centre (1, 0) around the section
+    ang = numpy.linspace(-0.5 * math.pi, -1.5 * math.pi, 2 * nfoil + 1)
+    xout = numpy.concatenate([xw[::-1], 1. + radius * numpy.cos(ang[1:]), xw[1:]])
+    yout = numpy.concatenate([-radius * numpy.ones(nwake + 1), radius * numpy.sin(ang[1:]), radius * numpy.ones(nwake)])
+    # geometric stretching along j
+    q = 1.
+    for _ in range(200):        # growth rate q with first step wall_step and total length 1 (in units of radius)
+        tot = wall_step * (nj if abs(q - 1.) < 1e-12 else (q ** nj - 1.) / (q - 1.))
+        q = q * (1. / tot) ** (1. / nj) if tot > 0 else q
+        if abs(tot - 1.) < 1e-12:
+            break
+    sj = numpy.concatenate([[0.], numpy.cumsum(wall_step * q ** numpy.arange(nj))])
+    sj = sj / sj[-1]
+    g = 2
+    X = numpy.zeros((ni + 1 + 2 * g, nj + 1 + 2 * g, 2)); Y = numpy.zeros_like(X); Z = numpy.zeros_like(X)
+    for jj in range(nj + 1):
+        X[g:g + ni + 1, g + jj, :] = (xin + sj[jj] * (xout - xin))[:, None]
+        Y[g:g + ni + 1, g + jj, :] = (yin + sj[jj] * (yout - yin))[:, None]
+    for A in (X, Y):            # ghost nodes: linear extrapolation, j then i
+        for r in range(1, g + 1):
+            A[:, g - r, :] = 2. * A[:, g - r + 1, :] - A[:, g - r + 2, :]
+            A[:, g + nj + r, :] = 2. * A[:, g + nj + r - 1, :] - A[:, g + nj + r - 2, :]
+        for r in range(1, g + 1):
+            A[g - r, :, :] = 2. * A[g - r + 1, :, :] - A[g - r + 2, :, :]
+            A[g + ni + r, :, :] = 2. * A[g + ni + r - 1, :, :] - A[g + ni + r - 2, :, :]
+    for r in range(1, g + 1):   # across the wake cut the ghost nodes are the nodes of the other side
+        for i in list(range(0, nwake + 1)) + list(range(ni - nwake, ni + 1)):
+            X[g + i, g - r, :] = X[g + ni - i, g + r, :]
+            Y[g + i, g - r, :] = Y[g + ni - i, g + r, :]
+    hz = 1.
+    Z[:, :, 1] = hz
+    z = C.cart((0., 0., 0.), (1., 1., 1.), (ni + 1 + 2 * g, nj + 1 + 2 * g, 2), name='cmesh')
+    gc = Internal.getNodeFromName1(z, Internal.__GridCoordinates__)
+    for name, A in (('CoordinateX', X), ('CoordinateY', Y), ('CoordinateZ', Z)):
+        Internal.getNodeFromName1(gc, name)[1][...] = A
+    a, b = nwake + 1, ni - nwake           # section cells along i (1-based interior numbering)
+    C.addBC2Zone(z, 'wall', 'BCWall', [a + g, b + g + 1, 1, 1, 1, 2])
+    C.addBC2Zone(z, 'far jmax', 'BCFarfield', 'jmax')
+    C.addBC2Zone(z, 'far imin', 'BCFarfield', 'imin')
+    C.addBC2Zone(z, 'far imax', 'BCFarfield', 'imax')
+    t = C.newPyTree(['Base', z])
+    C.addState(t, 'GoverningEquations', model)
+    C.addState(t, adim='adim1', MInf=mach, ReInf=reynolds)
+    state = C.getState(Internal.getNodeFromName(t, 'ReferenceState'))
+    C._initVars(t, 'centers:Density', state[0])
+    C._initVars(t, 'centers:VelocityX', state[1] / state[0])
+    C._initVars(t, 'centers:VelocityY', 0.)
+    C._initVars(t, 'centers:VelocityZ', 0.)
+    C._initVars(t, 'centers:Temperature', state[6])
+    if model in ('NSTurbulent', 'nsspalart'):
+        nu = state[15] / state[0]
+        C._initVars(t, 'centers:TurbulentSANuTilde', 3. * nu)
+        # wall distance: to the section for the columns that start on it, to the trailing edge in the wake
+        xc = 0.25 * (X[:-1, :-1, 0] + X[1:, :-1, 0] + X[:-1, 1:, 0] + X[1:, 1:, 0])
+        yc = 0.25 * (Y[:-1, :-1, 0] + Y[1:, :-1, 0] + Y[:-1, 1:, 0] + Y[1:, 1:, 0])
+        xb = 0.5 * (X[:-1, g, 0] + X[1:, g, 0]); yb = 0.5 * (Y[:-1, g, 0] + Y[1:, g, 0])
+        d = numpy.sqrt((xc - xb[:, None]) ** 2 + (yc - yb[:, None]) ** 2)
+        dte = numpy.sqrt((xc - 1.) ** 2 + yc ** 2)
+        wake = numpy.ones(ni + 2 * g, dtype=bool); wake[g + a - 1:g + b] = False
+        d[wake, :] = dte[wake, :]
+        sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+        C._initVars(t, 'centers:TurbulentDistance', 0.)
+        Internal.getNodeFromName1(sol, 'TurbulentDistance')[1][:, :, 0] = numpy.maximum(d, 1.e-8)
+    numb = {'temporal_scheme': temporal_scheme, 'modulo_verif': 50, 'ss_iteration': ss_iteration}
+    numz = {'time_step': 1.e-3, 'scheme': scheme}
+    if temporal_scheme == 'implicit':
+        numz.update({'time_step_nature': 'local', 'cfl': cfl})
+    if extra_numz:
+        numz.update(extra_numz)
+    if extra_numb:
+        numb.update(extra_numb)
+    FastC._setNum2Zones(t, numz)
+    FastC._setNum2Base(t, numb)
+    return t
+
+
 def vortex(n=64, scheme='roe', time_step=None, extra_numz=None, extra_numb=None):
     """Isentropic vortex (strength beta=5, core radius 1) in a 10^3 periodic box, free
     stream along x at M=0.5, Euler, sound-speed scaling (rho_inf = c_inf = T_inf = 1)."""

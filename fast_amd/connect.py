@@ -51,6 +51,20 @@ def face_points(face, nv, ghost=2):
     return lin(I, J, K), lin(I, J, Kd)
 
 
+def cmesh_wake_join(ni, nj, nwake, ghost=2):
+    """(receiver_pts, donor_pts) of the match join that closes the wake cut of a two-dimensional C-mesh with
+    ni x nj interior cells whose jmin line is [lower wake | section | upper wake], nwake cells per wake side:
+    the ghost cell (i, 1 - r) below the cut coincides with the interior cell (ni + 1 - i, r) of the other side
+    (r = 1, 2).  The zone is its own donor.  Two-dimensional zone: no ghost layer along k."""
+    nis = ni + 2 * ghost
+    rp, dp = [], []
+    for r in range(1, ghost + 1):
+        for i in list(range(1, nwake + 1)) + list(range(ni - nwake + 1, ni + 1)):
+            rp.append((i + ghost - 1) + (1 - r + ghost - 1) * nis)
+            dp.append((ni + 1 - i + ghost - 1) + (r + ghost - 1) * nis)
+    return numpy.array(rp, dtype=numpy.int32), numpy.array(dp, dtype=numpy.int32)
+
+
 def block_index(pos, blocks):
     return pos[0] + pos[1] * blocks[0] + pos[2] * blocks[0] * blocks[1]
 

@@ -97,7 +97,7 @@ static std::string g_create_err;
 static int bc_kinds(const std::vector<FsBcWin> &v)
 {
   int k = 0;
-  for (auto &w : v) k |= (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE) ? 1 : 2;
+  for (auto &w : v) k |= (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE || w.type == FS_BC_ZERO) ? 1 : 2;
   return k;
 }
 
@@ -370,8 +370,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   }
   if (implicit) {
     // BCzone with lrhs = 1 (Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,262-264): faces that carry a wall
-    // BC (tags 3..7) get the residual extrapolated over the whole face, then their BCs applied to it (walls as
-    // walls, the rest as extrapolation); the LU range grows by one ghost layer there
+    // BC (tags 3..7) get the ghost residual zeroed over the whole face (extrapolation with c1 = 0), then their BCs
+    // applied to it (walls as walls, the rest as the same zeroing); the LU range grows by one ghost layer there
     int lskip[6] = {1, 1, 1, 1, 1, 1};
     for (int ndf = 0; ndf < nb; ndf++) {
       const int pt = p[pt_bcs + 1 + ndf], tag = p[pt], idir = p[pt + 1];
@@ -389,7 +389,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       if (f % 2 == 0) fen[2 * d + 1] = 1; else fen[2 * d] = fen[2 * d + 1];
       FsBcWin w;
       memset(&w, 0, sizeof w);
-      w.type = FS_BC_EXTRAPOLATE; w.idir = f + 1;
+      w.type = FS_BC_ZERO; w.idir = f + 1;
       if (!bc_window(p, w.idir, fen, w)) continue;
       long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
       if (cells > zn.rhs_max_cells) zn.rhs_max_cells = cells;
@@ -403,7 +403,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       w.idir = idir;
       if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
       else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
-      else w.type = FS_BC_EXTRAPOLATE;
+      else w.type = FS_BC_ZERO;
       if (!bc_window(p, idir, p + pt + 2, w)) continue;
       w.tcn = idir <= 2 ? mtr[0] : (idir <= 4 ? mtr[1] : mtr[2]);
       long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);

@@ -6,7 +6,9 @@
 // one BC window: ghost cells lo..hi (interior-based indices, ghosts <= 0 or > n)
 // device-side BC kinds: the tags of Fast/FastC/FastC/PyTree.py:30-82 after the dispatch of BCzone.cpp
 // (tag 4 is a slip wall for Euler and a no-slip wall otherwise)
-enum { FS_BC_EXTRAPOLATE = 0, FS_BC_FARFIELD = 1, FS_BC_WALL_SLIP = 3, FS_BC_WALL_NOSLIP = 6, FS_BC_PERIODIC = 11 };
+// FS_BC_ZERO: the extrapolation BC applied to the Newton residual (lrhs = 1): ghost = first interior cell * 0
+// (BCExtrapolate_init.for:2-6)
+enum { FS_BC_EXTRAPOLATE = 0, FS_BC_FARFIELD = 1, FS_BC_WALL_SLIP = 3, FS_BC_WALL_NOSLIP = 6, FS_BC_PERIODIC = 11, FS_BC_ZERO = 100 };
 
 struct FsBcWin {
   int type;          // FS_BC_*

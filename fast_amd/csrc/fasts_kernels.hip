@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) k_bc_copy(FsZone z, int nwin, const FsBcW
 {
   const FsBcWin *w = wins + blockIdx.y;
   const int type = w->type;
-  if (type != FS_BC_PERIODIC && type != FS_BC_EXTRAPOLATE) return;
+  if (type != FS_BC_PERIODIC && type != FS_BC_EXTRAPOLATE && type != FS_BC_ZERO) return;
   const int lo0 = w->lo[0], lo1 = w->lo[1], lo2 = w->lo[2];
   const int n0 = w->hi[0] - lo0 + 1, n1 = w->hi[1] - lo1 + 1, n2 = w->hi[2] - lo2 + 1;
   const int idir = w->idir;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) k_bc_copy(FsZone z, int nwin, const FsBcW
     int i = lo0 + (int)(t % n0), j = lo1 + (int)((t / n0) % n1), k = lo2 + (int)(t / ((long long)n0 * n1));
     const long long l = fs_inddm(z, i, j, k);
     long long ls = l + shift;
-    if (type == FS_BC_EXTRAPOLATE) {
+    if (type != FS_BC_PERIODIC) {
       switch (idir) {
         case 1: i = 1; break; case 2: i = z.iv; break;
         case 3: j = 1; break; case 4: j = z.jv; break;
@@ -232,7 +232,8 @@ __global__ void __launch_bounds__(256) k_bc_copy(FsZone z, int nwin, const FsBcW
       }
       ls = fs_inddm(z, i, j, k);
     }
-    for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls];
+    if (type == FS_BC_ZERO) { for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls] * 0.; }
+    else { for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls]; }
   }
 }
 
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
   const long long inc = sgn * stride;                          // from a ghost cell towards the interior
   const long long nd = z.nd;
   const long long n = (long long)na * nb;
-  if (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE) return;   // k_bc_copy
+  if (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE || w.type == FS_BC_ZERO) return;   // k_bc_copy
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     int q[3];
     q[da] = w.lo[da] + (int)(t % na);

@@ -966,11 +966,16 @@ static fo_face fo_face_of(const i32 *p, int idir)
 /* BCExtrapolate: every ghost rank = first interior cell
  * (Fast/FastS/FastS/BC/bvbs_extrapolate.for, BCExtrapolate_i.for, BCExtrapolate.for with
  * c1 = 1, vmax = -1e30 from BCExtrapolate_init.for) */
-void fo_bc_extrapolate(const i32 *p, int idir, const i32 *cl, double *rop)
+static void fo_bc_extrapolate_c(const i32 *p, int idir, const i32 *cl, double *rop, double c1);
+void fo_bc_extrapolate(const i32 *p, int idir, const i32 *cl, double *rop) { fo_bc_extrapolate_c(p, idir, cl, rop, 1.); }
+
+/* c1 = 1 on the state; c1 = 0 when the routine is applied to the Newton residual (lrhs = 1,
+ * BCExtrapolate_init.for:2-6): the ghost residual becomes (signed) zero */
+static void fo_bc_extrapolate_c(const i32 *p, int idir, const i32 *cl, double *rop, double c1)
 {
   GEOM(p)
   const fo_face f = fo_face_of(p, idir);
-  const double vmax = -1.e30, c1 = 1.;
+  const double vmax = -1.e30;
   for (int k = cl[4]; k <= cl[5]; k++)
     for (int j = cl[2]; j <= cl[3]; j++)
       for (int i = cl[0]; i <= cl[1]; i++) {
@@ -1687,9 +1692,9 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
 
 /* BCzone with lrhs = 1 on the Newton residual (Fast/FastS/FastS/Compute/lhs.cpp:53-68,
  * Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,451-523).  On every zone face that carries a wall-type BC
- * (tags 3..7) the residual is extrapolated into the ghost cells over the whole face, then every BC of that
+ * (tags 3..7) the ghost residual is first zeroed over the whole face (extrapolation with c1 = 0), then every BC of that
  * face is applied to the residual (walls as walls: bvbs_wall_* with lrhs = 1 only switch the mesh velocity
- * off; every other type as extrapolation), the LU range grows by one ghost layer on that face, and edges
+ * off; every other type as that same zeroing), the LU range grows by one ghost layer on that face, and edges
  * and corners are averaged.  lu receives the LU range; returns -1 for BC types that are not restated. */
 int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *tj, const double *tk, i32 *lu)
 {
@@ -1714,7 +1719,7 @@ int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *t
     if (f % 2 == 0) { fen[2 * d] = 1; fen[2 * d + 1] = 1; }
     else fen[2 * d] = fen[2 * d + 1];
     if (fo_indice_cl(f + 1, p, fen, sdm, cl)) continue;
-    fo_bc_extrapolate(p, f + 1, cl, drodm);
+    fo_bc_extrapolate_c(p, f + 1, cl, drodm, 0.);
   }
   for (int ndf = 0; ndf < nb; ndf++) {
     const int pt = p[pt_bcs + 1 + ndf], type = p[pt], idir = p[pt + 1];
@@ -1722,7 +1727,7 @@ int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *t
     if (fo_indice_cl(idir, p, p + pt + 2, sdm, cl)) continue;
     if (type == 0 || type == 1 || type == 2 || type == 10 || type == 11 || type == 14 || type == 16 || type == 17 ||
         type == 20 || type == 21)
-      fo_bc_extrapolate(p, idir, cl, drodm);
+      fo_bc_extrapolate_c(p, idir, cl, drodm, 0.);
     else if (type == 22) continue;
     else if (type == 3 || (type == 4 && p[IFLOW] == 1) || type == 5) fo_bc_wall_inviscid(p, idir, cl, drodm, ti, tj, tk);
     else if ((type == 6 || type == 4) && p[IFLOW] > 1) fo_bc_wall_viscous(p, idir, cl, drodm);

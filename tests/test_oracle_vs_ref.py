@@ -301,6 +301,40 @@ def test_spalart_allmaras_general_mesh_bit_exact(dim, scheme, bcs, implicit):
     assert np.isfinite(so.zones[0].ro).all() and d[5] > 1e-7 and d[1] > 1e-4
 
 
+@pytest.mark.parametrize("scheme,model,temporal", [
+    ('ausmpred', 'NSTurbulent', 'implicit'),
+    ('senseur', 'NSTurbulent', 'implicit'),
+    ('ausmpred', 'NSLaminar', 'implicit'),
+    ('ausmpred', 'NSTurbulent', 'explicit'),
+])
+def test_naca0012_cmesh_bit_exact(scheme, model, temporal):
+    """Steady-RANS set-up on a two-dimensional C-mesh: Spalart-Allmaras, implicit LU-SGS with a local time step,
+    wall on the section, far field outside, match join across the wake cut (the zone is its own donor)."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    if temporal == 'explicit':
+        extra['time_step'] = 2.e-5
+    nf, nw, nj = 16, 6, 10
+    t = cases.naca_cmesh(nfoil=nf, nwake=nw, nj=nj, scheme=scheme, model=model, temporal_scheme=temporal, extra_numz=extra)
+    metrics = prepare(t)
+    z = Internal.getZones(t)[0]
+    pint, preal, xyz = zone_arrays(z)
+    rp, dp = connect.cmesh_wake_join(2 * nf + 2 * nw, nj, nw)
+    so = O.OracleSolver([O.OracleZone(pint, preal, FastC.level_buffer(z), metrics[0][0], wall_distance(z))], [(0, rp, 0, dp)])
+    sr = R.RefSolver([R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], FastC.level_buffer(z), metrics[0][0], wall_distance(z))],
+                     [(0, rp, 0, dp)])
+    assert int(pint[25]) == 3
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 7):
+        so.step(); sr.step(it)
+        d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(so.zones[0].neq, -1).max(axis=1)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
+
+
 def test_roe_with_walls_is_refused_by_the_oracle():
     """The reference corrects the roe flux on wall faces (BC/bfl3.for); that correction is not
     restated, so the combination is refused rather than computed without it."""
