@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from fast_amd import cases, connect, FastC, Internal
 from oracle import ref_harness as R
-from common import prepare, zone_arrays
+from common import prepare, zone_arrays, wall_distance
 
 SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
 
@@ -57,6 +57,16 @@ CASES = {
     'implicit_channel_curv':    ('tgv', (10, 9, 8), 'ausmpred', 'NSLaminar', (1, 1, 1), 'single', 8,
                                  {'jmin': 'BCWall', 'jmax': 'BCWallViscous', 'kmin': 'BCFarfield'},
                                  {'ss_iteration': 4, 'time_step': 0.02, 'perturb': 0.15}),
+    # Spalart-Allmaras (6 equations; the wall distance is stored with the inputs), two-dimensional zones
+    # (kind 'tgv2d', n = (ni, nj)) and the NACA0012 C-mesh (kind 'naca', n = (nfoil, nwake, nj)): steady-RANS
+    # set-up of the reference, SA + implicit LU-SGS + local time step + wall / far field / wake match join
+    'sa_channel_ausmpred':      ('tgv', (10, 9, 8), 'ausmpred', 'NSTurbulent', (1, 1, 1), 'single', 10,
+                                 {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}),
+    'sa_implicit_curv_roe':     ('tgv', (10, 9, 8), 'roe', 'NSTurbulent', (1, 1, 1), 'single', 6, None,
+                                 {'ss_iteration': 3, 'time_step': 0.02, 'perturb': 0.15}),
+    'plane2d_senseur_lamin':    ('tgv2d', (14, 10), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 20,
+                                 {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {'perturb': 0.15}),
+    'naca0012_sa_implicit':     ('naca', (16, 6, 10), 'ausmpred', 'NSTurbulent', (1, 1, 1), 'single', 20),
     'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
     'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
 }
@@ -72,7 +82,29 @@ def build(kind, n, scheme, model, blocks, cache, bcs=None, opts=None, modulo_ver
             kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': opts['ss_iteration']}}
         return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra, bcs=bcs, modulo_verif=modulo_verif,
                          perturb=opts.get('perturb', 0.), time_step=opts.get('time_step'), **kw)
+    if kind == 'tgv2d':
+        kw = {}
+        if 'ss_iteration' in opts:
+            kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': opts['ss_iteration']}}
+        return cases.tgv2d(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=opts.get('perturb', 0.),
+                           time_step=opts.get('time_step'), extra_numb={'modulo_verif': modulo_verif}, **kw)
+    if kind == 'naca':
+        return cases.naca_cmesh(nfoil=n[0], nwake=n[1], nj=n[2], scheme=scheme, model=model, extra_numz=extra,
+                                extra_numb={'modulo_verif': modulo_verif})
     return cases.vortex(n, scheme, extra_numz=extra)
+
+
+def case_joins(kind, n, blocks):
+    """[(receiver_zone, donor_zone, receiver_pts, donor_pts)] of a case."""
+    if kind == 'naca':
+        rp, dp = connect.cmesh_wake_join(2 * n[0] + 2 * n[1], n[2], n[1])
+        return [(0, 0, rp, dp)]
+    if blocks == (1, 1, 1):
+        return []
+    if isinstance(n, int):
+        n = (n, n, n)
+    nv = tuple(n[d] // blocks[d] for d in range(3))
+    return connect.periodic_block_joins(blocks, nv)
 
 
 def main():
@@ -93,18 +125,17 @@ def main():
         for b, (z, m) in enumerate(zip(zones, metrics)):
             pint, preal, xyz = zone_arrays(z)
             ro0 = FastC.level_buffer(z).copy()
-            rz.append(R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], ro0, m[0]))
+            dist = wall_distance(z)
+            rz.append(R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], ro0, m[0], dist))
+            if dist is not None:
+                out['dist%d' % b] = np.ascontiguousarray(dist.reshape(-1, order='F'))
             # metrics from the reference's own cp_tijk / cp_vol
             out['mtr%d' % b] = R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2])
             out['pint%d' % b] = np.asarray(pint, dtype=np.int32)
             out['preal%d' % b] = np.asarray(preal, dtype=np.float64)
             out['ro0_%d' % b] = ro0
-        joins = []
-        if nb > 1:
-            if isinstance(n, int):
-                n = (n, n, n)
-            nv = tuple(n[d] // blocks[d] for d in range(3))
-            joins = [(br, r, bd, d) for br, bd, r, d in connect.periodic_block_joins(blocks, nv)]
+        joins = [(br, r, bd, d) for br, bd, r, d in case_joins(kind, n, blocks)]
+        if joins:
             out['njoin'] = np.int32(len(joins))
             for q, (br, r, bd, d) in enumerate(joins):
                 out['join%d_zones' % q] = np.array([br, bd], dtype=np.int32)
@@ -119,7 +150,7 @@ def main():
         for it in range(1, nit + 1):
             s.step(it)
             for b, (l2, loo) in enumerate(s.residuals()):
-                res[it - 1, b, 0] = l2; res[it - 1, b, 1] = loo
+                res[it - 1, b, 0] = l2[:5]; res[it - 1, b, 1] = loo[:5]
             if it in (1, 3, nit):
                 for b in range(nb):
                     out['ro_it%d_%d' % (it, b)] = rz[b].ro.copy()

@@ -14,7 +14,8 @@ GOLD = sorted(glob.glob(os.path.join(HERE, 'golden', '*.npz')))
 def load(path):
     g = np.load(path)          # allow_pickle stays False
     nb = int(g['nzone'])
-    zones = [O.OracleZone(g['pint%d' % b], g['preal%d' % b], g['ro0_%d' % b], g['mtr%d' % b]) for b in range(nb)]
+    zones = [O.OracleZone(g['pint%d' % b], g['preal%d' % b], g['ro0_%d' % b], g['mtr%d' % b],
+                          g['dist%d' % b] if 'dist%d' % b in g.files else None) for b in range(nb)]
     joins = []
     if 'njoin' in g.files:
         for q in range(int(g['njoin'])):
@@ -37,14 +38,15 @@ def test_oracle_bit_exact_single_cache_block(path):
     s.fill_ghostcells()
     for b, z in enumerate(zones):
         assert np.array_equal(z.ro, g['ghost_%d' % b]), "ghost fill, zone %d" % b
+        z.ro_m1[:] = z.ro; z.ro_p1[:] = z.ro
     nit = int(g['nit'])
     res = g['residuals']
     for it in range(1, nit + 1):
         s.step()
         for b, z in enumerate(zones):
             l2, loo = z.residuals()
-            np.testing.assert_allclose(l2, res[it - 1, b, 0], rtol=1e-12, atol=1e-300)
-            np.testing.assert_allclose(loo, res[it - 1, b, 1], rtol=1e-12, atol=1e-300)
+            np.testing.assert_allclose(l2[:5], res[it - 1, b, 0], rtol=1e-12, atol=1e-300)
+            np.testing.assert_allclose(loo[:5], res[it - 1, b, 1], rtol=1e-12, atol=1e-300)
             key = 'ro_it%d_%d' % (it, b)
             if key in g.files:
                 assert np.array_equal(z.ro, g[key]), "step %d zone %d: max abs diff %g" % (
