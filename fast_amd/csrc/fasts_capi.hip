@@ -336,6 +336,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     // dispatch of Fast/FastS/FastS/BC/BCzone.cpp:262-283,451-461,513-523,578-586
     const int tag = w.type;
     if (tag == 11 || tag == 0 || tag == 1) w.type = tag;
+    else if ((tag == 13 || tag == 2) && p[pt + 8] == 0) w.type = tag;   // BCInflow / BCInflowSupersonic on the reference state
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
     else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
     else {
@@ -398,6 +399,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     for (int ndf = 0; ndf < nb; ndf++) {
       const int pt = p[pt_bcs + 1 + ndf], tag = p[pt], idir = p[pt + 1];
       if (tag == 22 || idir < 1 || idir > 6 || lskip[idir - 1]) continue;
+      if (tag == 13)
+        return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: BCInflow on a zone face that also carries a wall is not implemented with the implicit scheme");
       FsBcWin w;
       memset(&w, 0, sizeof w);
       w.idir = idir;

@@ -296,12 +296,23 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         rop[l + 4 * nd] = rop[lm + 4 * nd];
         if (z.neq == 6) rop[l + 5 * nd] = rop[lm + 5 * nd];    // BCWallInviscidSA_i.for
       }
-    } else {  // FS_BC_FARFIELD
+    } else {  // FS_BC_FARFIELD, FS_BC_INFLOW (same characteristic state, BCInflow_i.for), FS_BC_SUPERSONIC
       const double snorm = (w.idir & 1) ? -1. : 1.;
-      double tc[3];
-      fs_bc_metric(z, w, d, q, tc);
-      const bool inflow = fs_bc_farfield_first(z, w.st, tc[0] * snorm, tc[1] * snorm, tc[2] * snorm, rop, l1 - inc, l1);
-      if (z.neq == 6) rop[l1 - inc + 5 * nd] = inflow ? w.nue : rop[l1 + 5 * nd];   // BCFarfield_firstrank_SA.for
+      if (w.type == FS_BC_SUPERSONIC) {   // first rank = reference state (BCInflowSupersonic_i.for)
+        const long long l = l1 - inc;
+        const double ro_state = w.st[0], u_state = w.st[1] / w.st[0], v_state = w.st[2] / w.st[0], w_state = w.st[3] / w.st[0];
+        const double t_state = (w.st[4] - 0.5 * ro_state * (u_state * u_state + v_state * v_state + w_state * w_state)) /
+                               (ro_state * z.cv);
+        rop[l] = ro_state; rop[l + nd] = u_state; rop[l + 2 * nd] = v_state; rop[l + 3 * nd] = w_state;
+        rop[l + 4 * nd] = t_state;
+        if (z.neq == 6) rop[l + 5 * nd] = w.nue;
+      } else {
+        double tc[3];
+        fs_bc_metric(z, w, d, q, tc);
+        const bool inflow = fs_bc_farfield_first(z, w.st, tc[0] * snorm, tc[1] * snorm, tc[2] * snorm, rop, l1 - inc, l1);
+        // BCFarfield_firstrank_SA.for; BCInflowSA_i.for always takes the state value
+        if (z.neq == 6) rop[l1 - inc + 5 * nd] = (inflow || w.type == FS_BC_INFLOW) ? w.nue : rop[l1 + 5 * nd];
+      }
       const double c4 = 5. / 6., c5 = 2. / 6., c6 = -1. / 6.;
       const double c0 = 1. / c6, c1 = -(c4 + c5) * c0, c2 = -c6 * c0, c3 = (2. - c5 - c4) * c0;
       for (int r = 2; r <= nr; r++) {   // BC_nextrank.for

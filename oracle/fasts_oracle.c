@@ -1075,8 +1075,21 @@ void fo_bc_wall_inviscid(const i32 *p, int idir, const i32 *cl, double *rop, con
 #define VYINF 20
 #define VZINF 21
 #define PINF 4
+static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
+                             const double *tj, const double *tk, int mode);
 void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
                     const double *tj, const double *tk)
+{
+  fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 0);
+}
+
+/* mode 0: BCFarfield.  mode 1: BCInflow without data = the same characteristic state from the reference state
+ * (bvbs_inflow.for, BCInflow_i.for, BCInflow_init.for), nu_tilde always taken from the state (BCInflowSA_i.for).
+ * mode 2: BCInflowSupersonic without data: the first ghost rank takes the reference state
+ * (bvbs_inflow_supersonic.for:127-135, BCInflowSupersonic_i.for), the next ranks are extrapolated as for the
+ * far field. */
+static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
+                             const double *tj, const double *tk, int mode)
 {
   GEOM(p)
   const fo_face f = fo_face_of(p, idir);
@@ -1101,7 +1114,14 @@ void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, dou
         const long l1 = INDDM(i, j, k);      /* first interior cell */
         long l = l1 - inc;                   /* first ghost rank */
         fo_bc_metric(p, idir, i, j, k, ti, tj, tk, tc);
-        {
+        if (mode == 2) {
+          const double ro_state = st[0], u_state = st[1] / st[0], v_state = st[2] / st[0], w_state = st[3] / st[0];
+          const double t_state = (st[4] - 0.5 * ro_state * (u_state * u_state + v_state * v_state + w_state * w_state)) /
+                                 (ro_state * pr[CVINF]);
+          rop[l] = ro_state; rop[l + nd] = u_state; rop[l + 2 * nd] = v_state; rop[l + 3 * nd] = w_state;
+          rop[l + 4 * nd] = t_state;
+          if (p[NEQ] == 6) rop[l + 5 * nd] = pr[8] / st[0];
+        } else {
           double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
           double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
           double roi = rop[l1], rui = rop[l1 + nd] * roi, rvi = rop[l1 + 2 * nd] * roi, rwi = rop[l1 + 3 * nd] * roi;
@@ -1151,7 +1171,7 @@ void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, dou
           rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
           rop[l + 4 * nd] = (qvar5 * roinv - .5 * (u * u + v * v + w * w)) * cvinv;
           if (p[NEQ] == 6)   /* BCFarfield_firstrank_SA.for, BCFarfield_init.for: nue = state(6)/state(1) */
-            rop[l + 5 * nd] = eigv1 < 0. ? pr[8] / roe : rop[l1 + 5 * nd];
+            rop[l + 5 * nd] = (mode == 1 || eigv1 < 0.) ? pr[8] / roe : rop[l1 + 5 * nd];
         }
         for (int r = 2; r <= f.nr; r++) {   /* next ranks, outwards */
           l = l1 - r * inc;
@@ -1258,6 +1278,8 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     else if (type == 22) continue;
     else if (type == 0) fo_bc_extrapolate(p, idir, cl, rop);
     else if (type == 1) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
+    else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1);
+    else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2);
     else if (p[KFLUDOM] == 5 && type >= 3 && type <= 6)
       return -1; /* roe + walls: the wall-face flux correction (BC/bfl3.for) is not restated */
     else if (type == 3 || (type == 4 && p[IFLOW] == 1) || type == 5) fo_bc_wall_inviscid(p, idir, cl, rop, ti, tj, tk);
@@ -1706,6 +1728,10 @@ int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *t
     const int pt = p[pt_bcs + 1 + ndf], type = p[pt], idir = p[pt + 1];
     if (type == 12 || type == 18 || type == 30) return -1;
     if (type >= 3 && type <= 7) { lskip[idir - 1] = 0; any = 1; }
+  }
+  for (int ndf = 0; ndf < nb; ndf++) {   /* BCInflow keeps its own treatment of the residual: not restated */
+    const int pt = p[pt_bcs + 1 + ndf];
+    if (p[pt] == 13 && !lskip[p[pt + 1] - 1]) return -1;
   }
   for (int d = 0; d < 3; d++) {
     lu[2 * d] = sdm[2 * d] - (1 - lskip[2 * d]);

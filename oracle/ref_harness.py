@@ -215,10 +215,16 @@ class RefSolver:
                                     _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
             elif btype == 22:
                 pass   # BCOverlap: ghost cells come from the join transfer
-            elif btype in (1, 3, 4, 5, 6):
-                # dispatch of Fast/FastS/FastS/BC/BCzone.cpp:279-283,451-461,513-523 (these use ind_CL)
+            elif btype in (1, 2, 3, 4, 5, 6, 13):
+                # dispatch of Fast/FastS/FastS/BC/BCzone.cpp:279-283,299-310,417-425,451-461,513-523 (these use ind_CL)
+                if int(p[pt_bc + 8]) != 0:
+                    raise NotImplementedError("ref_harness: BC data")
                 if btype == 1:
                     fn = L.bvbs_farfield_
+                elif btype == 13:
+                    fn = L.bvbs_inflow_
+                elif btype == 2:
+                    fn = L.bvbs_inflow_supersonic_
                 elif btype == 3 or (btype == 4 and p[IFLOW] == 1) or btype == 5:
                     fn = L.bvbs_wall_inviscid_
                 elif p[IFLOW] > 1:

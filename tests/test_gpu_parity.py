@@ -48,6 +48,7 @@ BC_CASES = [
     ('Euler', 'senseur', (10, 12, 9), {'jmin': 'BCWall', 'kmax': 'BCWallInviscid', 'imin': 'BCSymmetryPlane'}),
     ('NSLaminar', 'senseur', (9, 8, 10), FAR),
     ('Euler', 'roe', (8, 9, 7), {'imin': 'BCExtrapolate', 'imax': 'BCFarfield', 'kmin': 'BCExtrapolate'}),
+    ('NSLaminar', 'ausmpred', (9, 8, 10), {'imin': 'BCInflow', 'imax': 'BCFarfield', 'jmin': 'BCWall', 'kmax': 'BCInflowSupersonic'}),
 ]
 
 
@@ -75,8 +76,8 @@ def test_unsupported_options_are_refused():
     t = cases.tgv(8, 'roe', model='Euler', bcs={'jmin': 'BCWall'})
     with pytest.raises(_capi.FastsHipError, match="wall-face flux correction"):
         FastS.warmup(t, None)
-    t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCInflow'})
-    with pytest.raises(_capi.FastsHipError, match="tag 13"):
+    t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCOutflow'})
+    with pytest.raises(_capi.FastsHipError, match="tag 10"):
         FastS.warmup(t, None)
     t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'nb_relax': 2})
     with pytest.raises(_capi.FastsHipError, match="nb_relax"):

@@ -21,6 +21,7 @@ CASES = [
     ((12, 9, 10), 'ausmpred', {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 6),
     ((10, 9, 8), 'senseur', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, 5),
     ((12, 10, 9), 'roe', None, 6),
+    ((10, 9, 8), 'senseur', {'imin': 'BCInflow', 'imax': 'BCExtrapolate', 'jmax': 'BCInflowSupersonic'}, 5),
 ]
 
 

@@ -53,6 +53,8 @@ FAR = {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')
     ('Euler', 'senseur', {'jmin': 'BCWall', 'imin': 'BCWall'}),          # tag 4 is a slip wall for Euler
     ('NSLaminar', 'senseur', FAR),
     ('Euler', 'roe', {'imin': 'BCExtrapolate', 'imax': 'BCExtrapolate', 'jmax': 'BCFarfield', 'kmin': 'BCExtrapolate'}),
+    ('NSLaminar', 'ausmpred', {'imin': 'BCInflow', 'imax': 'BCFarfield', 'jmin': 'BCWall', 'kmax': 'BCInflowSupersonic'}),
+    ('NSTurbulent', 'senseur', {'imin': 'BCInflow', 'imax': 'BCExtrapolate', 'jmax': 'BCInflowSupersonic'}),
 ])
 def test_boundary_conditions_bit_exact(model, scheme, bcs):
     """Ghost fill of walls, far field and extrapolation against bvbs_wall_viscous_adia /
