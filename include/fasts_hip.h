@@ -84,7 +84,9 @@ int fs_set_first_it(fs_ctx *ctx, int first_it);
  * scalars.  Curvilinear zone (ITYPZONE 0): ti,tj,tk(NDIMDX_MTR,3) and vol(NDIMDX_MTR), dimensioned
  * on the nodes with the strides of NIJK_MTR (Fast/FastC/FastC/Metric/nature_geom_dom.for:186-503,
  * cp_tijk.for:60-123, cp_vol.for:55-93); the array is copied to the device during this call.
- * Zone types 1 (k-homogeneous) and 3 (2-D) return FS_ERR_UNSUPPORTED. */
+ * Two-dimensional zone (ITYPZONE 3: one cell along k, NIJK(5) = 0): ti,tj(NDIMDX_MTR,2) and vol(NDIMDX_MTR)
+ * on the nodes of one k-plane, no tk (nature_geom_dom.for:186-198, cp_tijk.for:376-402, cp_vol.for:177-212).
+ * Zone type 1 (k-homogeneous) returns FS_ERR_UNSUPPORTED. */
 int fs_zone_add(fs_ctx *ctx, const int32_t *param_int, int n_int, const double *param_real,
                 int n_real, double *ro, double *ro_m1, double *ro_p1, const double *mtr,
                 int n_mtr);
