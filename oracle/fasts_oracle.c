@@ -1280,14 +1280,103 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     else if (type == 1) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
     else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1);
     else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2);
-    else if (p[KFLUDOM] == 5 && type >= 3 && type <= 6)
-      return -1; /* roe + walls: the wall-face flux correction (BC/bfl3.for) is not restated */
     else if (type == 3 || (type == 4 && p[IFLOW] == 1) || type == 5) fo_bc_wall_inviscid(p, idir, cl, rop, ti, tj, tk);
     else if ((type == 6 || type == 4) && p[IFLOW] > 1) fo_bc_wall_viscous(p, idir, cl, rop);
     else return -1;
   }
   fo_correct_coins(p, rop);
   return 0;
+}
+
+/* Wall-face flux correction of the roe scheme (Fast/FastS/FastS/BC/bfl3.for, CL_correction_flu.for): for every
+ * wall window, in the order of the BC table, the Euler roe flux that the balance put through the wall face is
+ * taken back (ROE/<type>/corr_fluroe_euler_o3_<type>.for with assemble_drodm_corr.for: iflow = 1, five
+ * equations) and the wall flux is put in its place: pressure only on a no-slip wall (tags 4, 6: bflwall.for),
+ * pressure + the mean normal mass flux on a slip wall (tag 3: bflwallslip.for).  c_ale = 0 (fixed mesh). */
+void fo_bfl3(const i32 *p, const double *pr, const double *rop, double *drodm, const double *wig,
+             const double *xmut, const double *ti, const double *tj, const double *tk, const double *vol)
+{
+  GEOM(p)
+  if (p[KFLUDOM] != 5) return;
+  const int pt_bcs = p[PT_BC], nb = p[pt_bcs];
+  if (nb == 0) return;
+  const i32 sdm[6] = {1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2]};
+  i32 pe[256];                 /* Euler view of the zone for the correction flux (iflow = 1) */
+  memcpy(pe, p, sizeof(i32) * 137);
+  pe[IFLOW] = 1;
+  fluxctx c;
+  fluxctx_init(&c, pe, pr, ti, tj, tk, vol);
+  const double rgp = pr[CVINF] * (pr[GAMMA] - 1.), gam2 = pr[GAMMA] / (pr[GAMMA] - 1.);
+  const long strides[3] = {1, ni, ninj};
+  for (int ndf = 0; ndf < nb; ndf++) {
+    const int pt = p[pt_bcs + 1 + ndf], type = p[pt], idir = p[pt + 1];
+    if (type != 3 && type != 4 && type != 6 && type != 7 && type != 12) continue;
+    i32 cl[6];
+    if (fo_indice_cl(idir, p, p + pt + 2, sdm, cl)) continue;
+    const int d = (idir - 1) / 2, maxside = idir % 2 == 0;
+    if (!maxside) { cl[2 * d] = 1; cl[2 * d + 1] = 1; }
+    else cl[2 * d + 1] = cl[2 * d];
+    const long inc = strides[d], shift = maxside ? inc : 0;
+    /* 1. take the roe flux of the wall face back */
+    {
+      const double sens = maxside ? 1. : -1.;
+      double f[6];
+      for (int k = cl[4]; k <= cl[5]; k++)
+        for (int j = cl[2]; j <= cl[3]; j++)
+          for (int i = cl[0]; i <= cl[1]; i++) {
+            const long l = INDDM(i, j, k), l0 = l - shift;
+            if (c.ityp == 0 || c.ityp == 3) face_flux_full(&c, rop, wig, xmut, l, INDMTR(p, i, j, k), d, f);
+            else face_flux(&c, rop, wig, xmut, l, d, f);
+            for (int e = 0; e < 5; e++) drodm[l0 + e * nd] = drodm[l0 + e * nd] + f[e] * sens;
+          }
+    }
+    /* 2. wall flux */
+    {
+      const double sens = maxside ? -1. : 1.;
+      const int slip = type == 3;
+      if (type != 3 && type != 4 && type != 6) continue;   /* tags 7, 12: walls with data, not restated */
+      for (int k = cl[4]; k <= cl[5]; k++)
+        for (int j = cl[2]; j <= cl[3]; j++)
+          for (int i = cl[0]; i <= cl[1]; i++) {
+            const long l = INDDM(i, j, k), iadrf = l - inc, l0 = l - shift;
+            /* face metric at the loop cell: its min face is the wall face on both sides */
+            double tc[3];
+            {
+              int q[3] = {i, j, k};
+              if (maxside) q[d] -= 1;   /* fo_bc_metric adds 1 on a max face */
+              fo_bc_metric(p, idir, q[0], q[1], q[2], ti, tj, tk, tc);
+            }
+            const double tcx = tc[0], tcy = tc[1], tcz = tc[2];
+            const double qen = (0. * tcx + 0. * tcy + 0. * tcz * 0.) * 0.;
+            double r = 0.5 * (rop[l] + rop[iadrf]);
+            double u = 0.5 * (rop[l + nd] + rop[iadrf + nd]);
+            double v = 0.5 * (rop[l + 2 * nd] + rop[iadrf + 2 * nd]);
+            double w = 0.5 * (rop[l + 3 * nd] + rop[iadrf + 3 * nd]);
+            const double u_int = tcx * u + tcy * v + tcz * w - qen;
+            double fl[6] = {0., 0., 0., 0., 0., 0.};
+            if (!slip) {
+              const double pp = 0.5 * (rop[l + 4 * nd] * rop[l] + rop[iadrf + 4 * nd] * rop[iadrf]) * rgp;
+              fl[0] = 0.;
+              fl[1] = tcx * pp + u_int * u * r;
+              fl[2] = tcy * pp + u_int * v * r;
+              fl[3] = tcz * pp + u_int * w * r;
+              fl[4] = pp * qen;
+            } else {
+              if (p[NEQ] == 6) { r = rop[iadrf]; u = rop[iadrf + nd]; v = rop[iadrf + 2 * nd]; w = rop[iadrf + 3 * nd]; }
+              double pp = rop[iadrf + 4 * nd] * rop[iadrf] * rgp;
+              const double h = gam2 * pp + r * (u * u + v * v + w * w) * 0.5;
+              pp = 0.5 * (rop[l + 4 * nd] * rop[l] + rop[iadrf + 4 * nd] * rop[iadrf]) * rgp;
+              fl[0] = u_int * r;
+              fl[1] = tcx * pp + u_int * r * u;
+              fl[2] = tcy * pp + u_int * r * v;
+              fl[3] = tcz * pp + u_int * r * w;
+              fl[4] = u_int * h + pp * qen;
+              if (p[NEQ] == 6) fl[5] = u_int * r * rop[iadrf + 5 * nd];
+            }
+            for (int e = 0; e < p[NEQ]; e++) drodm[l0 + e * nd] = drodm[l0 + e * nd] + fl[e] * sens;
+          }
+    }
+  }
 }
 
 /* One sub-iteration of one zone with a single cache block and no neighbouring thread:
@@ -1322,6 +1411,7 @@ void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in
     fo_spsource_SA(p, pr, nitcfg, sdm, rop_in, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_in, wig);
   fo_flux(p, pr, sdm, rop_in, drodm, wig, xmut, ti, tj, tk, vol);
+  fo_bfl3(p, pr, rop_in, drodm, wig, xmut, ti, tj, tk, vol);
   fo_core3ark3(p, pr, nitcfg, sdm, rop_out, rop_in, drodm, coe);
 }
 
@@ -1796,6 +1886,7 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   }
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_ss, wig);
   fo_flux(p, pr, sdm, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);
+  fo_bfl3(p, pr, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);
   fo_core3as2(p, pr, nitcfg, first_it, sdm, rop_ss, ro, ro_m1, drodm, coe);
   if (newton_rhs) memcpy(newton_rhs, drodm, sizeof(double) * p[NEQ] * (size_t)p[NDIMDX]);
   i32 lu[6];

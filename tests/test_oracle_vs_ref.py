@@ -337,13 +337,34 @@ def test_naca0012_cmesh_bit_exact(scheme, model, temporal):
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
 
 
-def test_roe_with_walls_is_refused_by_the_oracle():
-    """The reference corrects the roe flux on wall faces (BC/bfl3.for); that correction is not
-    restated, so the combination is refused rather than computed without it."""
-    t = cases.tgv(6, 'roe', model='Euler', bcs={'jmin': 'BCWall'})
-    so, _ = _pair(t)
-    with pytest.raises(NotImplementedError):
-        so.fill_ghostcells()
+@pytest.mark.parametrize("model,perturb,dim,bcs,implicit", [
+    ('Euler', 0., 3, {'jmin': 'BCWall', 'jmax': 'BCWallInviscid'}, False),
+    ('NSLaminar', 0., 3, {'jmin': 'BCWall', 'kmax': 'BCWallViscous', 'imin': 'BCSymmetryPlane'}, False),
+    ('NSLaminar', 0.15, 3, {'jmin': 'BCWall', 'jmax': 'BCWallInviscid', 'imax': 'BCFarfield'}, False),
+    ('NSTurbulent', 0.15, 3, {'jmin': 'BCWall', 'jmax': 'BCWallInviscid'}, False),
+    ('NSLaminar', 0.15, 2, {'jmin': 'BCWall', 'jmax': 'BCFarfield', 'imin': 'BCWallInviscid'}, False),
+    ('NSLaminar', 0., 3, {'jmin': 'BCWall', 'jmax': 'BCWallInviscid'}, True),
+    ('NSTurbulent', 0.15, 2, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, True),
+])
+def test_roe_wall_flux_correction_bit_exact(model, perturb, dim, bcs, implicit):
+    """roe + walls: the flux through a wall face is replaced by the wall flux (BC/bfl3.for, bflwall.for,
+    bflwallslip.for, corr_fluroe_euler_o3_*.for)."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    kw = dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3}) if implicit else {}
+    if dim == 3:
+        t = cases.tgv((9, 8, 7), 'roe', model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **kw)
+    else:
+        t = cases.tgv2d((10, 8), 'roe', model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **kw)
+    so, sr = _pair(t)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(so.zones[0].neq, -1).max(axis=1)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
 
 
 @pytest.mark.parametrize("blocks,nn", [((2, 1, 1), (12, 6, 6)), ((1, 1, 3), (6, 6, 15)), ((2, 2, 2), (8, 8, 8))])
