@@ -47,6 +47,9 @@ struct Zone {
   int *shell_dev = nullptr, *inner_dev = nullptr;
   int n_shell = 0, n_inner = 0;
   bool has_sends = false;         // some of its cells are donors of joins to other contexts
+  // roe + walls: windows whose wall-face flux is corrected after the balance (BC/bfl3.for), in BC-table order
+  struct RoeWall { int tag, idir, lo[3], hi[3]; };
+  std::vector<RoeWall> roe_walls;
   hipEvent_t ev_part = nullptr;   // start of a split stage (timing)
 };
 
@@ -344,10 +347,6 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       snprintf(msg, sizeof msg, "fs_zone_add: boundary condition tag %d is not implemented", tag);
       return fail(ctx, FS_ERR_UNSUPPORTED, msg);
     }
-    if ((w.type == FS_BC_WALL_SLIP || w.type == FS_BC_WALL_NOSLIP) && p[KFLUDOM] == 5)
-      return fail(ctx, FS_ERR_UNSUPPORTED,
-                  "fs_zone_add: the wall-face flux correction of the roe scheme (bfl3) is not implemented; "
-                  "use ausmpred or senseur with wall boundaries");
     if (p[pt + 8] != 0 && tag != 11)
       return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: boundary conditions carrying their own data are not implemented");
     if (w.idir < 1 || w.idir > 6) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window is not on a zone face");
@@ -368,7 +367,15 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
     if (cells > zn.bc_max_cells) zn.bc_max_cells = cells;
     zn.bc.push_back(w);
+    if (p[KFLUDOM] == 5 && (tag == 3 || tag == 4 || tag == 6)) {   // bfl3.for:58-63 (tag 5 is not corrected)
+      Zone::RoeWall rw;
+      rw.tag = tag; rw.idir = w.idir;
+      for (int a = 0; a < 3; a++) { rw.lo[a] = w.lo[a]; rw.hi[a] = w.hi[a]; }
+      zn.roe_walls.push_back(rw);
+    }
   }
+  if (!zn.roe_walls.empty() && (ctx->plain_stage || !ctx->dma_stage))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: roe with wall boundaries needs the default stage kernels");
   if (implicit) {
     // BCzone with lrhs = 1 (Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,262-264): faces that carry a wall
     // BC (tags 3..7) get the ghost residual zeroed over the whole face (extrapolation with c1 = 0), then their BCs
@@ -612,7 +619,7 @@ static int build_shell_lists(fs_ctx *ctx)
     Zone &zn = ctx->zones[nz];
     const FsZone &z = zn.z;
     for (auto &s : ctx->sends) if (s.donor_zone == (int)nz) zn.has_sends = true;
-    if (z.ityp == 0 || ctx->implicit || z.iflow == 3) continue;   // curvilinear / implicit / SA zones run their stage in one piece
+    if (z.ityp == 0 || ctx->implicit || z.iflow == 3 || !zn.roe_walls.empty()) continue;   // these zones run their stage in one piece
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
     std::vector<char> mark((size_t)nblk, 0);
@@ -692,12 +699,19 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       HIPCHK(ctx, hipEventRecord(zn.ev_part, ctx->stream));
     }
     int krc = 0;
+    // roe + walls: the stage kernel runs in Runge-Kutta form and leaves the balance in drodm; the wall rows are
+    // corrected and the end of the stage redone below.  Implicit scheme: balance from zero at every
+    // sub-iteration, the (unused) update goes to the spare level.
+    const bool deferred = !zn.roe_walls.empty();
+    const FsBdf *kbdf = deferred ? nullptr : pbdf;
+    const int kfirst = deferred && ctx->implicit ? 1 : (nstep == 1);
+    double *kout = deferred && ctx->implicit ? zn.scratch : zn.dev[out];
     if (z.iflow == 3 && z.ityp != 0)
-      krc = fsk_stage_sa(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.dist,
-                         (unsigned char *)zn.wig, pbdf, ctx->stream);
+      krc = fsk_stage_sa(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut, zn.dist,
+                         (unsigned char *)zn.wig, kbdf, ctx->stream);
     else if (z.ityp == 0)
-      krc = fsk_stage_full(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
-                           (unsigned char *)zn.wig, pbdf, zn.dist, ctx->stream);
+      krc = fsk_stage_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
+                           (unsigned char *)zn.wig, kbdf, zn.dist, ctx->stream);
     else if (ctx->plain_stage)
       krc = fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
     else if (!ctx->dma_stage)
@@ -707,11 +721,18 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
       const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
       if (!split || nlist > 0)
-        krc = fsk_stage_dma(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
-                            (unsigned char *)zn.wig, blist, nlist, pbdf, ctx->stream);
+        krc = fsk_stage_dma(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
+                            (unsigned char *)zn.wig, blist, nlist, kbdf, ctx->stream);
     }
     if (krc)
       return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": no kernel for this scheme / model");
+    if (deferred) {
+      for (auto &rw : zn.roe_walls) fsk_roe_wall(z, rw.idir, rw.lo, rw.hi, rw.tag, zn.dev[in], zn.drodm, ctx->stream);
+      if (ctx->implicit) fsk_finish_bdf(z, zn.dev[in], zn.drodm, bdf, ctx->stream);
+      else
+        for (auto &rw : zn.roe_walls)
+          fsk_finish_wall_rows(z, rw.idir, rw.lo, rw.hi, coefW, zn.dev[in], zn.dev[out], zn.drodm, ctx->stream);
+    }
     if (!closes) continue;
     if (ctx->timing) {   // one timed interval per stage, from its first launch to its last
       if (ctx->ev_used == ctx->ev.size()) {

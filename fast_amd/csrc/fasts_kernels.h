@@ -68,3 +68,11 @@ void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, doub
 // range[6] = cells swept (interior, plus one ghost layer on wall faces)
 int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out, double *scratch,
               double *dw, const double *coe, hipStream_t s);
+
+// roe + walls (fasts_wallflux.hip): correction of the balance on the cells next to one wall window (glo/ghi = its
+// ghost-cell window, tag = BC tag of the reference), then the end of the stage redone from the corrected balance
+void fsk_roe_wall(const FsZone &z, int idir, const int *glo, const int *ghi, int tag, const double *rop, double *drodm,
+                  hipStream_t s);
+void fsk_finish_wall_rows(const FsZone &z, int idir, const int *glo, const int *ghi, double coefW, const double *rop_in,
+                          double *rop_out, double *drodm, hipStream_t s);
+void fsk_finish_bdf(const FsZone &z, const double *rop_in, double *drodm, const FsBdf &bdf, hipStream_t s);

@@ -73,9 +73,6 @@ def test_boundary_conditions_bit_exact(model, scheme, n, bcs):
 
 def test_unsupported_options_are_refused():
     from fast_amd import cases
-    t = cases.tgv(8, 'roe', model='Euler', bcs={'jmin': 'BCWall'})
-    with pytest.raises(_capi.FastsHipError, match="wall-face flux correction"):
-        FastS.warmup(t, None)
     t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCOutflow'})
     with pytest.raises(_capi.FastsHipError, match="tag 10"):
         FastS.warmup(t, None)
