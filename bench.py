@@ -85,6 +85,10 @@ def main():
                     'this many Newton sub-iterations; not the headline workload')
     ap.add_argument('--perturb', type=float, default=0., help='node displacement in mesh steps: > 0 makes the block '
                     'curvilinear (per-cell metrics); not the headline workload')
+    ap.add_argument('--naca', type=int, default=0, metavar='NFOIL', help='steady-RANS set-up on a two-dimensional NACA0012 '
+                    'C-mesh (Spalart-Allmaras, implicit LU-SGS, local time step; 2*NFOIL + 2*(NFOIL/3) cells around, '
+                    '2*NFOIL/3 across; Newton sub-iterations from --implicit, default 3); not the headline workload')
+    ap.add_argument('--cfl', type=float, default=1., help='CFL number of the local time step (--naca)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -115,7 +119,22 @@ def main():
 
     if (a.perturb or a.implicit) and world > 1:
         raise SystemExit("bench.py: --perturb / --implicit are single-GPU options")
-    if world == 1:
+    if a.naca and world > 1:
+        raise SystemExit("bench.py: --naca is a single-GPU option")
+    if a.naca:
+        from fast_amd import connect
+        import fast_amd.pytree_lite as C
+        nf, nw, nj = a.naca, a.naca // 3, 2 * a.naca // 3
+        a.implicit = a.implicit or 3
+        t = cases.naca_cmesh(nfoil=nf, nwake=nw, nj=nj, scheme=a.scheme, ss_iteration=a.implicit, cfl=a.cfl)
+        tc = C.node2Center(t)
+        rp, dp = connect.cmesh_wake_join(2 * nf + 2 * nw, nj, nw)
+        connect.add_joins_to_tc(tc, [(0, 0, rp, dp)], [z[0] for z in Internal.getZones(t)])
+        (t, tc, metrics) = FastS.warmup(t, tc, device=local_rank)
+        ctx = FastC.HOOK['ctx']
+        run_step = lambda it: FastS._compute(t, metrics, it, tc)
+        ncell_total = (2 * nf + 2 * nw) * nj
+    elif world == 1:
         kw = {}
         if a.implicit:
             kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': a.implicit}}
@@ -173,7 +192,7 @@ def main():
             with open(tf) as fh:
                 traffic = json.load(fh).get('traffic_bytes_per_launch')
         # algorithmic bytes per launch; per-cell metrics (9 surface-vector components + volume) are read once per stage
-        bpl = (BYTES_PER_CELL_STEP[a.scheme] + (240.0 if a.perturb else 0.)) / 3.0 * a.n ** 3
+        bpl = (BYTES_PER_CELL_STEP[a.scheme] + (240.0 if (a.perturb or a.naca) else 0.)) / 3.0 * (ncell_total // world)
         ach = bpl / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.
         out = {
             "metric": "Mcell-iter/s (fp64 RK3 TGV 256^3)",
@@ -183,12 +202,15 @@ def main():
             "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TGV Re=1600 M=0.1, %d^3 cells per GPU, NSLaminar, scheme=%s, RK3, periodic"
+            "config": {"workload": "NACA0012 C-mesh %d x %d cells, NSTurbulent (Spalart-Allmaras), scheme=%s, wall + far field + "
+                                   "wake match join" % (2 * a.naca + 2 * (a.naca // 3), 2 * a.naca // 3, a.scheme) if a.naca else
+                                   "TGV Re=1600 M=0.1, %d^3 cells per GPU, NSLaminar, scheme=%s, RK3, periodic"
                                    % (a.n, a.scheme) if model != 'Euler' else
                                    "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
                        "blocks": list(split_for(world) or (1, 1, 1)), "ghost_layers": 2,
-                       "mesh": "curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian",
-                       "time_scheme": "implicit BDF2 LU-SGS, %d Newton sub-iterations" % a.implicit if a.implicit else "explicit RK3"},
+                       "mesh": "two-dimensional C-mesh" if a.naca else ("curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"),
+                       "time_scheme": ("implicit BDF1 local time step, LU-SGS, %d Newton sub-iterations" if a.naca else
+                                       "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit if a.implicit else "explicit RK3"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n},

@@ -194,9 +194,12 @@ def naca_cmesh(nfoil=32, nwake=12, nj=16, radius=8., wall_step=2.e-3, scheme='au
     (implicit, local time step, Spalart-Allmaras) by default.  Returns t."""
     ni = 2 * nwake + 2 * nfoil
     # inner line: nodes 0..ni
-    xw = 1. + (radius - 1.) * (numpy.linspace(0., 1., nwake + 1) ** 2)        # wake abscissa, clustered at the TE
-    th = numpy.linspace(0., math.pi, nfoil + 1)
-    xf = 0.5 * (1. + numpy.cos(th))                                          # TE -> LE, cosine clustering
+    # section abscissa TE -> LE, clustered at the leading edge only (a closed trailing edge is too thin for
+    # clustered cells: their ghost cells would fold); wake abscissa stretched from the trailing-edge cell size
+    xf = 1. - numpy.sin(0.5 * math.pi * numpy.linspace(0., 1., nfoil + 1))
+    xf[-1] = 0.
+    pw = math.log((1. - xf[1]) / (radius - 1.)) / math.log(1. / nwake)
+    xw = 1. + (radius - 1.) * (numpy.linspace(0., 1., nwake + 1) ** pw)
     xin = numpy.concatenate([xw[::-1], xf[1:], xf[::-1][1:], xw[1:]])
     yin = numpy.concatenate([numpy.zeros(nwake + 1), -_naca0012_y(xf[1:]), _naca0012_y(xf[::-1][1:]), numpy.zeros(nwake)])
     yin[nwake + nfoil] = 0.
