@@ -111,7 +111,10 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
                 if blocks[2] == 1: faces += ['kmin', 'kmax']
                 if bcs:
                     for f in [f for f in faces if f in bcs]:
-                        C.addBC2Zone(z, bcs[f].lower() + ' ' + f, bcs[f], f)
+                        if isinstance(bcs[f], tuple):    # (type, {name: window data})
+                            C.addBC2Zone(z, bcs[f][0].lower() + ' ' + f, bcs[f][0], f, data=bcs[f][1])
+                        else:
+                            C.addBC2Zone(z, bcs[f].lower() + ' ' + f, bcs[f], f)
                     faces = [f for f in faces if f not in bcs]
                 _periodic_faces(z, faces)
                 zones.append(z)
@@ -121,7 +124,8 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
     state = C.getState(Internal.getNodeFromName(t, 'ReferenceState'))
     tgv_fields(t, state)
     if model in ('NSTurbulent', 'nsspalart'):
-        sa_fields(t, state, [f for f, b in (bcs or {}).items() if b.startswith('BCWall')], L1)
+        sa_fields(t, state, [f for f, b in (bcs or {}).items()
+                             if (b[0] if isinstance(b, tuple) else b).startswith('BCWall')], L1)
     if time_step is None:
         time_step = 0.003 * 32. / n          # tgvMpi.py:271 scaled with the mesh size
     numb = {'temporal_scheme': temporal_scheme, 'modulo_verif': modulo_verif}

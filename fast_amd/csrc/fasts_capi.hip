@@ -40,6 +40,9 @@ struct Zone {
   int lu[6] = {0, 0, 0, 0, 0, 0};
   double *res_part = nullptr, *res_out = nullptr;
   FsBcWin *bc_dev = nullptr;
+  std::vector<double> bc_data;          // window data of the BCs that carry their own, concatenated
+  std::vector<long long> bc_data_off;   // per entry of bc: offset in bc_data, -1 without data
+  double *bc_data_dev = nullptr;
   std::vector<FsBcWin> bc;
   long long bc_max_cells = 0;
   bool have_res = false;
@@ -153,7 +156,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
   for (auto &zn : ctx->zones) {
     for (int r = 0; r < 3; r++) (void)hipFree(zn.dev[r]);
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
-    (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev);
+    (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
@@ -342,14 +345,34 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     else if ((tag == 13 || tag == 2) && p[pt + 8] == 0) w.type = tag;   // BCInflow / BCInflowSupersonic on the reference state
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
     else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
+    else if (tag == 16 || (tag == 32 && p[IFLOW] > 1)) w.type = tag;   // BCOutpres, BCWallViscousIsothermal: window data
     else {
       char msg[128];
       snprintf(msg, sizeof msg, "fs_zone_add: boundary condition tag %d is not implemented", tag);
       return fail(ctx, FS_ERR_UNSUPPORTED, msg);
     }
-    if (p[pt + 8] != 0 && tag != 11)
-      return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: boundary conditions carrying their own data are not implemented");
     if (w.idir < 1 || w.idir > 6) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window is not on a zone face");
+    long long data_off = -1;
+    w.data = nullptr; w.dlo[0] = w.dlo[1] = 0; w.dn = 1;
+    if (tag == 16 || tag == 32) {
+      // BCzone.cpp:257,545-551,577-585: one array of window data, optionally after/before a mesh-velocity
+      // coefficient of size 1; stored in Parameter_real at the pointer that follows the BC pointers
+      const int nbdata = p[pt + 8];
+      if (nbdata < 1 || nbdata > 2 || pt + 8 + nbdata >= n_int)
+        return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: BCOutpres / BCWallViscousIsothermal need one array of window data");
+      long long off = p[pt_bcs + 1 + ndf + nb];
+      int size = p[pt + 9];
+      if (size == 1) { off += 1; size = nbdata == 2 ? p[pt + 10] - p[pt + 9] : 0; }
+      const int32_t *fen = p + pt + 2;
+      const int da = w.idir <= 2 ? 1 : 0, db = w.idir <= 4 ? 2 : 1;
+      const int na = fen[2 * da + 1] - fen[2 * da] + 1, nbb = fen[2 * db + 1] - fen[2 * db] + 1;
+      if (size != na * nbb || off < 0 || off + size > n_real)
+        return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window data do not match the BC window");
+      data_off = (long long)zn.bc_data.size();
+      zn.bc_data.insert(zn.bc_data.end(), r + off, r + off + size);
+      w.dlo[0] = fen[2 * da]; w.dlo[1] = fen[2 * db]; w.dn = na;
+    } else if (p[pt + 8] != 0 && tag != 11)
+      return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: data on this boundary condition are not implemented");
     if (!bc_window(p, w.idir, p + pt + 2, w)) continue;
     // reference state of BCzone.cpp:26-38 and the face metric along the normal
     w.st[0] = r[ROINF]; w.st[1] = r[VXINF] * r[ROINF]; w.st[2] = r[VYINF] * r[ROINF]; w.st[3] = r[VZINF] * r[ROINF];
@@ -367,6 +390,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
     if (cells > zn.bc_max_cells) zn.bc_max_cells = cells;
     zn.bc.push_back(w);
+    zn.bc_data_off.push_back(data_off);
     if (p[KFLUDOM] == 5 && (tag == 3 || tag == 4 || tag == 6)) {   // bfl3.for:58-63 (tag 5 is not corrected)
       Zone::RoeWall rw;
       rw.tag = tag; rw.idir = w.idir;
@@ -406,8 +430,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     for (int ndf = 0; ndf < nb; ndf++) {
       const int pt = p[pt_bcs + 1 + ndf], tag = p[pt], idir = p[pt + 1];
       if (tag == 22 || idir < 1 || idir > 6 || lskip[idir - 1]) continue;
-      if (tag == 13)
-        return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: BCInflow on a zone face that also carries a wall is not implemented with the implicit scheme");
+      if (tag == 13 || tag == 32)
+        return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: BCInflow / BCWallViscousIsothermal on a zone face that also carries an adiabatic or slip wall is not implemented with the implicit scheme");
       FsBcWin w;
       memset(&w, 0, sizeof w);
       w.idir = idir;
@@ -536,6 +560,12 @@ extern "C" int fs_upload(fs_ctx *ctx)
       }
       HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 10 * (size_t)zn.z.jv * zn.z.kv));
       HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * 10));
+      if (!zn.bc_data.empty()) {
+        HIPCHK(ctx, hipMalloc(&zn.bc_data_dev, sizeof(double) * zn.bc_data.size()));
+        HIPCHK(ctx, hipMemcpy(zn.bc_data_dev, zn.bc_data.data(), sizeof(double) * zn.bc_data.size(), hipMemcpyHostToDevice));
+        for (size_t b = 0; b < zn.bc.size(); b++)
+          if (zn.bc_data_off[b] >= 0) zn.bc[b].data = zn.bc_data_dev + zn.bc_data_off[b];
+      }
       if (!zn.bc.empty()) {
         HIPCHK(ctx, hipMalloc(&zn.bc_dev, sizeof(FsBcWin) * zn.bc.size()));
         HIPCHK(ctx, hipMemcpy(zn.bc_dev, zn.bc.data(), sizeof(FsBcWin) * zn.bc.size(), hipMemcpyHostToDevice));

@@ -244,6 +244,8 @@ __global__ void __launch_bounds__(256) k_bc_copy(FsZone z, int nwin, const FsBcW
 //   no-slip wall       mirror cell, velocity reversed              BCWallViscous_i.for (c_ale = 0)
 //   slip wall          mirror cell, velocity reflected             FastC/BC/BCWallInviscid.for
 //   far field          characteristic state, then extrapolation    BCFarfield.for, BC_nextrank.for
+//   pressure outlet    imposed pressure along the normal, ranks copy  BCOutpres_i.for, BC_extrap_i.for
+//   isothermal wall    mirror cell, T = 2 Tw - T, rho from rho_w      BCWallViscousIsothermal_firstrank.for
 __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const FsBcWin *__restrict__ wins,
                                                     double *__restrict__ rop)
 {
@@ -296,6 +298,41 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         rop[l + 4 * nd] = rop[lm + 4 * nd];
         if (z.neq == 6) rop[l + 5 * nd] = rop[lm + 5 * nd];    // BCWallInviscidSA_i.for
       }
+    } else if (w.type == FS_BC_WALL_ISOTHERMAL) {   // BCWallViscousIsothermal_firstrank.for, c_ale = 0
+      const double tw = w.data[(q[da] - w.dlo[0]) + (long long)(q[db] - w.dlo[1]) * w.dn];
+      for (int r = 1; r <= nr; r++) {
+        const long long l = l1 - r * inc, lm = l1 + (r - 1) * inc;
+        const double rho_w = rop[lm] * rop[lm + 4 * nd] / tw;
+        const double u = rop[lm + nd], v = rop[lm + 2 * nd], ww = rop[lm + 3 * nd];
+        const double tm = rop[lm + 4 * nd];
+        rop[l] = 2. * rho_w - rop[lm];
+        rop[l + nd] = 0. - u;
+        rop[l + 2 * nd] = 0. - v;
+        rop[l + 3 * nd] = 0. - ww;
+        rop[l + 4 * nd] = 2. * tw - tm;
+        if (z.neq == 6) rop[l + 5 * nd] = -rop[lm + 5 * nd];   // BCWallViscousIsothermal_firstrank_SA.for
+      }
+    } else if (w.type == FS_BC_OUTPRES) {   // BCOutpres_i.for, linearization_state.for, BC_extrap_i.for
+      const double pext = w.data[(q[da] - w.dlo[0]) + (long long)(q[db] - w.dlo[1]) * w.dn];
+      const double snorm = (w.idir & 1) ? -1. : 1.;
+      double tc[3];
+      fs_bc_metric(z, w, d, q, tc);
+      const double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
+      const double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+      const double s_1 = 1. / sn;
+      double tnx = 1., tny = 0., tnz = 0.;
+      if (sn != 0.) { tnx = tcx * s_1; tny = tcy * s_1; tnz = tcz * s_1; }
+      const double roi = rop[l1], ui = rop[l1 + nd], vi = rop[l1 + 2 * nd], wi = rop[l1 + 3 * nd], Ti = rop[l1 + 4 * nd];
+      const double pi = roi * z.rgp * Ti;
+      const double roc0 = sqrt(roi * z.gam * pi);
+      const double dqn = (pext - pi) / roc0;
+      const double rog = roi + roi * roi * dqn / roc0;
+      double g[6];
+      g[0] = rog; g[1] = ui - dqn * tnx; g[2] = vi - dqn * tny; g[3] = wi - dqn * tnz;
+      g[4] = pext / (rog * z.rgp);
+      g[5] = z.neq == 6 ? rop[l1 + 5 * nd] : 0.;
+      for (int r = 1; r <= nr; r++)
+        for (int e = 0; e < z.neq; e++) rop[l1 - r * inc + e * nd] = g[e];
     } else {  // FS_BC_FARFIELD, FS_BC_INFLOW (same characteristic state, BCInflow_i.for), FS_BC_SUPERSONIC
       const double snorm = (w.idir & 1) ? -1. : 1.;
       if (w.type == FS_BC_SUPERSONIC) {   // first rank = reference state (BCInflowSupersonic_i.for)

@@ -198,9 +198,11 @@ def adim1(MInf=0.5, alphaZ=0., alphaY=0., ReInf=1.e8, **_):
 _WINDOWS = {'imin': 0, 'imax': 1, 'jmin': 2, 'jmax': 3, 'kmin': 4, 'kmax': 5}
 
 
-def addBC2Zone(z, bndName, bndType, wrange):
+def addBC2Zone(z, bndName, bndType, wrange, data=None):
     """Add a BC_t on a full face ('imin'...'kmax') or an explicit node window
-    [i1,i2,j1,j2,k1,k2] (1-based node indices, Converter.addBC2Zone semantics)."""
+    [i1,i2,j1,j2,k1,k2] (1-based node indices, Converter.addBC2Zone semantics).  data = {name: array}
+    attaches window data (one value per face cell of the window, first transverse direction fastest) as
+    BCDataSet_t / BCData_t / DataArray_t, the nesting the solver's BC table is built from."""
     d = Internal.getZoneDim(z)
     ni, nj, nk = d[1], d[2], d[3]
     if isinstance(wrange, str):
@@ -220,6 +222,11 @@ def addBC2Zone(z, bndName, bndType, wrange):
     bc = Internal.createChild(zbc, bndName, 'BC_t', bndType)
     pr = numpy.array([[w[0], w[1]], [w[2], w[3]], [w[4], w[5]]], dtype=Internal.E_NpyInt, order='F')
     Internal.createChild(bc, 'PointRange', 'IndexRange_t', pr)
+    if data:
+        ds = Internal.createChild(bc, 'BCDataSet', 'BCDataSet_t', bndType)
+        bd = Internal.createChild(ds, 'DirichletData', 'BCData_t', None)
+        for name, val in data.items():
+            Internal.createChild(bd, name, 'DataArray_t', numpy.ascontiguousarray(val, dtype=numpy.float64).ravel())
     return z
 
 

@@ -1189,6 +1189,97 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
       }
 }
 
+/* Window data of a BC (BCzone.cpp:257, 570-592, INCREMENT_BC.h): the first array stored for the window in
+ * Parameter_real, one value per face cell of the BC window, first transverse direction fastest; a leading
+ * array of size 1 is the mesh-velocity coefficient and is skipped.  Returns NULL without data. */
+static const double *fo_bc_data(const i32 *p, const double *pr, int ndf, int *inc_bc)
+{
+  const int pt_bcs = p[PT_BC], nb = p[pt_bcs], pt = p[pt_bcs + 1 + ndf], idir = p[pt + 1];
+  const i32 *fen = p + pt + 2;
+  if (p[pt + 8] == 0) return 0;
+  const double *d = pr + p[pt_bcs + 1 + ndf + nb];
+  if (p[pt + 9] == 1) d += 1;
+  if (idir <= 2) { inc_bc[0] = fen[3] - fen[2] + 1; inc_bc[1] = fen[2]; inc_bc[2] = fen[4]; }
+  else if (idir <= 4) { inc_bc[0] = fen[1] - fen[0] + 1; inc_bc[1] = fen[0]; inc_bc[2] = fen[4]; }
+  else { inc_bc[0] = fen[1] - fen[0] + 1; inc_bc[1] = fen[0]; inc_bc[2] = fen[2]; }
+  return d;
+}
+
+/* Pressure outlet: first ghost rank from the interior state and the imposed pressure along the face normal
+ * (Fast/FastS/FastS/BC/bvbs_outpres.for:151-197, BCOutpres_i.for, linearization_state.for), the next ranks copy
+ * the first one (BC_extrap_i.for); nu_tilde copied from the interior (BCOutpresSA_i.for). */
+void fo_bc_outpres(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
+                   const double *tj, const double *tk, const double *pext, const int *inc_bc)
+{
+  GEOM(p)
+  const fo_face f = fo_face_of(p, idir);
+  const long strides[3] = {1, ni, ninj};
+  const long inc = f.sgn * strides[f.d];
+  const double snorm = (idir % 2 == 0) ? 1. : -1.;
+  const double gam = pr[GAMMA], gam1 = pr[GAMMA] - 1., rgp = pr[CVINF] * gam1;
+  double tc[3];
+  int lo[3] = {cl[0], cl[2], cl[4]}, hi[3] = {cl[1], cl[3], cl[5]};
+  lo[f.d] = hi[f.d] = f.first;
+  const int da = f.d == 0 ? 1 : 0, db = f.d == 2 ? 1 : 2;
+  for (int k = lo[2]; k <= hi[2]; k++)
+    for (int j = lo[1]; j <= hi[1]; j++)
+      for (int i = lo[0]; i <= hi[0]; i++) {
+        const int q[3] = {i, j, k};
+        const long l1 = INDDM(i, j, k);
+        long l = l1 - inc;
+        const long li = (q[da] - inc_bc[1]) + (long)(q[db] - inc_bc[2]) * inc_bc[0];
+        fo_bc_metric(p, idir, i, j, k, ti, tj, tk, tc);
+        const double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
+        const double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
+        const double s_1 = 1. / sn;
+        double tnx, tny, tnz;
+        if (sn == 0.) { tnx = 1.; tny = 0.; tnz = 0.; } else { tnx = tcx * s_1; tny = tcy * s_1; tnz = tcz * s_1; }
+        const double roi = rop[l1], ui = rop[l1 + nd], vi = rop[l1 + 2 * nd], wi = rop[l1 + 3 * nd], Ti = rop[l1 + 4 * nd];
+        const double pi = roi * rgp * Ti;
+        const double ro0 = roi, p0 = ro0 * rgp * Ti;
+        const double roc0 = sqrt(ro0 * gam * p0);
+        const double dqn = (pext[li] - pi) / roc0;
+        const double rog = roi + ro0 * ro0 * dqn / roc0;
+        rop[l] = rog;
+        rop[l + nd] = ui - dqn * tnx;
+        rop[l + 2 * nd] = vi - dqn * tny;
+        rop[l + 3 * nd] = wi - dqn * tnz;
+        rop[l + 4 * nd] = pext[li] / (rog * rgp);
+        if (p[NEQ] == 6) rop[l + 5 * nd] = rop[l1 + 5 * nd];
+        for (int r = 2; r <= f.nr; r++) {
+          l = l1 - r * inc;
+          for (int e = 0; e < p[NEQ]; e++) rop[l + e * nd] = rop[l1 - inc + e * nd];
+        }
+      }
+}
+
+/* Isothermal no-slip wall: mirror cell, velocity reversed, temperature 2 Tw - T, density from the wall density
+ * rho_w = rho T / Tw at zero normal pressure gradient (Fast/FastS/FastS/BC/bvbs_wall_viscous_isothermal.for:151-197,
+ * BCWallViscousIsothermal_firstrank.for with c_ale = 0; nu_tilde reversed, BCWallViscousIsothermal_firstrank_SA.for). */
+void fo_bc_wall_isothermal(const i32 *p, int idir, const i32 *cl, double *rop, const double *tw, const int *inc_bc)
+{
+  GEOM(p)
+  const fo_face f = fo_face_of(p, idir);
+  const int ref = 2 * f.first - f.sgn;
+  const int da = f.d == 0 ? 1 : 0, db = f.d == 2 ? 1 : 2;
+  for (int k = cl[4]; k <= cl[5]; k++)
+    for (int j = cl[2]; j <= cl[3]; j++)
+      for (int i = cl[0]; i <= cl[1]; i++) {
+        int q[3] = {i, j, k};
+        const long li = (q[da] - inc_bc[1]) + (long)(q[db] - inc_bc[2]) * inc_bc[0];
+        q[f.d] = ref - q[f.d];
+        const long l = INDDM(i, j, k), lm = INDDM(q[0], q[1], q[2]);
+        const double rho_w = rop[lm] * rop[lm + 4 * nd] / tw[li];
+        rop[l] = 2. * rho_w - rop[lm];
+        const double u = rop[lm + nd], v = rop[lm + 2 * nd], w = rop[lm + 3 * nd];
+        rop[l + nd] = 0. - u;
+        rop[l + 2 * nd] = 0. - v;
+        rop[l + 3 * nd] = 0. - w;
+        rop[l + 4 * nd] = 2. * tw[li] - rop[lm + 4 * nd];
+        if (p[NEQ] == 6) rop[l + 5 * nd] = -rop[lm + 5 * nd];
+      }
+}
+
 /* Edge ghosts = mean of the two neighbouring face ghosts, corner ghosts = mean of three
  * (Fast/FastS/FastS/BC/correct_coins.for:23-420), whole zone range. */
 void fo_correct_coins(const i32 *p, double *rop)
@@ -1282,6 +1373,12 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2);
     else if (type == 3 || (type == 4 && p[IFLOW] == 1) || type == 5) fo_bc_wall_inviscid(p, idir, cl, rop, ti, tj, tk);
     else if ((type == 6 || type == 4) && p[IFLOW] > 1) fo_bc_wall_viscous(p, idir, cl, rop);
+    else if ((type == 16 || (type == 32 && p[IFLOW] > 1)) && p[pt + 8] >= 1 && p[pt + 8] <= 2) {
+      int inc_bc[3];
+      const double *d = fo_bc_data(p, pr, ndf, inc_bc);
+      if (type == 16) fo_bc_outpres(p, pr, idir, cl, rop, ti, tj, tk, d, inc_bc);
+      else fo_bc_wall_isothermal(p, idir, cl, rop, d, inc_bc);
+    }
     else return -1;
   }
   fo_correct_coins(p, rop);
@@ -1821,7 +1918,7 @@ int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *t
   }
   for (int ndf = 0; ndf < nb; ndf++) {   /* BCInflow keeps its own treatment of the residual: not restated */
     const int pt = p[pt_bcs + 1 + ndf];
-    if (p[pt] == 13 && !lskip[p[pt + 1] - 1]) return -1;
+    if ((p[pt] == 13 || p[pt] == 32) && !lskip[p[pt + 1] - 1]) return -1;
   }
   for (int d = 0; d < 3; d++) {
     lu[2 * d] = sdm[2 * d] - (1 - lskip[2 * d]);

@@ -215,6 +215,25 @@ class RefSolver:
                                     _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
             elif btype == 22:
                 pass   # BCOverlap: ghost cells come from the join transfer
+            elif btype in (16, 32):
+                # Fast/FastS/FastS/BC/BCzone.cpp:539-558,570-592 with INCREMENT_BC.h: one array of window data
+                nbdata = int(p[pt_bc + 8])
+                if nbdata < 1 or nbdata > 2 or (btype == 32 and p[IFLOW] <= 1):
+                    raise NotImplementedError("ref_harness: BC tag %d with %d data arrays" % (btype, nbdata))
+                off = int(p[pt_bcs + 1 + ndf + nb_bc])
+                size0 = int(p[pt_bc + 9])
+                if size0 == 1:
+                    off += 1; size0 = int(p[pt_bc + 10])
+                data = zn.preal[off:]
+                if idir <= 2: inc_bc = [fen[3] - fen[2] + 1, fen[2], fen[4]]
+                elif idir <= 4: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[4]]
+                else: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[2]]
+                inc_bc = np.array(inc_bc, dtype=np.int32)
+                fn = L.bvbs_outpres_ if btype == 16 else L.bvbs_wall_viscous_isothermal_
+                fn(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl),
+                   _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+                   _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state),
+                   _p(data), _i(int(p[pt_bc + 9])), _p(inc_bc))
             elif btype in (1, 2, 3, 4, 5, 6, 13):
                 # dispatch of Fast/FastS/FastS/BC/BCzone.cpp:279-283,299-310,417-425,451-461,513-523 (these use ind_CL)
                 if int(p[pt_bc + 8]) != 0:

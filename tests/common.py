@@ -52,3 +52,22 @@ def wall_distance(z):
     sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
     n = Internal.getNodeFromName1(sol, 'TurbulentDistance') if sol is not None else None
     return None if n is None else n[1]
+
+
+def window_data(shape, base, amp=0.02):
+    """Deterministic window data for BCs that carry their own (one value per face cell)."""
+    import numpy as _np
+    n = int(_np.prod(shape))
+    return base * (1. + amp * _np.sin(0.7 * _np.arange(n) + 0.3))
+
+
+def data_bcs(n, model='NSLaminar'):
+    """BCOutpres on imax and kmin, isothermal wall on jmin (laminar / turbulent only), with window data."""
+    pinf = 1. / (1.4 * 0.1 * 0.1)    # adim2funk at M = 0.1: rho = T = 1
+    ni, nj, nk = n
+    bcs = {'imax': ('BCOutpres', {'Pressure': window_data((nj, nk), pinf)}),
+           'kmin': ('BCOutpres', {'Pressure': window_data((ni, nj), pinf, 0.01)}),
+           'imin': 'BCFarfield'}
+    if model != 'Euler':
+        bcs['jmin'] = ('BCWallViscousIsothermal', {'Temperature': window_data((ni, nk), 1.05)})
+    return bcs

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from fast_amd import cases, connect, FastC, Internal
 from oracle import ref_harness as R
-from common import prepare, zone_arrays, wall_distance
+from common import prepare, zone_arrays, wall_distance, data_bcs
 
 SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
 
@@ -67,6 +67,9 @@ CASES = {
     'plane2d_senseur_lamin':    ('tgv2d', (14, 10), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 20,
                                  {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {'perturb': 0.15}),
     'naca0012_sa_implicit':     ('naca', (16, 6, 10), 'ausmpred', 'NSTurbulent', (1, 1, 1), 'single', 20),
+    # BCs that read window data from Parameter_real: two pressure outlets, one isothermal wall, one far field
+    'outlet_isowall_curv':      ('tgv', (10, 9, 8), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 10,
+                                 data_bcs((10, 9, 8)), {'perturb': 0.15}),
     'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
     'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
 }

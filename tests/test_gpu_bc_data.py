@@ -1,0 +1,65 @@
+"""GPU parity of the boundary conditions that read window data from Parameter_real: pressure outlet
+(BCOutpres, tag 16) and isothermal no-slip wall (BCWallViscousIsothermal, tag 32), against the CPU restatement,
+itself bit-exact against bvbs_outpres / bvbs_wall_viscous_isothermal of the compiled reference
+(test_oracle_vs_ref.py).  Mean-flow cases must agree bit for bit; the Spalart-Allmaras ones to 1e-12 (the device
+pow of the destruction term differs from the host pow in the last bit)."""
+import numpy as np
+import pytest
+
+from fast_amd import cases, FastC, Internal, _capi
+import fast_amd.PyTree as FastS
+from oracle import oracle as O
+from common import zone_arrays, rel_err, SINGLE, wall_distance, data_bcs, window_data
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, model, scheme, perturb, temporal
+    ((9, 8, 7), 'NSLaminar', 'ausmpred', 0., 'explicit'),
+    ((70, 9, 12), 'NSLaminar', 'senseur', 0., 'explicit'),
+    ((10, 9, 8), 'Euler', 'senseur', 0., 'explicit'),
+    ((10, 8, 9), 'NSLaminar', 'roe', 0.15, 'explicit'),
+    ((9, 8, 10), 'NSTurbulent', 'ausmpred', 0.15, 'explicit'),
+    ((10, 9, 8), 'NSLaminar', 'senseur', 0.15, 'implicit'),
+    ((9, 10, 8), 'NSTurbulent', 'ausmpred', 0., 'implicit'),
+]
+
+
+@pytest.mark.parametrize("n,model,scheme,perturb,temporal", CASES)
+def test_bcs_with_window_data(n, model, scheme, perturb, temporal):
+    bcs = data_bcs(n, model)
+    implicit = temporal == 'implicit'
+    if implicit:
+        bcs['kmax'] = 'BCWall'
+    t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': 3}, bcs=bcs, perturb=perturb,
+                  temporal_scheme=temporal, time_step=0.02 if implicit else None)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    neq = int(pint[36])
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z) if neq == 6 else None)
+    oz.fill_ghostcells()
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)        # ghost fill of the initial field: bit-exact
+    if implicit:
+        oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, 6):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        if neq == 6:
+            e = rel_err(got, oz.ro, int(pint[41]), neq=6)
+            assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+        else:
+            assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-6
+
+
+def test_window_data_must_match_the_window():
+    n = (8, 8, 8)
+    t = cases.tgv(n, 'senseur', extra_numz=SINGLE, bcs={'imax': ('BCOutpres', {'Pressure': window_data((5, 5), 70.)})})
+    with pytest.raises(_capi.FastsHipError, match="window data"):
+        FastS.warmup(t, None)
+    t = cases.tgv(n, 'senseur', extra_numz=SINGLE, bcs={'imax': 'BCOutpres'})
+    with pytest.raises(_capi.FastsHipError, match="window data"):
+        FastS.warmup(t, None)

@@ -70,6 +70,36 @@ def test_boundary_conditions_bit_exact(model, scheme, bcs):
     assert np.isfinite(so.zones[0].ro).all()
 
 
+@pytest.mark.parametrize("model,scheme,perturb,temporal", [
+    ('NSLaminar', 'ausmpred', 0., 'explicit'),
+    ('Euler', 'senseur', 0., 'explicit'),
+    ('NSLaminar', 'roe', 0.15, 'explicit'),
+    ('NSTurbulent', 'ausmpred', 0.15, 'explicit'),
+    ('NSLaminar', 'senseur', 0.15, 'implicit'),
+    ('NSTurbulent', 'ausmpred', 0., 'implicit'),
+])
+def test_boundary_conditions_with_data_bit_exact(model, scheme, perturb, temporal):
+    """BCs that read window data from Parameter_real: pressure outlet (bvbs_outpres) and isothermal wall
+    (bvbs_wall_viscous_isothermal) of the compiled reference, Cartesian and curvilinear, 5 and 6 equations."""
+    from common import data_bcs
+    n = (9, 8, 7)
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    bcs = data_bcs(n, model)
+    if temporal == 'implicit':
+        bcs['kmax'] = 'BCWall'    # a face treated implicitly next to the outlets
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb,
+                  temporal_scheme=temporal, time_step=0.02 if temporal == 'implicit' else None)
+    so, sr = _pair(t)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+    assert np.isfinite(so.zones[0].ro).all()
+
+
 @pytest.mark.parametrize("scheme,model,bcs,blocks", [
     ('senseur', 'NSLaminar', None, (1, 1, 1)),
     ('ausmpred', 'Euler', None, (1, 1, 1)),
