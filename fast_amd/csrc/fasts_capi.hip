@@ -343,6 +343,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     const int tag = w.type;
     if (tag == 11 || tag == 0 || tag == 1) w.type = tag;
     else if ((tag == 13 || tag == 2) && p[pt + 8] == 0) w.type = tag;   // BCInflow / BCInflowSupersonic on the reference state
+    else if (tag == 2 && p[pt + 8] == p[NEQ] && pt + 9 < n_int && p[pt + 9] > 6) w.type = tag;   // its own state: BCzone.cpp:421-448
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
     else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
     else if (tag == 16 || (tag == 32 && p[IFLOW] > 1)) w.type = tag;   // BCOutpres, BCWallViscousIsothermal: window data
@@ -353,8 +354,21 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     }
     if (w.idir < 1 || w.idir > 6) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window is not on a zone face");
     long long data_off = -1;
-    w.data = nullptr; w.dlo[0] = w.dlo[1] = 0; w.dn = 1;
-    if (tag == 16 || tag == 32) {
+    w.data = nullptr; w.dlo[0] = w.dlo[1] = 0; w.dn = 1; w.dsize = 0;
+    if (tag == 2 && p[pt + 8] != 0) {
+      // NEQ arrays of one size, one value per face cell of the window: rho, rho u, rho v, rho w, rho E [, rho nu_tilde]
+      const int nbdata = p[pt + 8], size = p[pt + 9];
+      const long long off = p[pt_bcs + 1 + ndf + nb];
+      const int32_t *fen = p + pt + 2;
+      const int da = w.idir <= 2 ? 1 : 0, db = w.idir <= 4 ? 2 : 1;
+      const int na = fen[2 * da + 1] - fen[2 * da] + 1, nbb = fen[2 * db + 1] - fen[2 * db] + 1;
+      if (pt + 8 + nbdata >= n_int || size != na * nbb || p[pt + 8 + nbdata] != nbdata * size || off < 0 ||
+          off + (long long)nbdata * size > n_real)
+        return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window data do not match the BC window");
+      data_off = (long long)zn.bc_data.size();
+      zn.bc_data.insert(zn.bc_data.end(), r + off, r + off + (long long)nbdata * size);
+      w.dlo[0] = fen[2 * da]; w.dlo[1] = fen[2 * db]; w.dn = na; w.dsize = size;
+    } else if (tag == 16 || tag == 32) {
       // BCzone.cpp:257,545-551,577-585: one array of window data, optionally after/before a mesh-velocity
       // coefficient of size 1; stored in Parameter_real at the pointer that follows the BC pointers
       const int nbdata = p[pt + 8];

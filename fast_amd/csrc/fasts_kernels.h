@@ -22,6 +22,7 @@ struct FsBcWin {
   // (a - dlo[0]) + (b - dlo[1]) * dn, a = first transverse direction (BC/INCREMENT_BC.h, indbci)
   const double *data;
   int dlo[2], dn;
+  int dsize;         // values per array when the window carries several arrays back to back
 };
 
 // depth = ghost layers covered besides the interior: 1 for the explicit scheme (navier_stokes_struct.for:223,

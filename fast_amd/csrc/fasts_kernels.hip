@@ -335,7 +335,15 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         for (int e = 0; e < z.neq; e++) rop[l1 - r * inc + e * nd] = g[e];
     } else {  // FS_BC_FARFIELD, FS_BC_INFLOW (same characteristic state, BCInflow_i.for), FS_BC_SUPERSONIC
       const double snorm = (w.idir & 1) ? -1. : 1.;
-      if (w.type == FS_BC_SUPERSONIC) {   // first rank = reference state (BCInflowSupersonic_i.for)
+      if (w.type == FS_BC_SUPERSONIC && w.data) {   // first rank = the window's own conservative state
+        const long long l = l1 - inc;                 // (BCInflowSupersonic_fich_firstrank.for)
+        const double *dt = w.data + (q[da] - w.dlo[0]) + (long long)(q[db] - w.dlo[1]) * w.dn;
+        const double ro = dt[0], ru = dt[w.dsize], rv = dt[2 * (long long)w.dsize], rw = dt[3 * (long long)w.dsize];
+        const double re = dt[4 * (long long)w.dsize];
+        rop[l] = ro; rop[l + nd] = ru / ro; rop[l + 2 * nd] = rv / ro; rop[l + 3 * nd] = rw / ro;
+        rop[l + 4 * nd] = (re - 0.5 * (ru * ru + rv * rv + rw * rw) / ro) / (ro * z.cv);
+        if (z.neq == 6) rop[l + 5 * nd] = dt[5 * (long long)w.dsize] / ro;
+      } else if (w.type == FS_BC_SUPERSONIC) {   // first rank = reference state (BCInflowSupersonic_i.for)
         const long long l = l1 - inc;
         const double ro_state = w.st[0], u_state = w.st[1] / w.st[0], v_state = w.st[2] / w.st[0], w_state = w.st[3] / w.st[0];
         const double t_state = (w.st[4] - 0.5 * ro_state * (u_state * u_state + v_state * v_state + w_state * w_state)) /

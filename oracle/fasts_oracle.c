@@ -1076,20 +1076,24 @@ void fo_bc_wall_inviscid(const i32 *p, int idir, const i32 *cl, double *rop, con
 #define VZINF 21
 #define PINF 4
 static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
-                             const double *tj, const double *tk, int mode);
+                             const double *tj, const double *tk, int mode, const double *data, int dsize,
+                             const int *inc_bc);
 void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
                     const double *tj, const double *tk)
 {
-  fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 0);
+  fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 0, 0, 0, 0);
 }
 
 /* mode 0: BCFarfield.  mode 1: BCInflow without data = the same characteristic state from the reference state
  * (bvbs_inflow.for, BCInflow_i.for, BCInflow_init.for), nu_tilde always taken from the state (BCInflowSA_i.for).
  * mode 2: BCInflowSupersonic without data: the first ghost rank takes the reference state
  * (bvbs_inflow_supersonic.for:127-135, BCInflowSupersonic_i.for), the next ranks are extrapolated as for the
- * far field. */
+ * far field.  mode 2 with data: the first ghost rank takes the conservative state stored per face cell of the BC
+ * window, dsize values per variable (bvbs_inflow_supersonic_fich.for, BCInflowSupersonic_fich_firstrank.for,
+ * BCInflowSupersonic_fich_firstrank_SA.for). */
 static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
-                             const double *tj, const double *tk, int mode)
+                             const double *tj, const double *tk, int mode, const double *data, int dsize,
+                             const int *inc_bc)
 {
   GEOM(p)
   const fo_face f = fo_face_of(p, idir);
@@ -1114,7 +1118,16 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
         const long l1 = INDDM(i, j, k);      /* first interior cell */
         long l = l1 - inc;                   /* first ghost rank */
         fo_bc_metric(p, idir, i, j, k, ti, tj, tk, tc);
-        if (mode == 2) {
+        if (mode == 2 && data) {
+          const int q[3] = {i, j, k};
+          const int da = f.d == 0 ? 1 : 0, db = f.d == 2 ? 1 : 2;
+          const long li = (q[da] - inc_bc[1]) + (long)(q[db] - inc_bc[2]) * inc_bc[0];
+          const double ro = data[li], ru = data[li + dsize], rv = data[li + 2 * dsize], rw = data[li + 3 * dsize];
+          const double re = data[li + 4 * dsize];
+          rop[l] = ro; rop[l + nd] = ru / ro; rop[l + 2 * nd] = rv / ro; rop[l + 3 * nd] = rw / ro;
+          rop[l + 4 * nd] = (re - 0.5 * (ru * ru + rv * rv + rw * rw) / ro) / (ro * pr[CVINF]);
+          if (p[NEQ] == 6) rop[l + 5 * nd] = data[li + 5 * dsize] / ro;
+        } else if (mode == 2) {
           const double ro_state = st[0], u_state = st[1] / st[0], v_state = st[2] / st[0], w_state = st[3] / st[0];
           const double t_state = (st[4] - 0.5 * ro_state * (u_state * u_state + v_state * v_state + w_state * w_state)) /
                                  (ro_state * pr[CVINF]);
@@ -1369,8 +1382,14 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     else if (type == 22) continue;
     else if (type == 0) fo_bc_extrapolate(p, idir, cl, rop);
     else if (type == 1) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
-    else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1);
-    else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2);
+    else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1, 0, 0, 0);
+    else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2, 0, 0, 0);
+    else if (type == 2 && p[pt + 8] == p[NEQ] && p[pt + 9] > 6) {   /* BCzone.cpp:421-448: arrays of more than 6 values */
+      int inc_bc[3];
+      const int save = p[pt + 9];
+      const double *d = fo_bc_data(p, pr, ndf, inc_bc);
+      fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2, d, save, inc_bc);
+    }
     else if (type == 3 || (type == 4 && p[IFLOW] == 1) || type == 5) fo_bc_wall_inviscid(p, idir, cl, rop, ti, tj, tk);
     else if ((type == 6 || type == 4) && p[IFLOW] > 1) fo_bc_wall_viscous(p, idir, cl, rop);
     else if ((type == 16 || (type == 32 && p[IFLOW] > 1)) && p[pt + 8] >= 1 && p[pt + 8] <= 2) {

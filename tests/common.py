@@ -68,6 +68,16 @@ def data_bcs(n, model='NSLaminar'):
     bcs = {'imax': ('BCOutpres', {'Pressure': window_data((nj, nk), pinf)}),
            'kmin': ('BCOutpres', {'Pressure': window_data((ni, nj), pinf, 0.01)}),
            'imin': 'BCFarfield'}
+    neq = 6 if model == 'NSTurbulent' else 5
+    # supersonic inflow with its own conservative state (rho, rho u, rho v, rho w, rho E [, rho nu_tilde])
+    nf = ni * nj
+    ro = window_data((nf,), 1.02); u = window_data((nf,), 0.11, 0.1)
+    cv = 1. / (1.4 * 0.4 * 1.4 * 0.01)    # adim2funk: cv = 1 / (gamma (gamma-1) M^2)
+    sup = {'Density': ro, 'MomentumX': ro * 0.02, 'MomentumY': ro * 0.01, 'MomentumZ': -ro * u,
+           'EnergyStagnationDensity': ro * (cv * 1.01 + 0.5 * (0.02 ** 2 + 0.01 ** 2 + u * u))}
+    if neq == 6:
+        sup['TurbulentSANuTildeDensity'] = ro * window_data((nf,), 2e-5, 0.3)
+    bcs['kmax'] = ('BCInflowSupersonic', sup)
     if model != 'Euler':
         bcs['jmin'] = ('BCWallViscousIsothermal', {'Temperature': window_data((ni, nk), 1.05)})
     return bcs

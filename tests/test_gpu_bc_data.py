@@ -30,7 +30,7 @@ def test_bcs_with_window_data(n, model, scheme, perturb, temporal):
     bcs = data_bcs(n, model)
     implicit = temporal == 'implicit'
     if implicit:
-        bcs['kmax'] = 'BCWall'
+        bcs['jmax'] = 'BCWall'
     t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': 3}, bcs=bcs, perturb=perturb,
                   temporal_scheme=temporal, time_step=0.02 if implicit else None)
     (t, tc, metrics) = FastS.warmup(t, None)

@@ -86,7 +86,7 @@ def test_boundary_conditions_with_data_bit_exact(model, scheme, perturb, tempora
     extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
     bcs = data_bcs(n, model)
     if temporal == 'implicit':
-        bcs['kmax'] = 'BCWall'    # a face treated implicitly next to the outlets
+        bcs['jmax'] = 'BCWall'    # a face treated implicitly next to the outlets
     t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb,
                   temporal_scheme=temporal, time_step=0.02 if temporal == 'implicit' else None)
     so, sr = _pair(t)
