@@ -226,7 +226,16 @@ def display_temporal_criteria(t, metrics, nitrun, format=None, gmres=None, verbo
     for nd, z in enumerate(Internal.getZones(t)):
         l2, loo = ctx.residuals(nd)
         out[z[0]] = (l2, loo)
+        # CFL_minmaxmoy of the zone: filled by the compute call in the reference (computePT.cpp:610-643), here when
+        # the norms are fetched, so that _compute does not have to wait for the device
+        cfl = ctx.cfl(nd)
+        own = Internal.getNodeFromName1(z, '.Solver#ownData')
+        node = Internal.getNodeFromName1(own, 'CFL_minmaxmoy') if own is not None else None
+        if node is not None:
+            node[1][0:3] = cfl
         if format is None or format in ('single', 'double', 'flush'):
+            # display_ss_iteration.cpp:104
+            print("CFL_MOY_MAX_MIN(Zone= %32.32s, nitrun=%d) %f    %f    %f " % (z[0], nitrun, cfl[2], cfl[0], cfl[1]))
             print("%-24s nitrun=%d  L2 = %s  Loo = %s" % (
                 z[0], nitrun, ' '.join('%.6e' % v for v in l2), ' '.join('%.6e' % v for v in loo)))
         if stopAtNan and not numpy.all(numpy.isfinite(l2)):

@@ -16,7 +16,7 @@ SYMBOLS = [
     "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif", "fs_set_first_it",
     "fs_zone_add", "fs_zone_set_distance", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
-    "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_sync",
+    "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_cfl", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
 ]
 
@@ -183,6 +183,12 @@ class Context:
         self._chk(lib().fs_residuals(self._h, ctypes.c_int(zone), _pd(l2), _pd(loo), ctypes.c_int(5)),
                   "fs_residuals")
         return l2, loo
+
+    def cfl(self, zone=0):
+        """[max, min, mean] local CFL number of the last verification step."""
+        out = numpy.zeros(3)
+        self._chk(lib().fs_cfl(self._h, ctypes.c_int(zone), _pd(out)), "fs_cfl")
+        return out
 
     def sync(self):
         self._chk(lib().fs_sync(self._h), "fs_sync")

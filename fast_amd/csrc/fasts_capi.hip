@@ -38,7 +38,8 @@ struct Zone {
   FsBcWin *rhs_face_dev = nullptr, *rhs_bc_dev = nullptr;
   long long rhs_max_cells = 0;
   int lu[6] = {0, 0, 0, 0, 0, 0};
-  double *res_part = nullptr, *res_out = nullptr;
+  double *res_part = nullptr, *res_out = nullptr;   // res_out: 10 residual norms, then the CFL triple
+  bool have_cfl = false;
   FsBcWin *bc_dev = nullptr;
   std::vector<double> bc_data;          // window data of the BCs that carry their own, concatenated
   std::vector<long long> bc_data_off;   // per entry of bc: offset in bc_data, -1 without data
@@ -573,7 +574,7 @@ extern "C" int fs_upload(fs_ctx *ctx)
         HIPCHK(ctx, hipMemsetAsync(zn.scratch, 0, nb, ctx->stream));
       }
       HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 10 * (size_t)zn.z.jv * zn.z.kv));
-      HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * 10));
+      HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * 13));
       if (!zn.bc_data.empty()) {
         HIPCHK(ctx, hipMalloc(&zn.bc_data_dev, sizeof(double) * zn.bc_data.size()));
         HIPCHK(ctx, hipMemcpy(zn.bc_data_dev, zn.bc_data.data(), sizeof(double) * zn.bc_data.size(), hipMemcpyHostToDevice));
@@ -792,6 +793,12 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     if (nstep == 1 && (nitrun % ctx->modulo_verif == 0 || nitrun == 1)) {
       fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out, ctx->stream);
       zn.have_res = true;
+      // local CFL number of the state the step starts from (cptst3.for:114-120: first sub-iteration of a
+      // verification step), with the viscosity this stage has just evaluated
+      const double *r = zn.preal.data();
+      fsk_cfl(z, r[GAMMA] / r[PRANDT], r[GAMMA] * (r[CVINF] * (r[GAMMA] - 1.)), zn.dev[in], zn.xmut, zn.res_part,
+              zn.res_out + 10, ctx->stream);
+      zn.have_cfl = true;
     }
     if (ctx->implicit) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:53-68,135-161)
       if (!zn.rhs_face.empty()) {   // wall faces: BCs on the residual, two ordered passes, then edges/corners
@@ -994,6 +1001,18 @@ extern "C" int fs_apply_bc(fs_ctx *ctx, int nstep, int level)
   if (role < 0) return fail(ctx, FS_ERR_ARG, "fs_apply_bc: bad level");
   bcs_on_role(ctx, role);
   HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_cfl(fs_ctx *ctx, int zone, double *cfl)
+{
+  int rc = ensure_ready(ctx, "fs_cfl");
+  if (rc) return rc;
+  if (zone < 0 || zone >= (int)ctx->zones.size() || !cfl) return fail(ctx, FS_ERR_ARG, "fs_cfl: bad argument");
+  Zone &zn = ctx->zones[zone];
+  if (!zn.have_cfl) return fail(ctx, FS_ERR_STATE, "fs_cfl: no verification sub-iteration has run yet");
+  HIPCHK(ctx, hipMemcpyAsync(cfl, zn.res_out + 10, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FS_OK;
 }
 

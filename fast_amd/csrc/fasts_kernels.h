@@ -67,6 +67,10 @@ void fsk_halo_pack(int npts, int neq, long long nd, const int *pts, const double
 void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *rop, const double *buf, hipStream_t s);
 // use_coe = 1: norms of dt/vol * drodm (explicit balance); 0: norms of drodm (Newton residual, already scaled)
 void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s);
+// out[3] = largest, smallest and mean local CFL number of the interior cells (cpcfl3.for); part = 3 doubles per
+// (j,k) row of scratch; gam1 = gamma / Prandtl, gam2 = gamma * R
+void fsk_cfl(const FsZone &z, double gam1, double gam2, const double *rop, const double *xmut, double *part, double *out,
+             hipStream_t s);
 // implicit scheme (fasts_lusgs.hip)
 void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, double gamma, double prandtl, double rgp,
                       const double *rop, const double *xmut, double *coe, hipStream_t s);

@@ -533,6 +533,93 @@ __global__ void __launch_bounds__(256) k_residual_final(long long nblk, const do
 }
 
 // ------------------------------------------------------------------------------------------
+// local CFL number (Compute/cpcfl3.for:276-440 viscous, :635-790 Euler, fixed mesh): per-block
+// [max, min, sum] in a fixed order, folded by one block.  A two-dimensional zone runs with its metrics
+// expanded by zero z components and a zero tk: the terms it adds are exact zeros.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cfl_partial(FsZone z, double gam1, double gam2, int visc,
+                                                     const double *__restrict__ rop, const double *__restrict__ xmut,
+                                                     double *__restrict__ part)
+{
+  __shared__ double sred[3][256];
+  const int j = blockIdx.x + 1, k = blockIdx.y + 1;
+  double mx = 0., mn = 100000000., sm = 0.;
+  double surf_c = 0.;
+  if (z.ityp != 0) {
+    const double ddi = 2. * sqrt(z.tcx * z.tcx), ddj = 2. * sqrt(z.tcy * z.tcy), ddk = 2. * sqrt(z.tcz * z.tcz);
+    surf_c = 1. / fs_max(fs_max(ddi, ddj), ddk);
+  }
+  for (int i = threadIdx.x + 1; i <= z.iv; i += blockDim.x) {
+    const long long l = fs_inddm(z, i, j, k), nd = z.nd;
+    double surf = surf_c, volc = z.vol0;
+    if (z.ityp == 0) {
+      const long long lt = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj +
+                           (long long)(k + z.ifick - 1) * z.minck;
+      const long long ndm = z.ndm, inc[3] = {1, z.mincj, z.minck};
+      double dd[3];
+      for (int d = 0; d < 3; d++) {
+        const double *__restrict__ t = z.mt[d];
+        const long long lp = lt + inc[d];
+        double a = sqrt(t[lp] * t[lp] + t[lp + ndm] * t[lp + ndm] + t[lp + 2 * ndm] * t[lp + 2 * ndm]);
+        a = a + sqrt(t[lt] * t[lt] + t[lt + ndm] * t[lt + ndm] + t[lt + 2 * ndm] * t[lt + 2 * ndm]);
+        dd[d] = a;
+      }
+      surf = 1. / fs_max(fs_max(dd[0], dd[1]), dd[2]);
+      volc = z.vol[lt];
+    }
+    const double u = rop[l + nd], v = rop[l + 2 * nd], w = rop[l + 3 * nd], r = rop[l];
+    const double c = sqrt(gam2 * rop[l + 4 * nd]);
+    const double ur2 = u * u + v * v + w * w;
+    const double sp = sqrt(ur2);
+    const double xinvspc = 1. / (sp + c);
+    const double conv = 2. * volc * surf * xinvspc;
+    double comp = conv;
+    if (visc) {
+      const double xinvkt = gam1 / xmut[l];
+      const double vis = 2. * r * volc * volc * surf * surf * xinvkt;
+      comp = fs_min(vis, conv);
+    }
+    const double cfloc = z.dt / comp;
+    mx = fs_max(mx, cfloc); mn = fs_min(mn, cfloc); sm = sm + cfloc;
+  }
+  sred[0][threadIdx.x] = mx; sred[1][threadIdx.x] = mn; sred[2][threadIdx.x] = sm;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      sred[0][threadIdx.x] = fs_max(sred[0][threadIdx.x], sred[0][threadIdx.x + w]);
+      sred[1][threadIdx.x] = fs_min(sred[1][threadIdx.x], sred[1][threadIdx.x + w]);
+      sred[2][threadIdx.x] = sred[2][threadIdx.x] + sred[2][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    part[b * 3] = sred[0][0]; part[b * 3 + 1] = sred[1][0]; part[b * 3 + 2] = sred[2][0];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_cfl_final(long long nblk, double inv_cells, const double *__restrict__ part,
+                                                   double *__restrict__ out)
+{
+  __shared__ double sred[3][256];
+  double mx = 0., mn = 100000000., sm = 0.;
+  for (long long b = threadIdx.x; b < nblk; b += blockDim.x) {
+    mx = fs_max(mx, part[b * 3]); mn = fs_min(mn, part[b * 3 + 1]); sm = sm + part[b * 3 + 2];
+  }
+  sred[0][threadIdx.x] = mx; sred[1][threadIdx.x] = mn; sred[2][threadIdx.x] = sm;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      sred[0][threadIdx.x] = fs_max(sred[0][threadIdx.x], sred[0][threadIdx.x + w]);
+      sred[1][threadIdx.x] = fs_min(sred[1][threadIdx.x], sred[1][threadIdx.x + w]);
+      sred[2][threadIdx.x] = sred[2][threadIdx.x] + sred[2][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = sred[0][0]; out[1] = sred[1][0]; out[2] = sred[2][0] * inv_cells; }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
@@ -613,6 +700,14 @@ void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *ro
   unsigned gx = cdiv((long long)npts * neq, 256);
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(k_halo_unpack, dim3(gx), dim3(256), 0, s, npts, neq, nd, pts, rop, buf);
+}
+
+void fsk_cfl(const FsZone &z, double gam1, double gam2, const double *rop, const double *xmut, double *part,
+             double *out, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_cfl_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, gam1, gam2, z.iflow >= 2 ? 1 : 0, rop, xmut, part);
+  hipLaunchKernelGGL(k_cfl_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv,
+                     1. / ((double)z.iv * z.jv * z.kv), (const double *)part, out);
 }
 
 void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s)

@@ -167,6 +167,13 @@ int fs_apply_bc(fs_ctx *ctx, int nstep, int level);
  *  Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:128-141).  Synchronises. */
 int fs_residuals(fs_ctx *ctx, int zone, double *l2, double *loo, int neq);
 
+/* Largest, smallest and mean local CFL number of one zone, cfl[3] = {max, min, mean}, evaluated at the first
+ * sub-iteration of the last verification step on the state that step started from: what the reference stores
+ * in .Solver#ownData/CFL_minmaxmoy (Fast/FastS/FastS/Compute/cptst3.for:114-120 -> cpcfl3.for,
+ * Fast/FastS/FastS/Compute/computePT.cpp:519,610-643) and prints in
+ * Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:100-105.  Synchronises. */
+int fs_cfl(fs_ctx *ctx, int zone, double *cfl);
+
 /* Block until everything enqueued on the context's stream has finished. */
 int fs_sync(fs_ctx *ctx);
 

@@ -1918,6 +1918,72 @@ void fo_invlu(const i32 *p, const double *pr, const i32 *ind, double *dw, const 
   }
 }
 
+/* Largest, smallest and summed local CFL number of a zone (Fast/FastS/FastS/Compute/cpcfl3.for:276-440 viscous
+ * models, :635-790 Euler; fixed mesh), called at the first sub-iteration of a verification time step
+ * (cptst3.for:114-120).  cfl[0] = max, cfl[1] = min, cfl[2] = sum over the interior cells in the order of the
+ * reference loops (k, j, i); the caller divides the sum by the number of cells (computePT.cpp:627-643). */
+void fo_cpcfl3(const i32 *p, const double *pr, const double *rop, const double *xmut, const double *ti,
+               const double *tj, const double *tk, const double *vol, double *cfl)
+{
+  GEOM(p)
+  const int typ = p[ITYPZONE], visc = p[IFLOW] >= 2;
+  const double rgp = pr[CVINF] * (pr[GAMMA] - 1.);
+  const double gam1 = pr[GAMMA] / pr[PRANDT], gam2 = pr[GAMMA] * rgp;
+  const double dt = pr[DTC];
+  const long ndm = p[NDIMDX_MTR];
+  const long inci = p[NIJK_MTR], incj = p[NIJK_MTR + 1], inck = p[NIJK_MTR + 2];
+  double surf_c = 0.;
+  if (typ == 2) {
+    const double ddi = 2. * sqrt(ti[0] * ti[0]), ddj = 2. * sqrt(tj[0] * tj[0]), ddk = 2. * sqrt(tk[0] * tk[0]);
+    surf_c = 1. / dmax(dmax(ddi, ddj), ddk);
+  }
+  for (int k = 1; k <= p[IJKV + 2]; k++)
+    for (int j = 1; j <= p[IJKV + 1]; j++)
+      for (int i = 1; i <= p[IJKV]; i++) {
+        const long l = INDDM(i, j, k);
+        double surf = surf_c, volc = vol[0];
+        double w = rop[l + 3 * nd];
+        if (typ == 0) {
+          const long lt = INDMTR(p, i, j, k);
+          double ddi = sqrt(ti[lt + inci] * ti[lt + inci] + ti[lt + inci + ndm] * ti[lt + inci + ndm] +
+                            ti[lt + inci + 2 * ndm] * ti[lt + inci + 2 * ndm]);
+          ddi = ddi + sqrt(ti[lt] * ti[lt] + ti[lt + ndm] * ti[lt + ndm] + ti[lt + 2 * ndm] * ti[lt + 2 * ndm]);
+          double ddj = sqrt(tj[lt + incj] * tj[lt + incj] + tj[lt + incj + ndm] * tj[lt + incj + ndm] +
+                            tj[lt + incj + 2 * ndm] * tj[lt + incj + 2 * ndm]);
+          ddj = ddj + sqrt(tj[lt] * tj[lt] + tj[lt + ndm] * tj[lt + ndm] + tj[lt + 2 * ndm] * tj[lt + 2 * ndm]);
+          double ddk = sqrt(tk[lt + inck] * tk[lt + inck] + tk[lt + inck + ndm] * tk[lt + inck + ndm] +
+                            tk[lt + inck + 2 * ndm] * tk[lt + inck + 2 * ndm]);
+          ddk = ddk + sqrt(tk[lt] * tk[lt] + tk[lt + ndm] * tk[lt + ndm] + tk[lt + 2 * ndm] * tk[lt + 2 * ndm]);
+          surf = 1. / dmax(dmax(ddi, ddj), ddk);
+          volc = vol[lt];
+        } else if (typ == 3) {
+          const long lt = INDMTR(p, i, j, k);
+          double ddi = sqrt(ti[lt + inci] * ti[lt + inci] + ti[lt + inci + ndm] * ti[lt + inci + ndm]);
+          ddi = ddi + sqrt(ti[lt] * ti[lt] + ti[lt + ndm] * ti[lt + ndm]);
+          double ddj = sqrt(tj[lt + incj] * tj[lt + incj] + tj[lt + incj + ndm] * tj[lt + incj + ndm]);
+          ddj = ddj + sqrt(tj[lt] * tj[lt] + tj[lt + ndm] * tj[lt + ndm]);
+          surf = 1. / dmax(ddi, ddj);
+          volc = vol[lt];
+        }
+        const double u = rop[l + nd], v = rop[l + 2 * nd], r = rop[l];
+        const double c = sqrt(gam2 * rop[l + 4 * nd]);
+        const double ur2 = typ == 3 ? u * u + v * v : u * u + v * v + w * w;
+        const double sp = sqrt(ur2);
+        const double xinvspc = 1. / (sp + c);
+        const double conv = 2. * volc * surf * xinvspc;
+        double comp = conv;
+        if (visc) {
+          const double xinvkt = gam1 / xmut[l];
+          const double vis = 2. * r * volc * volc * surf * surf * xinvkt;
+          comp = vis < conv ? vis : conv;
+        }
+        const double cfloc = dt / comp;
+        cfl[0] = dmax(cfl[0], cfloc);
+        cfl[1] = cfloc < cfl[1] ? cfloc : cfl[1];
+        cfl[2] = cfl[2] + cfloc;
+      }
+}
+
 /* BCzone with lrhs = 1 on the Newton residual (Fast/FastS/FastS/Compute/lhs.cpp:53-68,
  * Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,451-523).  On every zone face that carries a wall-type BC
  * (tags 3..7) the ghost residual is first zeroed over the whole face (extrapolation with c1 = 0), then every BC of that

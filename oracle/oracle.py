@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libfasts_oracle.so")
 _lib = None
 
 NIJK = 0; IJKV = 20; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NDIMDX = 41; NDIMDX_MTR = 43
-NSSITER = 58; DTC = 0; ITYPCP = 29; NEQ_COE = 39
+NSSITER = 58; DTC = 0; ITYPCP = 29; NEQ_COE = 39; IFLOW = 27
 
 
 def build():
@@ -104,6 +104,21 @@ class OracleZone:
         n = int(p[IJKV]) * int(p[IJKV + 1]) * int(p[IJKV + 2])
         dt = self.preal[DTC]
         return np.sqrt(s / n) / dt, m / dt
+
+    def cfl(self):
+        """[max, min, mean] of the local CFL number of the current state: what the first sub-iteration of a
+        verification step stores in CFL_minmaxmoy (cptst3.for:114-120, computePT.cpp:519,627-643)."""
+        p = self.pint
+        ind = np.array([1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2]], dtype=np.int32)
+        if int(p[IFLOW]) == 3:
+            lib().fo_vispalart(_p(p), _p(self.preal), _p(ind), _p(self.ro), _p(self.xmut))
+        elif int(p[IFLOW]) == 2:
+            lib().fo_invist(_p(p), _p(self.preal), _p(ind), _p(self.ro), _p(self.xmut))
+        out = np.array([0., 100000000., 0.])
+        lib().fo_cpcfl3(_p(p), _p(self.preal), _p(self.ro), _p(self.xmut), _p(self.ti), _p(self.tj), _p(self.tk),
+                        _p(self.vol), _p(out))
+        out[2] /= int(p[IJKV]) * int(p[IJKV + 1]) * int(p[IJKV + 2])
+        return out
 
     # -- split form of a time step, for multi-zone jobs -----------------------------------
     def roles(self, nstep):

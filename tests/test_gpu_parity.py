@@ -79,3 +79,34 @@ def test_unsupported_options_are_refused():
     t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'nb_relax': 2})
     with pytest.raises(_capi.FastsHipError, match="nb_relax"):
         FastS.warmup(t, None)
+
+
+@pytest.mark.parametrize("kind,model,perturb,temporal", [
+    ('tgv', 'NSLaminar', 0., 'explicit'), ('tgv', 'Euler', 0., 'explicit'), ('tgv', 'NSLaminar', 0.15, 'explicit'),
+    ('tgv', 'NSTurbulent', 0.15, 'implicit'), ('tgv2d', 'NSLaminar', 0.15, 'explicit'), ('tgv', 'Euler', 0.15, 'implicit'),
+])
+def test_cfl_diagnostic(kind, model, perturb, temporal):
+    """CFL_minmaxmoy of a verification step (cpcfl3.for) against the CPU restatement (itself checked against the
+    compiled reference): max and min bit for bit (1e-12 with Spalart-Allmaras: the device pow of the eddy
+    viscosity), the mean to 1e-13 (the device folds the sum in another order)."""
+    from fast_amd import cases
+    from common import SINGLE, wall_distance
+    kw = dict(model=model, extra_numz=SINGLE, perturb=perturb, temporal_scheme=temporal)
+    if temporal == 'implicit':
+        kw['time_step'] = 0.02
+    t = cases.tgv((34, 9, 8), 'ausmpred', **kw) if kind == 'tgv' else cases.tgv2d((37, 9), 'ausmpred', **kw)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0],
+                      wall_distance(z) if int(pint[36]) == 6 else None)
+    want = oz.cfl()
+    FastS._compute(t, metrics, 1, None)
+    FastS.display_temporal_criteria(t, metrics, 1, format='none')
+    got = Internal.getNodeFromName1(Internal.getNodeFromName1(z, '.Solver#ownData'), 'CFL_minmaxmoy')[1]
+    if int(pint[36]) == 6:
+        np.testing.assert_allclose(got[:2], want[:2], rtol=1e-12)
+    else:
+        assert got[0] == want[0] and got[1] == want[1]
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-13)
+    assert want[0] > want[1] > 0.

@@ -443,3 +443,34 @@ def test_host_metrics_equal_reference(n, perturb):
     assert typ == int(pint[25]) == (0 if perturb else 2)
     assert nijk_mtr == [int(v) for v in pint[5:10]]
     assert ndimdx_mtr == int(pint[43]) and neq_ij == int(pint[37]) and neq_k == int(pint[38])
+
+
+@pytest.mark.parametrize("kind,model,perturb", [
+    ('tgv', 'NSLaminar', 0.), ('tgv', 'Euler', 0.), ('tgv', 'NSLaminar', 0.15), ('tgv', 'Euler', 0.15),
+    ('tgv', 'NSTurbulent', 0.15), ('tgv2d', 'NSLaminar', 0.15), ('tgv2d', 'Euler', 0.),
+])
+def test_cfl_diagnostic_vs_reference(kind, model, perturb):
+    """[max, min, sum] of the local CFL number against cpcfl3_ of the compiled reference, on the three zone types,
+    Euler and viscous.  The reference loop carries an OpenMP SIMD directive, so its sum may be folded in a
+    different order: max and min must be equal, the mean to 1e-13."""
+    import ctypes
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    if kind == 'tgv':
+        t = cases.tgv((9, 8, 7), 'ausmpred', model=model, extra_numz=extra, perturb=perturb)
+    else:
+        t = cases.tgv2d((11, 9), 'ausmpred', model=model, extra_numz=extra, perturb=perturb)
+    so, sr = _pair(t)
+    oz, rz = so.zones[0], sr.zones[0]
+    so.fill_ghostcells()
+    got = oz.cfl()
+    L = R.lib()
+    p = oz.pint
+    ind = np.array([1, p[20], 1, p[21], 1, p[22]], dtype=np.int32)
+    ref = np.array([0., 100000000., 0.])
+    venti = np.zeros(8)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    L.cpcfl3_(ctypes.byref(ctypes.c_int32(0)), vp(p), vp(oz.preal), vp(ind), vp(ref), vp(oz.ro), vp(oz.xmut), vp(venti),
+              vp(rz.ti), vp(rz.tj), vp(rz.tk), vp(rz.vol))
+    ref[2] /= int(p[20]) * int(p[21]) * int(p[22])
+    assert got[0] == ref[0] and got[1] == ref[1] and got[0] > got[1] > 0.
+    np.testing.assert_allclose(got[2], ref[2], rtol=1e-13)
