@@ -345,7 +345,7 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
 {
   if (z.ityp != 0 || !z.vol || !z.mt[0] || !z.mt[1] || !z.mt[2]) return -1;
   if (z.iflow == 3 && (z.neq != 6 || !dist)) return -1;
-  int kchunk = 32;
+  int kchunk = 16;   // 256^3: 2.85 ms per stage against 2.96 with 32 (more workgroups in flight per CU)
   if (const char *ev = getenv("FASTS_HIP_KCHUNK_FULL")) {
     int v = atoi(ev);
     if (v >= 1) kchunk = v;
