@@ -365,16 +365,12 @@ def _build_omp(t):
 
 
 # ======================================================================================
-def nature_geom_dom(x, y, z, ific, ifick):
-    """Zone type detection (0 curvilinear, 1 k-homogeneous, 2 Cartesian constant step,
-    3 two-dimensional), vectorised restatement of
-    Fast/FastC/FastC/Metric/nature_geom_dom.for:186-503 (tolerance 2e-8, :29).
-    x, y, z are node arrays (ni, nj, nk).  Collapsed cells (:52-180) are ignored in the
-    tests, as in the reference.  Returns (typ_zone, nijk_mtr[5], ndimdx_mtr, neq_ij, neq_k)."""
+def degenerate_cells(x, y, z):
+    """Cells collapsed by the ghost-cell construction at a boundary: the four edges along one direction have zero
+    length (Fast/FastC/FastC/Metric/nature_geom_dom.for:52-180, tolerance 2e-8).  x, y, z are node arrays
+    (ni, nj, nk); returns a bool array (ni-1, nj-1, nk-1) indexed like the cells."""
     eps = 2.e-8
     ni, nj, nk = x.shape
-    if nk == 2:
-        return 3, [1, ni, 0, ific, ifick], ni * nj, 2, 0
 
     def seg(a, b):
         return numpy.sqrt((x[a] - x[b]) ** 2 + (y[a] - y[b]) ** 2 + (z[a] - z[b]) ** 2)
@@ -382,7 +378,6 @@ def nature_geom_dom(x, y, z, ific, ifick):
     def sl(di, dj, dk):
         return (slice(di, ni - 1 + di), slice(dj, nj - 1 + dj), slice(dk, nk - 1 + dk))
     deg = numpy.zeros((ni - 1, nj - 1, nk - 1), dtype=bool)
-    # a cell is collapsed when its four edges along one direction have zero length
     dirs = [
         [((0, 0, 0), (1, 0, 0)), ((0, 1, 0), (1, 1, 0)), ((0, 1, 1), (1, 1, 1)), ((0, 0, 1), (1, 0, 1))],
         [((0, 0, 0), (0, 1, 0)), ((1, 0, 0), (1, 1, 0)), ((1, 0, 1), (1, 1, 1)), ((0, 0, 1), (0, 1, 1))],
@@ -393,6 +388,134 @@ def nature_geom_dom(x, y, z, ific, ifick):
         for (a, b) in edges:
             allz &= seg(sl(*a), sl(*b)) <= eps
         deg |= allz
+    return deg
+
+
+def _ghost_planes(pint, typ):
+    """(first interior, last interior, ghost depth) per direction and the face order of tijk_extrap.for /
+    dist_extrap.for: kmin, kmax (when the zone has ghost layers along k), jmin, jmax, imin, imax."""
+    hi = [int(pint[IJKV]), int(pint[IJKV + 1]), int(pint[IJKV + 2]) if typ != 3 else 1]
+    nf = [int(pint[NIJK + 3]), int(pint[NIJK + 3]), int(pint[NIJK + 4])]
+    faces = ([(2, 0), (2, 1)] if nf[2] != 0 else []) + [(1, 0), (1, 1), (0, 0), (0, 1)]
+    return hi, nf, faces
+
+
+def tijk_extrap(pint, deg, mtr):
+    """Metrics of the collapsed ghost cells (Fast/FastC/FastC/Metric/tijk_extrap.for, called by init_metric.cpp:318):
+    the surface vectors of the transverse faces and the volume are taken from the mirror cell inside the zone,
+    and the vector of the face along the normal is rebuilt so that the six vectors of the cell still sum to zero.
+    Two passes, the second one over the edge and corner ghost cells too.  In place on the flat metric buffer
+    [ti | tj | tk | vol] of a curvilinear (type 0) or two-dimensional (type 3) zone; deg from degenerate_cells."""
+    typ = int(pint[ITYPZONE])
+    if typ not in (0, 3) or not deg.any():
+        return
+    ni, nj, nk = (int(v) for v in pint[NIJK_XYZ:NIJK_XYZ + 3])
+    nkm = nk if typ == 0 else 1
+    n = int(pint[NDIMDX_MTR]); neq_ij = int(pint[NEQ_IJ]); neq_k = int(pint[NEQ_K])
+    neq = [neq_ij, neq_ij, neq_k]
+    off = [0, n * neq_ij, 2 * n * neq_ij]
+    T = [[mtr[off[d] + c * n:off[d] + (c + 1) * n].reshape((ni, nj, nkm), order='F') for c in range(neq[d])]
+         for d in range(3)]
+    vol = mtr[2 * n * neq_ij + n * neq_k:].reshape((ni, nj, nkm), order='F')
+    hi, nf, faces = _ghost_planes(pint, typ)
+
+    def at(idx):      # cell / face indices (1 = first interior) -> array indices
+        return tuple(idx[d] + nf[d] - 1 for d in range(3))
+
+    for npass in (1, 2):
+        lo_l = [1 if npass == 1 else 1 - nf[d] for d in range(3)]
+        hi_l = [hi[d] if npass == 1 else hi[d] + nf[d] for d in range(3)]
+        for (d, side) in faces:
+            a, b = [t for t in range(3) if t != d]
+            planes = range(0, -nf[d], -1) if side == 0 else range(hi[d] + 1, hi[d] + nf[d] + 1)
+            A, B = numpy.meshgrid(numpy.arange(lo_l[a], hi_l[a] + 1), numpy.arange(lo_l[b], hi_l[b] + 1), indexing='ij')
+            for g in planes:
+                g0 = 1 - g if side == 0 else 2 * hi[d] + 1 - g
+                cell = [None] * 3; cell[d] = numpy.full_like(A, g); cell[a] = A; cell[b] = B
+                mir = list(cell); mir[d] = numpy.full_like(A, g0)
+                M = deg[at(cell)]
+                if not M.any():
+                    continue
+
+                def shifted(idx, t, by=1):
+                    out = list(idx); out[t] = idx[t] + by
+                    return out
+                for t in (a, b):
+                    if neq[t] == 0:
+                        continue
+                    nb = list(cell); nb[t] = numpy.maximum(1 - nf[t], cell[t] - 1)
+                    c1 = M & deg[at(nb)]
+                    nb[t] = numpy.minimum(hi[t] + nf[t], cell[t] + 1)
+                    c2 = M & deg[at(nb)]
+                    for c in range(neq[t]):
+                        w = tuple(v[c1] for v in at(cell)); r = tuple(v[c1] for v in at(mir))
+                        T[t][c][w] = T[t][c][r]
+                        w = tuple(v[c2] for v in at(shifted(cell, t))); r = tuple(v[c2] for v in at(shifted(mir, t)))
+                        T[t][c][w] = T[t][c][r]
+                # vector of the face along the normal (same operand order as the reference)
+                sel = lambda idx: tuple(v[M] for v in at(idx))
+                c0, cd = sel(cell), sel(shifted(cell, d))
+                if neq_k == 3:
+                    ca, cb = sel(shifted(cell, a)), sel(shifted(cell, b))
+                    for c in range(neq_ij):
+                        if side == 0:
+                            T[d][c][c0] = T[d][c][cd] - T[a][c][c0] + T[a][c][ca] - T[b][c][c0] + T[b][c][cb]
+                        else:
+                            T[d][c][cd] = T[d][c][c0] + T[a][c][c0] - T[a][c][ca] + T[b][c][c0] - T[b][c][cb]
+                elif d == 2:
+                    for c in range(neq_k):
+                        if side == 0: T[2][c][c0] = T[2][c][cd]
+                        else: T[2][c][cd] = T[2][c][c0]
+                else:
+                    o = 1 - d
+                    co = sel(shifted(cell, o))
+                    for c in range(neq_ij):
+                        if side == 0:
+                            T[d][c][c0] = T[d][c][cd] - T[o][c][c0] + T[o][c][co]
+                        else:
+                            T[d][c][cd] = T[d][c][c0] + T[o][c][c0] - T[o][c][co]
+                vol[c0] = vol[sel(mir)]
+
+
+def dist_extrap(pint, deg, dist):
+    """Wall distance of the collapsed ghost cells = that of the mirror cell inside the zone
+    (Fast/FastC/FastC/Metric/dist_extrap.for, init_metric.cpp:324-329).  dist: cell array (ni, nj, nk), in place."""
+    if not deg.any():
+        return
+    typ = int(pint[ITYPZONE])
+    hi, nf, faces = _ghost_planes(pint, typ)
+    hi[2] = int(pint[IJKV + 2])
+
+    def at(idx):
+        return tuple(idx[d] + nf[d] - 1 for d in range(3))
+    for npass in (1, 2):
+        lo_l = [1 if npass == 1 else 1 - nf[d] for d in range(3)]
+        hi_l = [hi[d] if npass == 1 else hi[d] + nf[d] for d in range(3)]
+        for (d, side) in faces:
+            a, b = [t for t in range(3) if t != d]
+            planes = range(0, -nf[d], -1) if side == 0 else range(hi[d] + 1, hi[d] + nf[d] + 1)
+            A, B = numpy.meshgrid(numpy.arange(lo_l[a], hi_l[a] + 1), numpy.arange(lo_l[b], hi_l[b] + 1), indexing='ij')
+            for g in planes:
+                g0 = 1 - g if side == 0 else 2 * hi[d] + 1 - g
+                cell = [None] * 3; cell[d] = numpy.full_like(A, g); cell[a] = A; cell[b] = B
+                mir = list(cell); mir[d] = numpy.full_like(A, g0)
+                M = deg[at(cell)]
+                if M.any():
+                    dist[tuple(v[M] for v in at(cell))] = dist[tuple(v[M] for v in at(mir))]
+
+
+# ======================================================================================
+def nature_geom_dom(x, y, z, ific, ifick):
+    """Zone type detection (0 curvilinear, 1 k-homogeneous, 2 Cartesian constant step,
+    3 two-dimensional), vectorised restatement of
+    Fast/FastC/FastC/Metric/nature_geom_dom.for:186-503 (tolerance 2e-8, :29).
+    x, y, z are node arrays (ni, nj, nk).  Collapsed cells (:52-180) are ignored in the
+    tests, as in the reference.  Returns (typ_zone, nijk_mtr[5], ndimdx_mtr, neq_ij, neq_k)."""
+    eps = 2.e-8
+    ni, nj, nk = x.shape
+    if nk == 2:
+        return 3, [1, ni, 0, ific, ifick], ni * nj, 2, 0
+    deg = degenerate_cells(x, y, z)
     ok = ~deg
     # index (1,1,1) of the reference = first interior node = [ific, ific, ifick]
     i1, j1, k1 = ific, ific, ifick
@@ -681,8 +804,18 @@ def allocate_metric_zone(z, nssiter):
     else:
         raise ValueError("fast_amd: zone %s is k-homogeneous (zone type 1); only Cartesian (2), curvilinear (0) "
                          "and two-dimensional (3) zones are implemented on the device." % z[0])
-    degen = numpy.zeros(1, Internal.E_NpyInt)
-    return [mtr, mtr, None, mtr, rdm, ind_dm, it_lu_ssdom, degen]
+    # collapsed ghost cells: flags dimensioned on the nodes like the reference's (metrics[7]), then the metric
+    # correction of init_metric.cpp:318 and, for the Spalart-Allmaras model, that of the wall distance (:324-329)
+    deg = degenerate_cells(x, y, zz)
+    degen = numpy.zeros((ni, nj, nk), Internal.E_NpyInt, order='F')
+    degen[:ni - 1, :nj - 1, :nk - 1] = deg
+    tijk_extrap(pint, deg, mtr)
+    if pint[IFLOW] == 3:
+        sol = Internal.getNodeFromName1(z, 'FlowSolution#Centers')
+        dn = Internal.getNodeFromName1(sol, 'TurbulentDistance') if sol is not None else None
+        if dn is not None:
+            dist_extrap(pint, deg, dn[1])
+    return [mtr, mtr, None, mtr, rdm, ind_dm, it_lu_ssdom, degen.reshape(-1, order='F')]
 
 
 # ======================================================================================

@@ -36,6 +36,21 @@ def _perturb(z, amp, L=2. * math.pi):
     xs[2][...] = zc + amp * h[2] * numpy.sin(w * x + 1.1) * numpy.cos(w * y) * numpy.cos(w * zc)
 
 
+def _collapse(z, faces, ghost=2):
+    """Put the ghost nodes of the given faces on the boundary nodes: the flat ghost cells a mesh generator leaves
+    behind physical boundaries (the solver then takes their metrics from the mirror cells)."""
+    g = Internal.getNodeFromName1(z, Internal.__GridCoordinates__)
+    for name in ('CoordinateX', 'CoordinateY', 'CoordinateZ'):
+        a = Internal.getNodeFromName1(g, name)[1]
+        for f in faces:
+            d = 'ijk'.index(f[0]); n = a.shape[d]
+            for r in range(ghost):
+                src = [slice(None)] * 3; dst = [slice(None)] * 3
+                src[d] = ghost if f.endswith('min') else n - 1 - ghost
+                dst[d] = r if f.endswith('min') else n - 1 - r
+                a[tuple(dst)] = a[tuple(src)]
+
+
 def _periodic_faces(z, faces=('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')):
     for f in faces:
         C.addBC2Zone(z, 'period ' + f, 'BCautoperiod', f)
@@ -81,7 +96,7 @@ def sa_fields(t, state, walls=(), L=2. * math.pi):
 
 def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
         temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None, bcs=None,
-        perturb=0., extra_numb=None):
+        perturb=0., extra_numb=None, collapse=()):
     """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
     whole box; blocks = (bi,bj,bk) split; only = block numbers to instantiate (the blocks of one
     rank; block b = ib + jb*bi + kb*bi*bj is named 'cart<b>').  Split directions carry no BC:
@@ -105,6 +120,8 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
                 z = _box(nb, ln, org, name)
                 if perturb:
                     _perturb(z, perturb, L1)
+                if collapse:
+                    _collapse(z, collapse)
                 faces = []
                 if blocks[0] == 1: faces += ['imin', 'imax']
                 if blocks[1] == 1: faces += ['jmin', 'jmax']
@@ -140,7 +157,7 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
 
 
 def tgv2d(n=(16, 12), scheme='ausmpred', model='NSLaminar', time_step=None, temporal_scheme='explicit',
-          extra_numz=None, extra_numb=None, bcs=None, perturb=0.):
+          extra_numz=None, extra_numb=None, bcs=None, perturb=0., collapse=()):
     """Two-dimensional zone (one cell along k, no ghost layer along k: zone type 3) on [-pi,pi]^2 with the
     Taylor-Green fields of the plane z = 0; faces without an entry in bcs are periodic.  perturb displaces the
     nodes in the plane."""
@@ -153,6 +170,8 @@ def tgv2d(n=(16, 12), scheme='ausmpred', model='NSLaminar', time_step=None, temp
         x, y = xs[0].copy(), xs[1].copy()
         xs[0][...] = x + perturb * h[0] * numpy.sin(y + 0.3) * numpy.cos(x)
         xs[1][...] = y + perturb * h[1] * numpy.sin(x + 0.7) * numpy.cos(y)
+    if collapse:
+        _collapse(z, collapse)
     faces = ['imin', 'imax', 'jmin', 'jmax']
     if bcs:
         for f in [f for f in faces if f in bcs]:

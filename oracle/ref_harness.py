@@ -136,6 +136,49 @@ def ref_nature_geom_dom(x, y, z, ific, ifick):
     return typ.value, nijk_mtr.tolist(), ndimdx_mtr.value, neq_ij.value, neq_k.value
 
 
+def ref_degenerate(x, y, z, ific, ifick):
+    """Collapsed-cell flags (dimensioned on the nodes) through the reference's nature_geom_dom_."""
+    L = lib()
+    ni, nj, nk = x.shape
+    nijk_xyz = np.array([ni, nj, nk, ific, ifick], dtype=np.int32)
+    nijk_mtr = np.zeros(5, dtype=np.int32)
+    degen = np.zeros(ni * nj * nk, dtype=np.int32)
+    a = ctypes.c_int32(0); b = ctypes.c_int32(0); c = ctypes.c_int32(0); typ = ctypes.c_int32(0)
+    preal = np.zeros(80)
+    xf = np.ascontiguousarray(x.reshape(-1, order='F')); yf = np.ascontiguousarray(y.reshape(-1, order='F'))
+    zf = np.ascontiguousarray(z.reshape(-1, order='F'))
+    L.nature_geom_dom_(_p(nijk_xyz), _i(ni * nj * nk), _p(xf), _p(yf), _p(zf), _p(degen), _i(0), _p(preal),
+                       _p(nijk_mtr), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(typ))
+    return degen
+
+
+def ref_tijk_extrap(param_int, degen, mtr):
+    """tijk_extrap_ of the reference on a metric buffer [ti | tj | tk | vol], with the range of
+    Fast/FastC/FastC/Metric/init_metric.cpp:289-322; returns the corrected copy."""
+    L = lib()
+    p = np.ascontiguousarray(param_int, dtype=np.int32)
+    nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
+    out = np.array(mtr, dtype=np.float64, copy=True)
+    ti = out[0:nm * nij]; tj = out[nm * nij:2 * nm * nij]
+    tk = out[2 * nm * nij:2 * nm * nij + nm * nk]; vol = out[2 * nm * nij + nm * nk:]
+    ind = np.array([1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2] if p[ITYPZONE] == 0 else 1], dtype=np.int32)
+    L.tijk_extrap_(_i(nm), _i(p[41 + 1]), _p(np.ascontiguousarray(p[10:15])), _p(np.ascontiguousarray(p[5:10])),
+                   _p(np.ascontiguousarray(p[0:5])), _i(nij), _i(nk), _p(ind), _p(np.ascontiguousarray(degen, dtype=np.int32)),
+                   _p(ti), _p(tj), _p(tk), _p(ti), _p(tj), _p(tk), _p(vol))
+    return out
+
+
+def ref_dist_extrap(param_int, degen, dist):
+    L = lib()
+    p = np.ascontiguousarray(param_int, dtype=np.int32)
+    out = np.ascontiguousarray(np.asarray(dist, dtype=np.float64).reshape(-1, order='F')).copy()
+    full = np.zeros(int(p[41])); full[:out.size] = out
+    ind = np.array([1, p[IJKV], 1, p[IJKV + 1], 1, p[IJKV + 2]], dtype=np.int32)
+    L.dist_extrap_(_i(p[41]), _i(p[42]), _p(np.ascontiguousarray(p[0:5])), _p(np.ascontiguousarray(p[10:15])), _p(ind),
+                   _p(np.ascontiguousarray(degen, dtype=np.int32)), _p(full))
+    return full[:out.size]
+
+
 class RefSolver:
     """Runs explicit (RK) time steps of a list of RefZone on the reference Fortran."""
 

@@ -110,3 +110,34 @@ def test_cfl_diagnostic(kind, model, perturb, temporal):
         assert got[0] == want[0] and got[1] == want[1]
     np.testing.assert_allclose(got[2], want[2], rtol=1e-13)
     assert want[0] > want[1] > 0.
+
+
+@pytest.mark.parametrize("kind,n,model,collapse,temporal", [
+    ('tgv', (34, 9, 8), 'NSLaminar', ('jmin', 'kmax'), 'explicit'),
+    ('tgv', (10, 9, 8), 'NSLaminar', ('jmin', 'jmax', 'imin'), 'implicit'),
+    ('tgv2d', (37, 9), 'NSLaminar', ('jmin',), 'implicit'),
+])
+def test_collapsed_ghost_cells(kind, n, model, collapse, temporal):
+    """Walls with flat ghost cells behind them (metrics of the ghost cells from tijk_extrap): bit for bit."""
+    from fast_amd import cases
+    from common import SINGLE
+    bcs = {f: 'BCWall' for f in collapse}
+    kw = dict(model=model, extra_numz=SINGLE, bcs=bcs, perturb=0.15, collapse=collapse, temporal_scheme=temporal)
+    if temporal == 'implicit':
+        kw['time_step'] = 0.02
+    t = cases.tgv(n, 'senseur', **kw) if kind == 'tgv' else cases.tgv2d(n, 'senseur', **kw)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert metrics[0][7].sum() > 0
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)
+    if temporal == 'implicit':
+        oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    for it in range(1, 5):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+    assert np.isfinite(got).all()

@@ -474,3 +474,44 @@ def test_cfl_diagnostic_vs_reference(kind, model, perturb):
     ref[2] /= int(p[20]) * int(p[21]) * int(p[22])
     assert got[0] == ref[0] and got[1] == ref[1] and got[0] > got[1] > 0.
     np.testing.assert_allclose(got[2], ref[2], rtol=1e-13)
+
+
+@pytest.mark.parametrize("kind,n,perturb,collapse,model", [
+    ('tgv', (9, 8, 7), 0.15, ('jmin',), 'NSLaminar'),
+    ('tgv', (8, 7, 9), 0.15, ('jmin', 'jmax', 'kmax', 'imin'), 'NSTurbulent'),
+    ('tgv', (7, 9, 8), 0.2, ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax'), 'NSLaminar'),
+    ('tgv2d', (11, 9), 0.15, ('jmin', 'imax'), 'NSTurbulent'),
+    ('tgv', (8, 8, 8), 0., ('jmin', 'kmin'), 'NSLaminar'),     # stays Cartesian: collapsed cells are not tested
+])
+def test_collapsed_ghost_cells_vs_reference(kind, n, perturb, collapse, model):
+    """Flat ghost cells behind physical boundaries: flags of nature_geom_dom_, metrics after tijk_extrap_ and wall
+    distance after dist_extrap_ of the compiled reference against the host model (bit for bit)."""
+    bcs = {f: 'BCWall' for f in collapse}
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    if kind == 'tgv':
+        t = cases.tgv(n, 'ausmpred', model=model, extra_numz=extra, bcs=bcs, perturb=perturb, collapse=collapse)
+    else:
+        t = cases.tgv2d(n, 'ausmpred', model=model, extra_numz=extra, bcs=bcs, perturb=perturb, collapse=collapse)
+    z = Internal.getZones(t)[0]
+    dist0 = None
+    if model == 'NSTurbulent':
+        dist0 = Internal.getNodeFromName1(Internal.getNodeFromName1(z, 'FlowSolution#Centers'), 'TurbulentDistance')[1].copy()
+    metrics = prepare(t)
+    pint, preal, xyz = zone_arrays(z)
+    degen = R.ref_degenerate(xyz[0], xyz[1], xyz[2], int(pint[3]), int(pint[4]))
+    assert degen.sum() > 0 and np.array_equal(degen, metrics[0][7])
+    assert int(pint[25]) == (2 if perturb == 0. else (0 if kind == 'tgv' else 3))
+    want = R.ref_tijk_extrap(pint, degen, R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2]))
+    assert np.array_equal(want, metrics[0][0])
+    if int(pint[25]) != 2:
+        assert not np.array_equal(want, R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2]))
+    if dist0 is not None:
+        got = Internal.getNodeFromName1(Internal.getNodeFromName1(z, 'FlowSolution#Centers'), 'TurbulentDistance')[1]
+        assert np.array_equal(R.ref_dist_extrap(pint, degen, dist0), got.reshape(-1, order='F'))
+    # and the flow solver runs on them
+    so, sr = _pair(t)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for it in range(1, 4):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+    assert np.isfinite(so.zones[0].ro).all()
