@@ -104,7 +104,8 @@ static std::string g_create_err;
 static int bc_kinds(const std::vector<FsBcWin> &v)
 {
   int k = 0;
-  for (auto &w : v) k |= (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE || w.type == FS_BC_ZERO) ? 1 : 2;
+  for (auto &w : v)
+    k |= (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE || w.type == FS_BC_ZERO || w.type == FS_BC_EXTRAP_NUT) ? 1 : 2;
   return k;
 }
 
@@ -342,7 +343,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     if (w.type == 22) continue;  // BCOverlap: filled by the join transfer
     // dispatch of Fast/FastS/FastS/BC/BCzone.cpp:262-283,451-461,513-523,578-586
     const int tag = w.type;
-    if (tag == 11 || tag == 0 || tag == 1) w.type = tag;
+    if (tag == 11 || tag == 0 || tag == 1 || tag == 14) w.type = tag;   // 14: BCExtrapolateRANS, nu_tilde only
     else if ((tag == 13 || tag == 2) && p[pt + 8] == 0) w.type = tag;   // BCInflow / BCInflowSupersonic on the reference state
     else if (tag == 2 && p[pt + 8] == p[NEQ] && pt + 9 < n_int && p[pt + 9] > 6) w.type = tag;   // its own state: BCzone.cpp:421-448
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
@@ -393,7 +394,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     w.st[0] = r[ROINF]; w.st[1] = r[VXINF] * r[ROINF]; w.st[2] = r[VYINF] * r[ROINF]; w.st[3] = r[VZINF] * r[ROINF];
     w.st[4] = r[PINF] / (r[GAMMA] - 1.) + 0.5 * (r[VXINF] * w.st[1] + r[VYINF] * w.st[2] + r[VZINF] * w.st[3]);
     w.tcn = w.idir <= 2 ? mtr[0] : (w.idir <= 4 ? mtr[1] : mtr[2]);
-    w.nue = r[RONUTILDEINF] / w.st[0];
+    w.nue = tag == 14 ? r[RONUTILDEINF] : r[RONUTILDEINF] / w.st[0];
     switch (w.idir) {  // bvbs_periodique.for: incp = IJKV(dir) * stride, towards the interior
       case 1: w.shift = z.iv; break;
       case 2: w.shift = -(long long)z.iv; break;

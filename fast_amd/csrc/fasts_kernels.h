@@ -8,7 +8,7 @@
 // (tag 4 is a slip wall for Euler and a no-slip wall otherwise)
 // FS_BC_ZERO: the extrapolation BC applied to the Newton residual (lrhs = 1): ghost = first interior cell * 0
 // (BCExtrapolate_init.for:2-6)
-enum { FS_BC_EXTRAPOLATE = 0, FS_BC_FARFIELD = 1, FS_BC_SUPERSONIC = 2, FS_BC_INFLOW = 13, FS_BC_WALL_SLIP = 3, FS_BC_WALL_NOSLIP = 6, FS_BC_PERIODIC = 11, FS_BC_OUTPRES = 16, FS_BC_WALL_ISOTHERMAL = 32, FS_BC_ZERO = 100 };
+enum { FS_BC_EXTRAPOLATE = 0, FS_BC_FARFIELD = 1, FS_BC_SUPERSONIC = 2, FS_BC_INFLOW = 13, FS_BC_WALL_SLIP = 3, FS_BC_WALL_NOSLIP = 6, FS_BC_PERIODIC = 11, FS_BC_EXTRAP_NUT = 14, FS_BC_OUTPRES = 16, FS_BC_WALL_ISOTHERMAL = 32, FS_BC_ZERO = 100 };
 
 struct FsBcWin {
   int type;          // FS_BC_*
@@ -17,7 +17,8 @@ struct FsBcWin {
   long long shift;   // periodic source offset (bvbs_periodique.for: incp)
   double st[5];      // conservative reference state (BCzone.cpp:26-38)
   double tcn;        // face metric along the normal (ti, tj or tk of the Cartesian zone)
-  double nue;        // reference nu_tilde of the SA model (BCFarfield_init.for: state(6)/state(1))
+  double nue;        // reference nu_tilde of the SA model (BCFarfield_init.for: state(6)/state(1));
+                     // FS_BC_EXTRAP_NUT: the lower bound RONUTILDEINF (BCExtrapolateRansLes_init.for)
   // window data (device): one value per face cell of the BC window, value of face cell (a,b) at
   // (a - dlo[0]) + (b - dlo[1]) * dn, a = first transverse direction (BC/INCREMENT_BC.h, indbci)
   const double *data;

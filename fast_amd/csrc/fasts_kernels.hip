@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) k_bc_copy(FsZone z, int nwin, const FsBcW
 {
   const FsBcWin *w = wins + blockIdx.y;
   const int type = w->type;
-  if (type != FS_BC_PERIODIC && type != FS_BC_EXTRAPOLATE && type != FS_BC_ZERO) return;
+  if (type != FS_BC_PERIODIC && type != FS_BC_EXTRAPOLATE && type != FS_BC_ZERO && type != FS_BC_EXTRAP_NUT) return;
   const int lo0 = w->lo[0], lo1 = w->lo[1], lo2 = w->lo[2];
   const int n0 = w->hi[0] - lo0 + 1, n1 = w->hi[1] - lo1 + 1, n2 = w->hi[2] - lo2 + 1;
   const int idir = w->idir;
@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(256) k_bc_copy(FsZone z, int nwin, const FsBcW
       }
       ls = fs_inddm(z, i, j, k);
     }
-    if (type == FS_BC_ZERO) { for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls] * 0.; }
+    if (type == FS_BC_EXTRAP_NUT) {   // only nu_tilde, bounded from below (BCExtrapolateRansLesSA_i.for)
+      if (z.neq == 6) rop[5 * nd + l] = fs_max(w->nue, rop[5 * nd + ls]) * 1.;
+    } else if (type == FS_BC_ZERO) { for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls] * 0.; }
     else { for (int e = 0; e < z.neq; e++) rop[e * nd + l] = rop[e * nd + ls]; }
   }
 }
@@ -258,7 +260,8 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
   const long long inc = sgn * stride;                          // from a ghost cell towards the interior
   const long long nd = z.nd;
   const long long n = (long long)na * nb;
-  if (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE || w.type == FS_BC_ZERO) return;   // k_bc_copy
+  if (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE || w.type == FS_BC_ZERO || w.type == FS_BC_EXTRAP_NUT)
+    return;   // k_bc_copy
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     int q[3];
     q[da] = w.lo[da] + (int)(t % na);

@@ -986,6 +986,25 @@ static void fo_bc_extrapolate_c(const i32 *p, int idir, const i32 *cl, double *r
       }
 }
 
+/* BCExtrapolateRANS (RANS / LES interface): only nu_tilde is extrapolated, bounded from below by RONUTILDEINF; the
+ * mean-flow ghost values are left to the join (Fast/FastS/FastS/BC/bvbs_extrapolate_ransles.for,
+ * BCExtrapolateRansLes_init.for, BCExtrapolateRansLesSA_i.for; with 5 equations the routine changes nothing) */
+void fo_bc_extrapolate_nut(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop)
+{
+  GEOM(p)
+  if (p[NEQ] != 6) return;
+  const fo_face f = fo_face_of(p, idir);
+  const double vmax = pr[8];
+  for (int k = cl[4]; k <= cl[5]; k++)
+    for (int j = cl[2]; j <= cl[3]; j++)
+      for (int i = cl[0]; i <= cl[1]; i++) {
+        int q[3] = {i, j, k};
+        q[f.d] = f.first;
+        long l = INDDM(i, j, k), l1 = INDDM(q[0], q[1], q[2]);
+        rop[l + 5 * nd] = dmax(vmax, rop[l1 + 5 * nd]) * 1.;
+      }
+}
+
 /* Adiabatic no-slip wall on a fixed mesh: ghost rank r mirrors interior rank r with the
  * velocity reversed (Fast/FastS/FastS/BC/bvbs_wall_viscous_adia.for:118-160,
  * BCWallViscous_i.for with c_ale = 0: rop(l,2) = 2*ventx*c_ale - u). */
@@ -1381,6 +1400,7 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     if (type == 11) fo_bc_periodic(p, idir, cl, rop);
     else if (type == 22) continue;
     else if (type == 0) fo_bc_extrapolate(p, idir, cl, rop);
+    else if (type == 14) fo_bc_extrapolate_nut(p, pr, idir, cl, rop);
     else if (type == 1) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
     else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1, 0, 0, 0);
     else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2, 0, 0, 0);

@@ -256,6 +256,10 @@ class RefSolver:
                 L.bvbs_extrapolate_(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl119),
                                     _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
                                     _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
+            elif btype == 14:
+                L.bvbs_extrapolate_ransles_(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl119),
+                                            _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+                                            _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
             elif btype == 22:
                 pass   # BCOverlap: ghost cells come from the join transfer
             elif btype in (16, 32):

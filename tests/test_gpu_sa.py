@@ -22,6 +22,7 @@ CASES = [
     ((10, 9, 8), 'senseur', {'jmin': 'BCWall', 'kmax': 'BCFarfield', 'imin': 'BCExtrapolate', 'imax': 'BCWallInviscid'}, 5),
     ((12, 10, 9), 'roe', None, 6),
     ((10, 9, 8), 'senseur', {'imin': 'BCInflow', 'imax': 'BCExtrapolate', 'jmax': 'BCInflowSupersonic'}, 5),
+    ((10, 9, 8), 'ausmpred', {'imin': 'BCExtrapolateRANS', 'kmax': 'BCExtrapolateRANS', 'jmin': 'BCWall'}, 5),
 ]
 
 

@@ -55,6 +55,8 @@ FAR = {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')
     ('Euler', 'roe', {'imin': 'BCExtrapolate', 'imax': 'BCExtrapolate', 'jmax': 'BCFarfield', 'kmin': 'BCExtrapolate'}),
     ('NSLaminar', 'ausmpred', {'imin': 'BCInflow', 'imax': 'BCFarfield', 'jmin': 'BCWall', 'kmax': 'BCInflowSupersonic'}),
     ('NSTurbulent', 'senseur', {'imin': 'BCInflow', 'imax': 'BCExtrapolate', 'jmax': 'BCInflowSupersonic'}),
+    ('NSTurbulent', 'ausmpred', {'imin': 'BCExtrapolateRANS', 'kmax': 'BCExtrapolateRANS', 'jmin': 'BCWall'}),
+    ('NSLaminar', 'ausmpred', {'imax': 'BCExtrapolateRANS'}),      # 5 equations: the routine changes nothing
 ])
 def test_boundary_conditions_bit_exact(model, scheme, bcs):
     """Ghost fill of walls, far field and extrapolation against bvbs_wall_viscous_adia /
