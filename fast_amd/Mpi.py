@@ -89,7 +89,7 @@ class HaloPlan:
 class HaloExchange:
     """Per-peer send / receive buffers and the message round of one sub-iteration."""
 
-    def __init__(self, plan, device, neq=5, sync=None):
+    def __init__(self, plan, device, neq=5, sync=None, counts=None):
         """device: where pack / unpack work.  With the "nccl" backend (RCCL) the device buffers go
         on the wire as they are.  With a host transport ("gloo") and device buffers, messages are
         staged through pinned host memory; `sync` (a callable that waits for the pack kernels) is
@@ -105,9 +105,12 @@ class HaloExchange:
         dev = torch.device(device)
         backend = dist.get_backend() if dist.is_available() and dist.is_initialized() else 'none'
         self.staged = dev.type == 'cuda' and backend != 'nccl'
+        # counts(peer, is_send): message sizes as the device context counts them (zones may carry 5 or 6 variables)
+        if counts is None:
+            counts = lambda p, send: plan.count(p, send, neq)
         for p in plan.peers():
-            self.sbuf[p] = torch.empty(plan.count(p, True, neq), dtype=torch.float64, device=dev)
-            self.rbuf[p] = torch.empty(plan.count(p, False, neq), dtype=torch.float64, device=dev)
+            self.sbuf[p] = torch.empty(counts(p, True), dtype=torch.float64, device=dev)
+            self.rbuf[p] = torch.empty(counts(p, False), dtype=torch.float64, device=dev)
             if self.staged:
                 self.hs[p] = torch.empty(self.sbuf[p].numel(), dtype=torch.float64).pin_memory()
                 self.hr[p] = torch.empty(self.rbuf[p].numel(), dtype=torch.float64).pin_memory()
@@ -200,7 +203,7 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     ctx.upload()
     hook = FastS._set_hook(ctx, dtloc, names, mpi=1)
     with torch.cuda.stream(comm):
-        halo = HaloExchange(plan, torch.device('cuda', device))
+        halo = HaloExchange(plan, torch.device('cuda', device), counts=lambda p, send: ctx.halo_count(p, send))
     halo.stream = comm
     halo.main = main
     halo.overlap = os.environ.get('FASTS_HIP_OVERLAP', '1') != '0'

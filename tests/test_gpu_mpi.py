@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("blocks,n,mode", [((1, 1, 2), 12, 'explicit'), ((2, 1, 1), 10, 'explicit'),
-                                           ((1, 2, 1), 10, 'implicit'), ((1, 1, 2), 10, 'curvilinear')])
+                                           ((1, 2, 1), 10, 'implicit'), ((1, 1, 2), 10, 'curvilinear'),
+                                           ((1, 1, 2), 10, 'sa')])
 def test_two_ranks_one_gpu(blocks, n, mode):
     rcs, outs = _run(2, list(blocks) + [n, 3, mode], timeout=300, worker='mpi_gpu_worker.py')
     assert rcs == [0, 0], "\n".join(outs)
