@@ -504,16 +504,18 @@ extern "C" int fs_join_add(fs_ctx *ctx, int rcv_zone, int donor_zone, const int3
   if (!ctx || !rcv_pts || npts <= 0) return ctx ? fail(ctx, FS_ERR_ARG, "fs_join_add: bad argument") : FS_ERR_ARG;
   int rc = check_pts(ctx, rcv_zone, rcv_pts, npts, "fs_join_add");
   if (rc) return rc;
+  if (donor_zone >= 0) {   // every check before the first allocation: nothing to release on the error paths
+    if (!donor_pts) return fail(ctx, FS_ERR_ARG, "fs_join_add: donor list missing");
+    rc = check_pts(ctx, donor_zone, donor_pts, npts, "fs_join_add");
+    if (rc) return rc;
+    if (ctx->zones[donor_zone].z.neq != ctx->zones[rcv_zone].z.neq) return fail(ctx, FS_ERR_ARG, "fs_join_add: zones differ in NEQ");
+  }
   Join j;
   j.rcv_zone = rcv_zone; j.npts = npts;
   (void)hipSetDevice(ctx->device);
   HIPCHK(ctx, hipMalloc(&j.rcv_dev, sizeof(int) * npts));
   HIPCHK(ctx, hipMemcpy(j.rcv_dev, rcv_pts, sizeof(int) * npts, hipMemcpyHostToDevice));
   if (donor_zone >= 0) {
-    if (!donor_pts) return fail(ctx, FS_ERR_ARG, "fs_join_add: donor list missing");
-    rc = check_pts(ctx, donor_zone, donor_pts, npts, "fs_join_add");
-    if (rc) return rc;
-    if (ctx->zones[donor_zone].z.neq != ctx->zones[rcv_zone].z.neq) return fail(ctx, FS_ERR_ARG, "fs_join_add: zones differ in NEQ");
     j.donor_zone = donor_zone; j.peer_tag = -1;
     HIPCHK(ctx, hipMalloc(&j.dnr_dev, sizeof(int) * npts));
     HIPCHK(ctx, hipMemcpy(j.dnr_dev, donor_pts, sizeof(int) * npts, hipMemcpyHostToDevice));
