@@ -256,8 +256,10 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
   if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
-  if (p[DTLOC] != 0 && !(p[ITYPCP] == 1 && p[DTLOC] == 1))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: a local time step (time_step_nature='local') needs the implicit scheme");
+  if (p[DTLOC] != 0 && p[DTLOC] != 1)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: DTLOC must be 0 or 1");
+  if (p[DTLOC] == 1 && !implicit && (ctx->plain_stage || !ctx->dma_stage))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: a local time step with the explicit scheme needs the default stage kernels");
   if (!implicit && (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK])) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
   if (implicit && p[NSSITER] < 2) return fail(ctx, FS_ERR_ARG, "fs_zone_add: an implicit step needs at least one Newton sub-iteration (NSSITER >= 2)");
   if (p[NIJK + 3] != 2 || p[NIJK + 4] != (twod ? 0 : 2))
@@ -570,9 +572,11 @@ extern "C" int fs_upload(fs_ctx *ctx)
         HIPCHK(ctx, hipMemcpyAsync(zn.dist, zn.dist_host, sizeof(double) * (size_t)zn.z.ni * zn.z.nj * zn.z.nk,
                                    hipMemcpyHostToDevice, ctx->stream));
       }
-      if (ctx->implicit) {
+      if (ctx->implicit || zn.pint[DTLOC] == 1) {   // coe(:,1..5|6); an explicit local time step uses coe(:,1) only
         HIPCHK(ctx, hipMalloc(&zn.coe, nb));
         HIPCHK(ctx, hipMemsetAsync(zn.coe, 0, nb, ctx->stream));
+      }
+      if (ctx->implicit) {
         HIPCHK(ctx, hipMalloc(&zn.scratch, nb));
         HIPCHK(ctx, hipMemsetAsync(zn.scratch, 0, nb, ctx->stream));
       }
@@ -667,7 +671,7 @@ static int build_shell_lists(fs_ctx *ctx)
     Zone &zn = ctx->zones[nz];
     const FsZone &z = zn.z;
     for (auto &s : ctx->sends) if (s.donor_zone == (int)nz) zn.has_sends = true;
-    if (z.ityp == 0 || ctx->implicit || z.iflow == 3 || !zn.roe_walls.empty()) continue;   // these zones run their stage in one piece
+    if (z.ityp == 0 || ctx->implicit || z.iflow == 3 || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1) continue;   // these zones run their stage in one piece
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
     std::vector<char> mark((size_t)nblk, 0);
@@ -729,8 +733,14 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     if (ctx->first_it == 0 || dtloc) { bdf.c1 = -1.; bdf.c2 = 1.; bdf.c3 = 0.; }   // core3as2.for:37-45
     const FsBdf *pbdf = ctx->implicit ? &bdf : nullptr;
     if (opens && nstep == 1) {
-      if (z.iflow == 2) fsk_invist(z, ctx->implicit ? z.ific : 1, zn.dev[in], zn.xmut, ctx->stream);
+      if (z.iflow == 2) fsk_invist(z, (ctx->implicit || dtloc) ? z.ific : 1, zn.dev[in], zn.xmut, ctx->stream);
       if (z.iflow == 3) fsk_vispalart(z, zn.dev[in], zn.xmut, ctx->stream);
+      if (!ctx->implicit && dtloc) {
+        // tstb3_expli.for + dtloc.for: the CFL-limited step of every cell = coe(:,1) of the implicit coefficients
+        const double *r = zn.preal.data();
+        fsk_coe_implicit(z, 0, 1, r[CFL], r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in], zn.xmut, zn.coe,
+                         ctx->stream);
+      }
       if (ctx->implicit) {
         const double *r = zn.preal.data();
         fsk_coe_implicit(z, ctx->first_it, dtloc, r[CFL], r[GAMMA], r[PRANDT], r[CVINF] * (r[GAMMA] - 1.), zn.dev[in],
@@ -777,10 +787,14 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     if (deferred) {
       for (auto &rw : zn.roe_walls) fsk_roe_wall(z, rw.idir, rw.lo, rw.hi, rw.tag, zn.dev[in], zn.drodm, ctx->stream);
       if (ctx->implicit) fsk_finish_bdf(z, zn.dev[in], zn.drodm, bdf, ctx->stream);
-      else
+      else if (!dtloc)
         for (auto &rw : zn.roe_walls)
           fsk_finish_wall_rows(z, rw.idir, rw.lo, rw.hi, coefW, zn.dev[in], zn.dev[out], zn.drodm, ctx->stream);
     }
+    // explicit scheme with a local time step: the stage kernel has left the balance in drodm (and an update with
+    // the global step that is discarded); every cell is updated with its own coe(:,1)
+    if (dtloc && !ctx->implicit)
+      fsk_finish_rk_local(z, coefW, zn.coe, zn.dev[in], zn.dev[out], zn.drodm, ctx->stream);
     if (!closes) continue;
     if (ctx->timing) {   // one timed interval per stage, from its first launch to its last
       if (ctx->ev_used == ctx->ev.size()) {
@@ -794,7 +808,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       ctx->ev_used++;
     }
     if (nstep == 1 && (nitrun % ctx->modulo_verif == 0 || nitrun == 1)) {
-      fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out, ctx->stream);
+      fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out, ctx->stream,
+                   (!ctx->implicit && dtloc) ? zn.coe : nullptr);
       zn.have_res = true;
       // local CFL number of the state the step starts from (cptst3.for:114-120: first sub-iteration of a
       // verification step), with the viscosity this stage has just evaluated

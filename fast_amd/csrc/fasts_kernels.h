@@ -67,7 +67,9 @@ void fsk_join_copy(int npts, int neq, long long nd_r, long long nd_d, const int 
 void fsk_halo_pack(int npts, int neq, long long nd, const int *pts, const double *rop, double *buf, hipStream_t s);
 void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *rop, const double *buf, hipStream_t s);
 // use_coe = 1: norms of dt/vol * drodm (explicit balance); 0: norms of drodm (Newton residual, already scaled)
-void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s);
+// use_coe: norms of coe * drodm (explicit scheme); coe1 != NULL: the per-cell coe(:,1) of a local time step
+void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s,
+                  const double *coe1 = nullptr);
 // out[3] = largest, smallest and mean local CFL number of the interior cells (cpcfl3.for); part = 3 doubles per
 // (j,k) row of scratch; gam1 = gamma / Prandtl, gam2 = gamma * R
 void fsk_cfl(const FsZone &z, double gam1, double gam2, const double *rop, const double *xmut, double *part, double *out,
@@ -86,3 +88,5 @@ void fsk_roe_wall(const FsZone &z, int idir, const int *glo, const int *ghi, int
 void fsk_finish_wall_rows(const FsZone &z, int idir, const int *glo, const int *ghi, double coefW, const double *rop_in,
                           double *rop_out, double *drodm, hipStream_t s);
 void fsk_finish_bdf(const FsZone &z, const double *rop_in, double *drodm, const FsBdf &bdf, hipStream_t s);
+void fsk_finish_rk_local(const FsZone &z, double coefW, const double *coe1, const double *rop_in, double *rop_out,
+                         double *drodm, hipStream_t s);

@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256) k_halo_unpack(int npts, int neq, long lon
 // in index order, so the result does not depend on scheduling.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, int use_coe, const double *__restrict__ drodm,
-                                                          double *__restrict__ part)
+                                                          double *__restrict__ part, const double *__restrict__ coe1)
 {
   __shared__ double ssum[5][256];
   __shared__ double smax[5][256];
@@ -488,6 +488,7 @@ __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, int use_coe,
     long long l = fs_inddm(z, i, j, k);
     double coe = z.coe;
     if (!use_coe) coe = 1.;
+    else if (coe1) coe = coe1[l];
     else if (z.ityp == 0)   // dt/vol of the cell (tstb3_global.for:64-78)
       coe = z.dt / z.vol[(long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj +
                          (long long)(k + z.ifick - 1) * z.minck];
@@ -713,8 +714,9 @@ void fsk_cfl(const FsZone &z, double gam1, double gam2, const double *rop, const
                      1. / ((double)z.iv * z.jv * z.kv), (const double *)part, out);
 }
 
-void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s)
+void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s,
+                  const double *coe1)
 {
-  hipLaunchKernelGGL(k_residual_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, use_coe, drodm, part);
+  hipLaunchKernelGGL(k_residual_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, use_coe, drodm, part, coe1);
   hipLaunchKernelGGL(k_residual_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv, part, out);
 }

@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(128) k_finish(FsZone z, FsWallRow w, double co
   const int neq = z.neq;
   double q[6] = {0., 0., 0., 0., 0., 0.}, d[6] = {0., 0., 0., 0., 0., 0.}, o[6];
   for (int e = 0; e < neq; e++) { q[e] = rop_in[e * nd + l]; d[e] = drodm[e * nd + l]; }
-  const double coe = z.ityp == 0 ? z.dt / z.vol[wmtr(z, i, j, k)] : z.coe;
+  double coe = z.ityp == 0 ? z.dt / z.vol[wmtr(z, i, j, k)] : z.coe;
+  if (!BDF && bdf.coe1) coe = bdf.coe1[l];   // explicit scheme with a local time step: coe(:,1) of the cell
   if (BDF) {
     double qn[6] = {0., 0., 0., 0., 0., 0.}, qn1[6] = {0., 0., 0., 0., 0., 0.};
     for (int e = 0; e < neq; e++) qn1[e] = bdf.ro_n1[e * nd + l];
@@ -183,6 +184,21 @@ void fsk_finish_wall_rows(const FsZone &z, int idir, const int *glo, const int *
   const long long n = row_cells(w);
   if (n <= 0) return;
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
+  hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, z, w, coefW, rop_in, rop_out,
+                     drodm, b);
+}
+
+// Runge-Kutta update of every interior cell with its own time step coe1 (time_step_nature='local' with the
+// explicit scheme, core3ark3.for with coe(l,1) from tstb3_expli.for), from the balance kept in drodm.
+void fsk_finish_rk_local(const FsZone &z, double coefW, const double *coe1, const double *rop_in, double *rop_out,
+                         double *drodm, hipStream_t s)
+{
+  FsWallRow w;
+  w.d = 0; w.maxside = 0; w.slip = 0;
+  w.lo[0] = w.lo[1] = w.lo[2] = 1;
+  w.hi[0] = z.iv; w.hi[1] = z.jv; w.hi[2] = z.kv;
+  const long long n = row_cells(w);
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, coe1};
   hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, z, w, coefW, rop_in, rop_out,
                      drodm, b);
 }

@@ -1520,6 +1520,9 @@ void fo_bfl3(const i32 *p, const double *pr, const double *rop, double *drodm, c
  * block), sequence of Fast/FastS/FastS/Compute/navier_stokes_struct.for:199-275,295-301,
  * 310-345,467-475 and src_term.for:59-70,258-272.  rop_in is the stage input, rop_out the
  * stage output. */
+void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *ind, const double *rop,
+                       const double *xmut, double *coe, const double *ti, const double *tj, const double *tk,
+                       const double *vol);
 void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in, double *rop_out,
                 double *drodm, double *coe, double *xmut, double *wig, const double *ti,
                 const double *tj, const double *tk, const double *vol)
@@ -1537,6 +1540,16 @@ void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in
     }
     double volinv = pr[DTC] / vol[0]; /* Fast/FastS/FastS/Compute/tstb3_global.for:64-78 */
     GEOM(p)
+    if (p[46] == 1) {
+      /* local time step with the explicit scheme (cptst3.for:77-82 -> tstb3_expli.for + dtloc.for): the same
+       * CFL-limited step as coe(:,1) of the implicit scheme, on the interior cells */
+      double *tmp = (double *)malloc(sizeof(double) * 5 * (size_t)nd);
+      fo_tstb3_implicit(p, pr, 0, sdm, rop_in, xmut, tmp, ti, tj, tk, vol);
+      for (int k = 1; k <= kv; k++)
+        for (int j = 1; j <= jv; j++)
+          for (int i = 1; i <= iv; i++) coe[INDDM(i, j, k)] = tmp[INDDM(i, j, k)];
+      free(tmp);
+    } else
     for (int k = 1; k <= kv; k++)
       for (int j = 1; j <= jv; j++)
         for (int i = 1; i <= iv; i++)

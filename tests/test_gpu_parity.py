@@ -141,3 +141,44 @@ def test_collapsed_ghost_cells(kind, n, model, collapse, temporal):
         got = FastC.level_buffer(z)
         assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
     assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("kind,n,scheme,model,perturb,bcs", [
+    ('tgv', (34, 9, 8), 'ausmpred', 'NSLaminar', 0., None),
+    ('tgv', (70, 9, 12), 'senseur', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+    ('tgv', (10, 9, 8), 'senseur', 'Euler', 0.15, None),
+    ('tgv', (10, 9, 8), 'roe', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+    ('tgv', (12, 9, 8), 'roe', 'NSLaminar', 0., {'kmin': 'BCWall'}),
+    ('tgv', (10, 9, 8), 'ausmpred', 'NSTurbulent', 0., {'jmin': 'BCWall'}),
+    ('tgv2d', (37, 9), 'ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+])
+def test_explicit_local_time_step(kind, n, scheme, model, perturb, bcs):
+    """time_step_nature='local' with the explicit scheme (tstb3_expli.for): every cell advances with its own
+    CFL-limited step.  Bit for bit (1e-12 with Spalart-Allmaras); the residual norms use the same per-cell step."""
+    from fast_amd import cases
+    from common import SINGLE, wall_distance
+    extra = dict(SINGLE, time_step_nature='local', cfl=0.5)
+    kw = dict(model=model, extra_numz=extra, bcs=bcs, perturb=perturb)
+    t = cases.tgv(n, scheme, **kw) if kind == 'tgv' else cases.tgv2d(n, scheme, **kw)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[46]) == 1 and int(pint[29]) == 2
+    neq = int(pint[36])
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z) if neq == 6 else None)
+    oz.fill_ghostcells()
+    ro0 = oz.ro.copy()
+    for it in range(1, 6):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        if neq == 6:
+            assert rel_err(got, oz.ro, int(pint[41]), neq=6).max() < 1e-12, "step %d" % it
+        else:
+            assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+        if it == 1 and neq == 5:
+            l2, loo = FastS.display_temporal_criteria(t, metrics, it, format='none')[z[0]]
+            rl2, rloo = oz.residuals()
+            np.testing.assert_allclose(l2, rl2, rtol=1e-11)
+            np.testing.assert_allclose(loo, rloo, rtol=1e-13)
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-6

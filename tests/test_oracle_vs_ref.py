@@ -517,3 +517,29 @@ def test_collapsed_ghost_cells_vs_reference(kind, n, perturb, collapse, model):
         so.step(); sr.step(it)
         assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
     assert np.isfinite(so.zones[0].ro).all()
+
+
+@pytest.mark.parametrize("kind,scheme,model,perturb,bcs", [
+    ('tgv', 'ausmpred', 'NSLaminar', 0., None),
+    ('tgv', 'senseur', 'Euler', 0.15, None),
+    ('tgv', 'roe', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+    ('tgv', 'ausmpred', 'NSTurbulent', 0., {'jmin': 'BCWall'}),
+    ('tgv2d', 'ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+])
+def test_explicit_local_time_step_bit_exact(kind, scheme, model, perturb, bcs):
+    """time_step_nature='local' with the explicit scheme: every cell advances with its own CFL-limited step
+    (cptst3.for:77-82 -> tstb3_expli.for, dtloc.for) in the Runge-Kutta update."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000,
+             'time_step_nature': 'local', 'cfl': 0.5}
+    if kind == 'tgv':
+        t = cases.tgv((9, 8, 7), scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb)
+    else:
+        t = cases.tgv2d((11, 9), scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb)
+    so, sr = _pair(t)
+    assert int(so.zones[0].pint[46]) == 1 and int(so.zones[0].pint[29]) == 2
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 6):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-6
