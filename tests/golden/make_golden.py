@@ -70,6 +70,13 @@ CASES = {
     # BCs that read window data from Parameter_real: two pressure outlets, one isothermal wall, one far field
     'outlet_isowall_curv':      ('tgv', (10, 9, 8), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 10,
                                  data_bcs((10, 9, 8)), {'perturb': 0.15}),
+    # explicit scheme with a local time step (roe + walls); walls with flat ghost cells behind them and a RANS/LES
+    # extrapolation of nu_tilde, implicit
+    'explicit_local_roe_curv':  ('tgv', (10, 9, 8), 'roe', 'NSLaminar', (1, 1, 1), 'single', 10,
+                                 {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {'perturb': 0.15, 'local': 0.5}),
+    'collapsed_walls_sa_impl':  ('tgv', (10, 9, 8), 'ausmpred', 'NSTurbulent', (1, 1, 1), 'single', 6,
+                                 {'jmin': 'BCWall', 'kmax': 'BCWall', 'imin': 'BCExtrapolateRANS'},
+                                 {'perturb': 0.15, 'collapse': ('jmin', 'kmax'), 'ss_iteration': 3, 'time_step': 0.02}),
     'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
     'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
 }
@@ -79,10 +86,14 @@ def build(kind, n, scheme, model, blocks, cache, bcs=None, opts=None, modulo_ver
     """The tree of one case; shared with the tests that replay the golden vectors."""
     extra = SINGLE if cache == 'single' else None
     opts = opts or {}
+    if opts.get('local'):      # time_step_nature='local' at the given CFL number
+        extra = dict(extra or {}, time_step_nature='local', cfl=opts['local'])
     if kind == 'tgv':
         kw = {}
+        if 'collapse' in opts:
+            kw['collapse'] = opts['collapse']
         if 'ss_iteration' in opts:
-            kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': opts['ss_iteration']}}
+            kw.update({'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': opts['ss_iteration']}})
         return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra, bcs=bcs, modulo_verif=modulo_verif,
                          perturb=opts.get('perturb', 0.), time_step=opts.get('time_step'), **kw)
     if kind == 'tgv2d':
@@ -132,8 +143,12 @@ def main():
             rz.append(R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], ro0, m[0], dist))
             if dist is not None:
                 out['dist%d' % b] = np.ascontiguousarray(dist.reshape(-1, order='F'))
-            # metrics from the reference's own cp_tijk / cp_vol
-            out['mtr%d' % b] = R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2])
+            # metrics from the reference's own cp_tijk / cp_vol, then tijk_extrap on the collapsed ghost cells
+            mref = R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2])
+            if int(pint[25]) in (0, 3):
+                mref = R.ref_tijk_extrap(pint, R.ref_degenerate(xyz[0], xyz[1], xyz[2], int(pint[3]), int(pint[4])), mref)
+            assert np.array_equal(mref, m[0])
+            out['mtr%d' % b] = mref
             out['pint%d' % b] = np.asarray(pint, dtype=np.int32)
             out['preal%d' % b] = np.asarray(preal, dtype=np.float64)
             out['ro0_%d' % b] = ro0
