@@ -348,6 +348,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     if (tag == 11 || tag == 0 || tag == 1 || tag == 14) w.type = tag;   // 14: BCExtrapolateRANS, nu_tilde only
     else if ((tag == 13 || tag == 2) && p[pt + 8] == 0) w.type = tag;   // BCInflow / BCInflowSupersonic on the reference state
     else if (tag == 2 && p[pt + 8] == p[NEQ] && pt + 9 < n_int && p[pt + 9] > 6) w.type = tag;   // its own state: BCzone.cpp:421-448
+    else if (tag == 17 && p[pt + 8] == p[NEQ]) w.type = tag;   // BCInj1: d0x, d0y, d0z, pa, ha [, nu_tilde], BCzone.cpp:594-618
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
     else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
     else if (tag == 16 || (tag == 32 && p[IFLOW] > 1)) w.type = tag;   // BCOutpres, BCWallViscousIsothermal: window data
@@ -359,7 +360,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     if (w.idir < 1 || w.idir > 6) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC window is not on a zone face");
     long long data_off = -1;
     w.data = nullptr; w.dlo[0] = w.dlo[1] = 0; w.dn = 1; w.dsize = 0;
-    if (tag == 2 && p[pt + 8] != 0) {
+    w.nit = p[65]; w.tol = r[37];   // NIT_INFLOW, EPSI_INFLOW
+    if ((tag == 2 && p[pt + 8] != 0) || tag == 17) {
       // NEQ arrays of one size, one value per face cell of the window: rho, rho u, rho v, rho w, rho E [, rho nu_tilde]
       const int nbdata = p[pt + 8], size = p[pt + 9];
       const long long off = p[pt_bcs + 1 + ndf + nb];

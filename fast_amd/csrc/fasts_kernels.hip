@@ -338,7 +338,51 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         for (int e = 0; e < z.neq; e++) rop[l1 - r * inc + e * nd] = g[e];
     } else {  // FS_BC_FARFIELD, FS_BC_INFLOW (same characteristic state, BCInflow_i.for), FS_BC_SUPERSONIC
       const double snorm = (w.idir & 1) ? -1. : 1.;
-      if (w.type == FS_BC_SUPERSONIC && w.data) {   // first rank = the window's own conservative state
+      if (w.type == FS_BC_INJ1) {
+        // stagnation pressure pa, stagnation enthalpy ha and direction d0 imposed, outgoing characteristic from
+        // inside, Newton on the normal velocity (BCInj1_i.for, BCInflow_newton_{1,2,3}_firstrank.for; qen = 0)
+        const long long l = l1 - inc;
+        const double *dt = w.data + (q[da] - w.dlo[0]) + (long long)(q[db] - w.dlo[1]) * w.dn;
+        const long long ds = w.dsize;
+        const double d0x = dt[0], d0y = dt[ds], d0z = dt[2 * ds], pa = dt[3 * ds], ha = dt[4 * ds];
+        const double gam2 = z.gam / (z.gam - 1.);
+        double tc[3];
+        fs_bc_metric(z, w, d, q, tc);
+        const double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
+        const double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz), s_1 = 1. / sn;
+        double tnx = 1., tny = 0., tnz = 0.;
+        if (sn != 0.) { tnx = tcx * s_1; tny = tcy * s_1; tnz = tcz * s_1; }
+        const double roi = rop[l1], ui = rop[l1 + nd], vi = rop[l1 + 2 * nd], wi = rop[l1 + 3 * nd], Ti = rop[l1 + 4 * nd];
+        const double pi = roi * z.rgp * Ti;
+        const double qen = 0.;
+        const double vni = ui * tnx + vi * tny + wi * tnz;
+        const double roc0 = sqrt(roi * z.gam * pi);
+        const double usd0n = 1. / (d0x * tnx + d0y * tny + d0z * tnz), usd0n2 = usd0n * usd0n;
+        const double wni = vni - qen, ri = pi + roc0 * wni;
+        double wng = ui * tnx + vi * tny + wi * tnz - qen;
+        double residug = 1.e+20;
+        int nitnwt = 0;
+        while (residug > w.tol && nitnwt < w.nit) {
+          nitnwt++;
+          residug = 0.;
+          double b = 1. - ((wng + qen) * (wng + qen)) * usd0n2 / (2. * ha);
+          b = fs_max(0.2, b);
+          const double pg = pa * pow(b, gam2);
+          const double rog = gam2 * pg / (ha * b);
+          const double fn = pg + roc0 * wng - ri;
+          const double df = roc0 - rog * (wng + qen) * usd0n2;
+          const double dwng = -fn / df;
+          wng = wng + dwng;
+          residug = fs_max(residug, fabs(dwng / wng));
+        }
+        const double vng = wng + qen, vg = vng * usd0n;
+        double b = 1. - (vng * vng) * usd0n2 / (2. * ha);
+        b = fs_max(0.2, b);
+        const double pg = pa * pow(b, gam2), rog = gam2 * pg / (ha * b), Tg = pg / (rog * z.rgp);
+        rop[l] = rog; rop[l + nd] = vg * d0x; rop[l + 2 * nd] = vg * d0y; rop[l + 3 * nd] = vg * d0z;
+        rop[l + 4 * nd] = Tg;
+        if (z.neq == 6) rop[l + 5 * nd] = dt[5 * ds];
+      } else if (w.type == FS_BC_SUPERSONIC && w.data) {   // first rank = the window's own conservative state
         const long long l = l1 - inc;                 // (BCInflowSupersonic_fich_firstrank.for)
         const double *dt = w.data + (q[da] - w.dlo[0]) + (long long)(q[db] - w.dlo[1]) * w.dn;
         const double ro = dt[0], ru = dt[w.dsize], rv = dt[2 * (long long)w.dsize], rw = dt[3 * (long long)w.dsize];

@@ -1137,7 +1137,51 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
         const long l1 = INDDM(i, j, k);      /* first interior cell */
         long l = l1 - inc;                   /* first ghost rank */
         fo_bc_metric(p, idir, i, j, k, ti, tj, tk, tc);
-        if (mode == 2 && data) {
+        if (mode == 3) {
+          /* BCInj1: stagnation pressure pa, stagnation enthalpy ha and direction d0 imposed, the outgoing
+           * characteristic taken from inside, Newton on the normal velocity (bvbs_inflow_newton.for, BCInj1_i.for,
+           * BCInflow_newton_{1,2,3}_firstrank.for, linearization_state.for; fixed mesh: qen = 0) */
+          const int q[3] = {i, j, k};
+          const int da = f.d == 0 ? 1 : 0, db = f.d == 2 ? 1 : 2;
+          const long li = (q[da] - inc_bc[1]) + (long)(q[db] - inc_bc[2]) * inc_bc[0];
+          const double d0x = data[li], d0y = data[li + dsize], d0z = data[li + 2 * dsize];
+          const double pa = data[li + 3 * dsize], ha = data[li + 4 * dsize];
+          const double gam = pr[GAMMA], gamm1 = gam - 1., gam2 = gam / gamm1, rgp = pr[CVINF] * gamm1;
+          const double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
+          const double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz), s_1 = 1. / sn;
+          double tnx, tny, tnz;
+          if (sn == 0.) { tnx = 1.; tny = 0.; tnz = 0.; } else { tnx = tcx * s_1; tny = tcy * s_1; tnz = tcz * s_1; }
+          const double roi = rop[l1], ui = rop[l1 + nd], vi = rop[l1 + 2 * nd], wi = rop[l1 + 3 * nd], Ti = rop[l1 + 4 * nd];
+          const double pi = roi * rgp * Ti, p0 = pi;
+          const double qen = 0.;
+          const double vni = ui * tnx + vi * tny + wi * tnz;
+          const double roc0 = sqrt(roi * gam * p0);
+          const double usd0n = 1. / (d0x * tnx + d0y * tny + d0z * tnz), usd0n2 = usd0n * usd0n;
+          const double wni = vni - qen, ri = pi + roc0 * wni;
+          double wng = ui * tnx + vi * tny + wi * tnz - qen;
+          double residug = 1.e+20;
+          int nitnwt = 0;
+          while (residug > pr[37] && nitnwt < p[65]) {
+            nitnwt++;
+            residug = 0.;
+            double b = 1. - ((wng + qen) * (wng + qen)) * usd0n2 / (2. * ha);
+            b = dmax(0.2, b);
+            const double pg = pa * pow(b, gam2);
+            const double rog = gam2 * pg / (ha * b);
+            const double fn = pg + roc0 * wng - ri;
+            const double df = roc0 - rog * (wng + qen) * usd0n2;
+            const double dwng = -fn / df;
+            wng = wng + dwng;
+            residug = dmax(residug, fabs(dwng / wng));
+          }
+          const double vng = wng + qen, vg = vng * usd0n;
+          double b = 1. - (vng * vng) * usd0n2 / (2. * ha);
+          b = dmax(0.2, b);
+          const double pg = pa * pow(b, gam2), rog = gam2 * pg / (ha * b), Tg = pg / (rog * rgp);
+          rop[l] = rog; rop[l + nd] = vg * d0x; rop[l + 2 * nd] = vg * d0y; rop[l + 3 * nd] = vg * d0z;
+          rop[l + 4 * nd] = Tg;
+          if (p[NEQ] == 6) rop[l + 5 * nd] = data[li + 5 * dsize];
+        } else if (mode == 2 && data) {
           const int q[3] = {i, j, k};
           const int da = f.d == 0 ? 1 : 0, db = f.d == 2 ? 1 : 2;
           const long li = (q[da] - inc_bc[1]) + (long)(q[db] - inc_bc[2]) * inc_bc[0];
@@ -1404,6 +1448,13 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     else if (type == 1) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
     else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1, 0, 0, 0);
     else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2, 0, 0, 0);
+    else if (type == 17 && p[pt + 8] == p[NEQ]) {   /* BCzone.cpp:594-618: d0x, d0y, d0z, pa, ha [, nu_tilde] */
+      int inc_bc[3];
+      const int save = p[pt + 9];
+      const double *d = fo_bc_data(p, pr, ndf, inc_bc);
+      if (save == 1) return -1;
+      fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 3, d, save, inc_bc);
+    }
     else if (type == 2 && p[pt + 8] == p[NEQ] && p[pt + 9] > 6) {   /* BCzone.cpp:421-448: arrays of more than 6 values */
       int inc_bc[3];
       const int save = p[pt + 9];

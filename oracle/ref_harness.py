@@ -281,6 +281,22 @@ class RefSolver:
                    _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
                    _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state),
                    _p(data), _i(int(p[pt_bc + 9])), _p(inc_bc))
+            elif btype == 17:
+                # Fast/FastS/FastS/BC/BCzone.cpp:594-618: direction, stagnation pressure and enthalpy per face cell
+                nbdata = int(p[pt_bc + 8]); size0 = int(p[pt_bc + 9])
+                if nbdata != int(p[NEQ]):
+                    raise NotImplementedError("ref_harness: BCInj1 with %d data arrays" % nbdata)
+                off = int(p[pt_bcs + 1 + ndf + nb_bc])
+                if idir <= 2: inc_bc = [fen[3] - fen[2] + 1, fen[2], fen[4]]
+                elif idir <= 4: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[4]]
+                else: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[2]]
+                inc_bc = np.array(inc_bc, dtype=np.int32)
+                d = [zn.preal[off + e * size0:] for e in range(6)]
+                L.bvbs_inflow_newton_(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl),
+                                      _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+                                      _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut),
+                                      _p(state), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]),
+                                      _i(size0), _p(inc_bc))
             elif btype == 2 and int(p[pt_bc + 8]) != 0:
                 # Fast/FastS/FastS/BC/BCzone.cpp:417-448: conservative state per face cell, 5 or 6 arrays of one size
                 nbdata = int(p[pt_bc + 8]); size0 = int(p[pt_bc + 9])

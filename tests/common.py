@@ -61,6 +61,11 @@ def window_data(shape, base, amp=0.02):
     return base * (1. + amp * _np.sin(0.7 * _np.arange(n) + 0.3))
 
 
+def numpy_full(n, v):
+    import numpy as _np
+    return _np.full(n, v)
+
+
 def data_bcs(n, model='NSLaminar'):
     """BCOutpres on imax and kmin, isothermal wall on jmin (laminar / turbulent only), with window data."""
     pinf = 1. / (1.4 * 0.1 * 0.1)    # adim2funk at M = 0.1: rho = T = 1
@@ -78,6 +83,15 @@ def data_bcs(n, model='NSLaminar'):
     if neq == 6:
         sup['TurbulentSANuTildeDensity'] = ro * window_data((nf,), 2e-5, 0.3)
     bcs['kmax'] = ('BCInflowSupersonic', sup)
+    # subsonic injection: direction, stagnation pressure and stagnation enthalpy (BCInj1), on jmax
+    ng = ni * nk
+    hinf = 1.4 * cv * 1. + 0.5 * 1.     # cp T + u^2/2 of the reference state (rho = T = u = 1)
+    inj = {'d0x': numpy_full(ng, 0.1), 'd0y': numpy_full(ng, -0.99), 'd0z': window_data((ng,), 0.05, 0.5),
+           'StagnationPressure': window_data((ng,), pinf * 1.01, 0.002),
+           'StagnationEnthalpy': window_data((ng,), hinf, 0.001)}
+    if neq == 6:
+        inj['TurbulentSANuTilde'] = window_data((ng,), 2e-5, 0.3)
+    bcs['jmax'] = ('BCInj1', inj)
     if model != 'Euler':
         bcs['jmin'] = ('BCWallViscousIsothermal', {'Temperature': window_data((ni, nk), 1.05)})
     return bcs
