@@ -345,8 +345,12 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     if (w.type == 22) continue;  // BCOverlap: filled by the join transfer
     // dispatch of Fast/FastS/FastS/BC/BCzone.cpp:262-283,451-461,513-523,578-586
     const int tag = w.type;
+    // DEFAULT_STATE of BCzone.cpp:26-48: a far field / inflow may carry its own uniform conservative state, as one
+    // array of 6 values or as the 21 scalars of a ReferenceState node (state at positions 3..7 and 16)
+    const bool own_state = (tag == 1 || tag == 13 || tag == 2) &&
+                           (p[pt + 8] == 21 || (p[pt + 8] == 1 && pt + 9 < n_int && p[pt + 9] == 6));
     if (tag == 11 || tag == 0 || tag == 1 || tag == 14) w.type = tag;   // 14: BCExtrapolateRANS, nu_tilde only
-    else if ((tag == 13 || tag == 2) && p[pt + 8] == 0) w.type = tag;   // BCInflow / BCInflowSupersonic on the reference state
+    else if ((tag == 13 || tag == 2) && (p[pt + 8] == 0 || own_state)) w.type = tag;   // BCInflow / BCInflowSupersonic on a uniform state
     else if (tag == 2 && p[pt + 8] == p[NEQ] && pt + 9 < n_int && p[pt + 9] > 6) w.type = tag;   // its own state: BCzone.cpp:421-448
     else if (tag == 17 && p[pt + 8] == p[NEQ]) w.type = tag;   // BCInj1: d0x, d0y, d0z, pa, ha [, nu_tilde], BCzone.cpp:594-618
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
@@ -361,7 +365,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     long long data_off = -1;
     w.data = nullptr; w.dlo[0] = w.dlo[1] = 0; w.dn = 1; w.dsize = 0;
     w.nit = p[65]; w.tol = r[37];   // NIT_INFLOW, EPSI_INFLOW
-    if ((tag == 2 && p[pt + 8] != 0) || tag == 17) {
+    if ((tag == 2 && p[pt + 8] != 0 && !own_state) || tag == 17) {
       // NEQ arrays of one size, one value per face cell of the window: rho, rho u, rho v, rho w, rho E [, rho nu_tilde]
       const int nbdata = p[pt + 8], size = p[pt + 9];
       const long long off = p[pt_bcs + 1 + ndf + nb];
@@ -391,7 +395,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       data_off = (long long)zn.bc_data.size();
       zn.bc_data.insert(zn.bc_data.end(), r + off, r + off + size);
       w.dlo[0] = fen[2 * da]; w.dlo[1] = fen[2 * db]; w.dn = na;
-    } else if (p[pt + 8] != 0 && tag != 11)
+    } else if (p[pt + 8] != 0 && tag != 11 && !own_state)
       return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: data on this boundary condition are not implemented");
     if (!bc_window(p, w.idir, p + pt + 2, w)) continue;
     // reference state of BCzone.cpp:26-38 and the face metric along the normal
@@ -399,6 +403,14 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     w.st[4] = r[PINF] / (r[GAMMA] - 1.) + 0.5 * (r[VXINF] * w.st[1] + r[VYINF] * w.st[2] + r[VZINF] * w.st[3]);
     w.tcn = w.idir <= 2 ? mtr[0] : (w.idir <= 4 ? mtr[1] : mtr[2]);
     w.nue = tag == 14 ? r[RONUTILDEINF] : r[RONUTILDEINF] / w.st[0];
+    if (own_state) {
+      const long long off = p[pt_bcs + 1 + ndf + nb];
+      const int nval = p[pt + 8] == 21 ? 21 : 6;
+      if (off < 0 || off + nval > n_real) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC state data overrun Parameter_real");
+      const double *d = r + off;
+      if (nval == 21) { for (int e = 0; e < 5; e++) w.st[e] = d[3 + e]; w.nue = d[16] / w.st[0]; }
+      else { for (int e = 0; e < 5; e++) w.st[e] = d[e]; w.nue = d[5] / w.st[0]; }
+    }
     switch (w.idir) {  // bvbs_periodique.for: incp = IJKV(dir) * stride, towards the interior
       case 1: w.shift = z.iv; break;
       case 2: w.shift = -(long long)z.iv; break;

@@ -1122,10 +1122,15 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
   const double gam1 = pr[GAMMA] - 1., gam1_1 = 1. / gam1, cvinv = 1. / pr[CVINF];
   const double c4 = 5. / 6., c5 = 2. / 6., c6 = -1. / 6.;
   const double c0 = 1. / c6, c1 = -(c4 + c5) * c0, c2 = -c6 * c0, c3 = (2. - c5 - c4) * c0;
-  /* default state of BCzone.cpp:26-38 */
-  double st[5];
+  /* default state of BCzone.cpp:26-38; dsize < 0: the BC carries its own conservative state (6 values, :40-48) */
+  double st[5], ronut = pr[8];
   st[0] = pr[ROINF]; st[1] = pr[VXINF] * pr[ROINF]; st[2] = pr[VYINF] * pr[ROINF]; st[3] = pr[VZINF] * pr[ROINF];
   st[4] = pr[PINF] / (pr[GAMMA] - 1.) + 0.5 * (pr[VXINF] * st[1] + pr[VYINF] * st[2] + pr[VZINF] * st[3]);
+  if (dsize < 0) {
+    for (int e = 0; e < 5; e++) st[e] = data[e];
+    ronut = data[5];
+    data = 0;
+  }
   const double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
   double tc[3];
   /* transverse window */
@@ -1196,7 +1201,7 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
                                  (ro_state * pr[CVINF]);
           rop[l] = ro_state; rop[l + nd] = u_state; rop[l + 2 * nd] = v_state; rop[l + 3 * nd] = w_state;
           rop[l + 4 * nd] = t_state;
-          if (p[NEQ] == 6) rop[l + 5 * nd] = pr[8] / st[0];
+          if (p[NEQ] == 6) rop[l + 5 * nd] = ronut / st[0];
         } else {
           double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
           double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
@@ -1247,7 +1252,7 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
           rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
           rop[l + 4 * nd] = (qvar5 * roinv - .5 * (u * u + v * v + w * w)) * cvinv;
           if (p[NEQ] == 6)   /* BCFarfield_firstrank_SA.for, BCFarfield_init.for: nue = state(6)/state(1) */
-            rop[l + 5 * nd] = (mode == 1 || eigv1 < 0.) ? pr[8] / roe : rop[l1 + 5 * nd];
+            rop[l + 5 * nd] = (mode == 1 || eigv1 < 0.) ? ronut / roe : rop[l1 + 5 * nd];
         }
         for (int r = 2; r <= f.nr; r++) {   /* next ranks, outwards */
           l = l1 - r * inc;
@@ -1268,6 +1273,7 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
 /* Window data of a BC (BCzone.cpp:257, 570-592, INCREMENT_BC.h): the first array stored for the window in
  * Parameter_real, one value per face cell of the BC window, first transverse direction fastest; a leading
  * array of size 1 is the mesh-velocity coefficient and is skipped.  Returns NULL without data. */
+static int nb_of(const i32 *p) { return p[p[PT_BC]]; }
 static const double *fo_bc_data(const i32 *p, const double *pr, int ndf, int *inc_bc)
 {
   const int pt_bcs = p[PT_BC], nb = p[pt_bcs], pt = p[pt_bcs + 1 + ndf], idir = p[pt + 1];
@@ -1445,9 +1451,18 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     else if (type == 22) continue;
     else if (type == 0) fo_bc_extrapolate(p, idir, cl, rop);
     else if (type == 14) fo_bc_extrapolate_nut(p, pr, idir, cl, rop);
-    else if (type == 1) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
+    else if (type == 1 && p[pt + 8] == 0) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
     else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1, 0, 0, 0);
     else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2, 0, 0, 0);
+    else if ((type == 1 || type == 13 || type == 2) && (p[pt + 8] == 21 || (p[pt + 8] == 1 && p[pt + 9] == 6))) {
+      /* the BC's own uniform state: one array of 6 conservative values, or a copy of a ReferenceState node
+       * (21 scalars, the state at positions 3..7 and 16), BCzone.cpp:40-48 */
+      const double *d = pr + p[pt_bcs + 1 + ndf + nb_of(p)];
+      double stt[6];
+      if (p[pt + 8] == 21) { for (int e = 0; e < 5; e++) stt[e] = d[3 + e]; stt[5] = d[16]; }
+      else for (int e = 0; e < 6; e++) stt[e] = d[e];
+      fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, type == 1 ? 0 : (type == 13 ? 1 : 2), stt, -1, 0);
+    }
     else if (type == 17 && p[pt + 8] == p[NEQ]) {   /* BCzone.cpp:594-618: d0x, d0y, d0z, pa, ha [, nu_tilde] */
       int inc_bc[3];
       const int save = p[pt + 9];

@@ -297,7 +297,7 @@ class RefSolver:
                                       _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut),
                                       _p(state), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]),
                                       _i(size0), _p(inc_bc))
-            elif btype == 2 and int(p[pt_bc + 8]) != 0:
+            elif btype == 2 and int(p[pt_bc + 8]) != 0 and int(p[pt_bc + 9]) > 6:
                 # Fast/FastS/FastS/BC/BCzone.cpp:417-448: conservative state per face cell, 5 or 6 arrays of one size
                 nbdata = int(p[pt_bc + 8]); size0 = int(p[pt_bc + 9])
                 if size0 <= 6 or nbdata != int(p[NEQ]):
@@ -315,8 +315,17 @@ class RefSolver:
                                                _i(size0), _p(inc_bc))
             elif btype in (1, 2, 3, 4, 5, 6, 13):
                 # dispatch of Fast/FastS/FastS/BC/BCzone.cpp:279-283,299-310,417-425,451-461,513-523 (these use ind_CL)
-                if int(p[pt_bc + 8]) != 0:
-                    raise NotImplementedError("ref_harness: BC data")
+                st = state
+                nbdata = int(p[pt_bc + 8])
+                if nbdata != 0:     # DEFAULT_STATE, BCzone.cpp:40-48: the BC's own uniform state
+                    dd = zn.preal[int(p[pt_bcs + 1 + ndf + nb_bc]):]
+                    if btype in (1, 2, 13) and nbdata == 21:
+                        st = np.array([dd[3], dd[4], dd[5], dd[6], dd[7], dd[16]])
+                    elif btype in (1, 2, 13) and nbdata == 1 and int(p[pt_bc + 9]) == 6:
+                        st = np.ascontiguousarray(dd[:6])
+                    else:
+                        raise NotImplementedError("ref_harness: BC data")
+                state_save, state = state, st
                 if btype == 1:
                     fn = L.bvbs_farfield_
                 elif btype == 13:
@@ -332,6 +341,7 @@ class RefSolver:
                 fn(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl),
                    _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
                    _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state))
+                state = state_save
             else:
                 raise NotImplementedError("ref_harness: BC tag %d" % btype)
         L.correct_coins_(_i(nd), _p(p), _p(zn.ind_dm), _p(rop))

@@ -95,3 +95,19 @@ def data_bcs(n, model='NSLaminar'):
     if model != 'Euler':
         bcs['jmin'] = ('BCWallViscousIsothermal', {'Temperature': window_data((ni, nk), 1.05)})
     return bcs
+
+
+def own_state_bcs():
+    """Far field, inflow and supersonic inflow that carry their own uniform conservative state (rho, rho u, rho v,
+    rho w, rho E, rho nu_tilde): one array of 6 values, or the 21 scalars of a ReferenceState copy."""
+    import numpy as _np
+    cv = 1. / (1.4 * 0.4 * 1.4 * 0.01)
+    def state(ro, u, v, w, T, nut):
+        return _np.array([ro, ro * u, ro * v, ro * w, ro * (cv * T + 0.5 * (u * u + v * v + w * w)), ro * nut])
+    ref21 = _np.arange(21) * 0.
+    ref21[3:8] = state(0.97, 1.1, -0.05, 0.02, 1.02, 0.)[:5]; ref21[16] = 0.97 * 3e-5
+    return {'imin': ('BCInflow', {'State': state(1.03, 0.9, 0.1, 0., 0.99, 2e-5)}),
+            'imax': ('BCFarfield', {'State': state(0.98, 1.05, 0., 0.05, 1.01, 4e-5)}),
+            'kmax': ('BCInflowSupersonic', {'State': state(1.01, 0.2, 0.1, -1.2, 1., 1e-5)}),
+            'jmax': ('BCFarfield', {'s%02d' % i: _np.array([ref21[i]]) for i in range(21)}),
+            'jmin': 'BCWall'}

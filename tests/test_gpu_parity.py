@@ -52,10 +52,15 @@ BC_CASES = [
 ]
 
 
+BC_CASES += [('NSLaminar', 'senseur', (9, 8, 10), 'own_state'), ('Euler', 'roe', (10, 9, 8), 'own_state')]
+
+
 @pytest.mark.parametrize("model,scheme,n,bcs", BC_CASES)
 def test_boundary_conditions_bit_exact(model, scheme, n, bcs):
     from fast_amd import cases
-    from common import SINGLE
+    from common import SINGLE, own_state_bcs
+    if bcs == 'own_state':     # far field / inflow / supersonic inflow with their own uniform state
+        bcs = own_state_bcs()
     t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, bcs=bcs)
     (t, tc, metrics) = FastS.warmup(t, None)
     z = Internal.getZones(t)[0]

@@ -26,8 +26,14 @@ CASES = [
 ]
 
 
+CASES.append(((10, 9, 8), 'ausmpred', 'own_state', 5))
+
+
 @pytest.mark.parametrize("n,scheme,bcs,nit", CASES)
 def test_sa_matches_oracle(n, scheme, bcs, nit):
+    if bcs == 'own_state':
+        from common import own_state_bcs
+        bcs = own_state_bcs()
     t = cases.tgv(n, scheme, model='NSTurbulent', extra_numz=SINGLE, bcs=bcs)
     (t, tc, metrics) = FastS.warmup(t, None)
     z = Internal.getZones(t)[0]

@@ -57,11 +57,16 @@ FAR = {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')
     ('NSTurbulent', 'senseur', {'imin': 'BCInflow', 'imax': 'BCExtrapolate', 'jmax': 'BCInflowSupersonic'}),
     ('NSTurbulent', 'ausmpred', {'imin': 'BCExtrapolateRANS', 'kmax': 'BCExtrapolateRANS', 'jmin': 'BCWall'}),
     ('NSLaminar', 'ausmpred', {'imax': 'BCExtrapolateRANS'}),      # 5 equations: the routine changes nothing
+    ('NSLaminar', 'senseur', 'own_state'),
+    ('NSTurbulent', 'ausmpred', 'own_state'),
 ])
 def test_boundary_conditions_bit_exact(model, scheme, bcs):
     """Ghost fill of walls, far field and extrapolation against bvbs_wall_viscous_adia /
     bvbs_wall_inviscid / bvbs_farfield / bvbs_extrapolate of the compiled reference."""
     extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    if bcs == 'own_state':
+        from common import own_state_bcs
+        bcs = own_state_bcs()
     t = cases.tgv((9, 8, 7), scheme, model=model, extra_numz=extra, bcs=bcs)
     so, sr = _pair(t)
     so.fill_ghostcells(); sr.fill_ghostcells('ro')
