@@ -66,7 +66,7 @@ def numpy_full(n, v):
     return _np.full(n, v)
 
 
-def data_bcs(n, model='NSLaminar'):
+def data_bcs(n, model='NSLaminar', inj=True):
     """BCOutpres on imax and kmin, isothermal wall on jmin (laminar / turbulent only), with window data."""
     pinf = 1. / (1.4 * 0.1 * 0.1)    # adim2funk at M = 0.1: rho = T = 1
     ni, nj, nk = n
@@ -74,6 +74,7 @@ def data_bcs(n, model='NSLaminar'):
            'kmin': ('BCOutpres', {'Pressure': window_data((ni, nj), pinf, 0.01)}),
            'imin': 'BCFarfield'}
     neq = 6 if model == 'NSTurbulent' else 5
+    with_inj = inj
     # supersonic inflow with its own conservative state (rho, rho u, rho v, rho w, rho E [, rho nu_tilde])
     nf = ni * nj
     ro = window_data((nf,), 1.02); u = window_data((nf,), 0.11, 0.1)
@@ -91,7 +92,8 @@ def data_bcs(n, model='NSLaminar'):
            'StagnationEnthalpy': window_data((ng,), hinf, 0.001)}
     if neq == 6:
         inj['TurbulentSANuTilde'] = window_data((ng,), 2e-5, 0.3)
-    bcs['jmax'] = ('BCInj1', inj)
+    if with_inj:
+        bcs['jmax'] = ('BCInj1', inj)
     if model != 'Euler':
         bcs['jmin'] = ('BCWallViscousIsothermal', {'Temperature': window_data((ni, nk), 1.05)})
     return bcs

@@ -69,7 +69,7 @@ CASES = {
     'naca0012_sa_implicit':     ('naca', (16, 6, 10), 'ausmpred', 'NSTurbulent', (1, 1, 1), 'single', 20),
     # BCs that read window data from Parameter_real: two pressure outlets, one isothermal wall, one far field
     'outlet_isowall_curv':      ('tgv', (10, 9, 8), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 10,
-                                 data_bcs((10, 9, 8)), {'perturb': 0.15}),
+                                 data_bcs((10, 9, 8), inj=False), {'perturb': 0.15}),
     # explicit scheme with a local time step (roe + walls); walls with flat ghost cells behind them and a RANS/LES
     # extrapolation of nu_tilde, implicit
     'explicit_local_roe_curv':  ('tgv', (10, 9, 8), 'roe', 'NSLaminar', (1, 1, 1), 'single', 10,
