@@ -241,3 +241,11 @@ def display_temporal_criteria(t, metrics, nitrun, format=None, gmres=None, verbo
         if stopAtNan and not numpy.all(numpy.isfinite(l2)):
             raise FloatingPointError("NaN in the residual of zone %s at iteration %d" % (z[0], nitrun))
     return out
+
+
+def displayTemporalCriteria(t, metrics, nitrun, format=None, gmres=None, verbose='firstlast', stopAtNan=True):
+    """Alias kept by the reference (Fast/FastS/FastS/PyTree.py:2022-2028)."""
+    return display_temporal_criteria(t, metrics, nitrun, format, gmres, verbose, stopAtNan)
+
+
+_displayTemporalCriteria = displayTemporalCriteria
