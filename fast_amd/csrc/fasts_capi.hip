@@ -40,6 +40,7 @@ struct Zone {
   int lu[6] = {0, 0, 0, 0, 0, 0};
   double *res_part = nullptr, *res_out = nullptr;   // res_out: 10 residual norms, then the CFL triple
   bool have_cfl = false;
+  hipEvent_t ev_lu_fork = nullptr, ev_lu_join = nullptr;
   FsBcWin *bc_dev = nullptr;
   std::vector<double> bc_data;          // window data of the BCs that carry their own, concatenated
   std::vector<long long> bc_data_off;   // per entry of bc: offset in bc_data, -1 without data
@@ -81,6 +82,10 @@ struct fs_ctx {
   bool plain_stage = false;   // FASTS_HIP_STAGE=plain: untiled stage kernel (debugging aid)
   bool dma_stage = true;      // default: LDS-DMA staged kernel; FASTS_HIP_STAGE=tile64 selects the register-staged one
   int modulo_verif = 200;
+  // LU-SGS sweeps of different zones are independent and latency-bound (one small launch per hyperplane): they run
+  // on a few streams of their own, forked from and joined back into the context's stream by events
+  std::vector<hipStream_t> lu_streams;
+  int lu_nstreams = -1;    // -1: not decided yet (FASTS_HIP_LU_STREAMS, default 4; 0 or 1 = everything on one stream)
   bool implicit = false;      // ITYPCP 1: BDF + LU-SGS Newton sub-iterations (all zones of a context agree)
   int first_it = 0;           // FIRST_IT of the reference: 0 until one time step is complete (BDF1, xid = 1)
   std::string err;
@@ -162,7 +167,10 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
+    if (zn.ev_lu_fork) (void)hipEventDestroy(zn.ev_lu_fork);
+    if (zn.ev_lu_join) (void)hipEventDestroy(zn.ev_lu_join);
   }
+  for (hipStream_t st : ctx->lu_streams) (void)hipStreamDestroy(st);
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
   for (auto &s : ctx->sends) (void)hipFree(s.pts_dev);
   for (auto &p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -727,6 +735,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
   if (rc) return rc;
   if (part >= 0 && !(ctx->dma_stage && !ctx->plain_stage))
     return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": split stages need the default stage kernel");
+  std::vector<hipEvent_t> lu_joins;
+  int n_lu = 0;
   for (auto &zn : ctx->zones) {
     const FsZone &z = zn.z;
     if (nstep < 1 || nstep > z.nssiter) return fail(ctx, FS_ERR_ARG, std::string(who) + ": sub-iteration out of range");
@@ -838,10 +848,40 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
         fsk_bc_windows(z, (int)zn.rhs_bc.size(), zn.rhs_bc_dev, bc_kinds(zn.rhs_bc), zn.rhs_max_cells, zn.drodm, ctx->stream);
         fsk_bc_edges(z, zn.drodm, ctx->stream);
       }
-      if (fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ctx->stream))
+      hipStream_t ls = ctx->stream;
+      if (ctx->lu_nstreams < 0) {
+        const char *ev = getenv("FASTS_HIP_LU_STREAMS");
+        ctx->lu_nstreams = ev ? atoi(ev) : 4;
+        if (ctx->lu_nstreams > 8) ctx->lu_nstreams = 8;
+        if (ctx->lu_nstreams < 2 || ctx->zones.size() < 2) ctx->lu_nstreams = 0;
+        for (int q = 0; q < ctx->lu_nstreams; q++) {
+          hipStream_t st;
+          HIPCHK(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+          ctx->lu_streams.push_back(st);
+        }
+      }
+      if (ctx->lu_nstreams > 0) {
+        if (!zn.ev_lu_fork) {
+          HIPCHK(ctx, hipEventCreateWithFlags(&zn.ev_lu_fork, hipEventDisableTiming));
+          HIPCHK(ctx, hipEventCreateWithFlags(&zn.ev_lu_join, hipEventDisableTiming));
+        }
+        ls = ctx->lu_streams[n_lu % ctx->lu_nstreams];
+        HIPCHK(ctx, hipEventRecord(zn.ev_lu_fork, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ls, zn.ev_lu_fork, 0));
+      }
+      const int lrc = fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
+      if (ctx->lu_nstreams > 0) {
+        HIPCHK(ctx, hipEventRecord(zn.ev_lu_join, ls));
+        lu_joins.push_back(zn.ev_lu_join);
+        n_lu++;
+      }
+      if (lrc) {
+        for (hipEvent_t e : lu_joins) (void)hipStreamWaitEvent(ctx->stream, e, 0);
         return fail(ctx, FS_ERR_STATE, std::string(who) + ": LU-SGS scratch level missing");
+      }
     }
   }
+  for (hipEvent_t e : lu_joins) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, e, 0));
   HIPCHK(ctx, hipGetLastError());
   return FS_OK;
 }
