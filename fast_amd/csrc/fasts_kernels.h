@@ -40,7 +40,7 @@ int fsk_stage_tiled(const FsZone &z, double coefH, double coefW, int first, cons
 // same contract, planes staged by LDS-DMA (fasts_stage_dma.hip).  The zone is cut in nti x ntj x ntk
 // tiles of ti x tj x kchunk cells, numbered bi + nti*(bj + ntj*bk); blist (device, nlist entries)
 // restricts a launch to a subset of the tiles, NULL launches all of them.
-struct FsTiling { int nti, ntj, ntk, kchunk, ti, tj; };
+struct FsTiling { int nti, ntj, ntk, kchunk, ti, tj, pace; };
 FsTiling fsk_stage_dma_tiling(const FsZone &z);
 // bdf != NULL: the kernel writes the Newton residual of the implicit scheme to drodm instead of the
 // Runge-Kutta update (rop_out unused, coefH / coefW ignored)

@@ -22,24 +22,26 @@ ctx = FastC.HOOK['ctx']
 for it in range(1, 4):
     ctx.compute(it, 1, 3, 1)
 ctx.sync()
-buf = np.zeros(4 * 40 * 8, dtype=np.int64)
+NW = 12
+buf = np.zeros(NW * 40 * 8, dtype=np.int64)
 rc = _capi.lib().fs_stamp_fetch(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
-s = buf.reshape(4, 40, 8)
-names = ['requests', 'own column', 'k-face', 'finish cell', 'i/j faces (+edge)', 'barrier 1', 'partial+shift', 'barrier 2']
-print("last launch = stage 3; cycles per phase, iterations 2..30 averaged, per wave")
-for w in range(4):
+s = buf.reshape(NW, 40, 8)
+print("last launch = stage 3; shader cycles per phase, steps 2..30 averaged, per wave of workgroup 0")
+for w in range(NW):
     d = []
     for it in range(2, 30):
         row = s[w, it]
         nxt = s[w, it + 1, 0]
-        ph = [row[1] - row[0], row[2] - row[1], row[3] - row[2], row[4] - row[3], row[5] - row[4],
-              row[6] - row[5], row[7] - row[6], nxt - row[7]]
+        if w < 8:
+            ph = [row[1] - row[0], row[2] - row[1], row[3] - row[2], row[4] - row[3], row[5] - row[4],
+                  row[6] - row[5], row[7] - row[6], nxt - row[7]]
+        else:
+            ph = [row[1] - row[0], 0, 0, 0, row[5] - row[1], row[6] - row[5], row[7] - row[6], nxt - row[7]]
         d.append(ph)
-    d = np.array(d, dtype=float)
-    m = d.mean(axis=0)
-    print("wave %d: total %7.0f | " % (w, m.sum()) +
-          " | ".join("%s %6.0f" % (n, v) for n, v in zip(
-              ['req', 'own+kface', 'finish', 'ijfaces', 'bar1', 'partial', 'bar2', 'loop'], m)))
+    m = np.array(d, dtype=float).mean(axis=0)
+    names = ['top', 'own+kface', 'finish+req', 'jface', 'iface', 'bar1', 'combine', 'bar2'] if w < 8 else \
+            ['staging', '-', '-', '-', 'edge face', 'bar1', '-', 'bar2']
+    print("wave %2d: total %7.0f | " % (w, m.sum()) + " | ".join("%s %6.0f" % (n, v) for n, v in zip(names, m)))
 w0 = s[0, 2:30]
-print("iteration period (wave 0):", np.diff(w0[:, 0]).mean())
+print("step period (wave 0):", np.diff(w0[:, 0]).mean())
