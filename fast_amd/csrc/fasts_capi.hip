@@ -79,8 +79,6 @@ struct fs_ctx {
   std::vector<Join> joins;
   std::vector<Send> sends;
   bool uploaded = false;
-  bool plain_stage = false;   // FASTS_HIP_STAGE=plain: untiled stage kernel (debugging aid)
-  bool dma_stage = true;      // default: LDS-DMA staged kernel; FASTS_HIP_STAGE=tile64 selects the register-staged one
   int modulo_verif = 200;
   // LU-SGS sweeps of different zones are independent and latency-bound (one small launch per hyperplane): they run
   // on a few streams of their own, forked from and joined back into the context's stream by events
@@ -148,9 +146,6 @@ extern "C" int fs_create(fs_ctx **out, int device)
     return FS_ERR_HIP;
   }
   c->stream = c->own_stream;
-  const char *ev = getenv("FASTS_HIP_STAGE");
-  c->plain_stage = ev && strcmp(ev, "plain") == 0;
-  c->dma_stage = !(ev && strcmp(ev, "tile64") == 0);
   *out = c;
   return FS_OK;
 }
@@ -253,11 +248,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: explicit and implicit zones cannot share a context");
   if (implicit && (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[IMPLICITSOLVER] != 0))
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme is LU-SGS with nb_relax = 1 and lu_match = 0 (no SSOR relaxation, no overlap, no GMRES)");
-  if (implicit && !(ctx->dma_stage && !ctx->plain_stage))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme needs the default stage kernel");
   const bool sa = p[IFLOW] == 3 && p[NEQ] == 6;
   if (!sa && (p[NEQ] != 5 || p[IFLOW] > 2)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: governing equations must be Euler, NSLaminar or NSTurbulent (Spalart-Allmaras)");
-  if (twod && ctx->plain_stage) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: two-dimensional zones need the default stage kernels");
   if (sa && (p[47] > 1 || p[SA_DIST] != 1))
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented as plain SA (no DES variant), "
                 "with a TurbulentDistance field");
@@ -266,8 +258,6 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
   if (p[DTLOC] != 0 && p[DTLOC] != 1)
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: DTLOC must be 0 or 1");
-  if (p[DTLOC] == 1 && !implicit && (ctx->plain_stage || !ctx->dma_stage))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: a local time step with the explicit scheme needs the default stage kernels");
   if (!implicit && (p[RK] < 1 || p[RK] > 3 || p[NSSITER] != p[RK])) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Runge-Kutta order must be 1..3");
   if (implicit && p[NSSITER] < 2) return fail(ctx, FS_ERR_ARG, "fs_zone_add: an implicit step needs at least one Newton sub-iteration (NSSITER >= 2)");
   if (p[NIJK + 3] != 2 || p[NIJK + 4] != (twod ? 0 : 2))
@@ -438,8 +428,6 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       zn.roe_walls.push_back(rw);
     }
   }
-  if (!zn.roe_walls.empty() && (ctx->plain_stage || !ctx->dma_stage))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: roe with wall boundaries needs the default stage kernels");
   if (implicit) {
     // BCzone with lrhs = 1 (Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,262-264): faces that carry a wall
     // BC (tags 3..7) get the ghost residual zeroed over the whole face (extrapolation with c1 = 0), then their BCs
@@ -581,8 +569,9 @@ extern "C" int fs_upload(fs_ctx *ctx)
       HIPCHK(ctx, hipMalloc(&zn.xmut, sizeof(double) * (size_t)zn.z.nd));
       HIPCHK(ctx, hipMemsetAsync(zn.xmut, 0, sizeof(double) * (size_t)zn.z.nd, ctx->stream));
       if (zn.z.kflu == 2) {
-        // face sensors: 0/1 values, one byte each in the tiled kernel, doubles in the plain one
-        const size_t nw = (ctx->plain_stage && zn.z.ityp != 0 ? sizeof(double) : 1) * 3 * (size_t)zn.z.nd;
+        // face sensors: 0/1 values, one byte per cell and direction (curvilinear and SA kernels) or one byte per
+        // cell holding the three of them (Cartesian kernel)
+        const size_t nw = 3 * (size_t)zn.z.nd;
         HIPCHK(ctx, hipMalloc(&zn.wig, nw));
         HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, nw, ctx->stream));
       }
@@ -627,7 +616,7 @@ extern "C" int fs_upload(fs_ctx *ctx)
       HIPCHK(ctx, hipMemcpyAsync(zn.dev[r], zn.host[r], nb, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (!ctx->uploaded && ctx->dma_stage && !ctx->plain_stage) {
+  if (!ctx->uploaded) {
     int rc = build_shell_lists(ctx);
     if (rc) return rc;
   }
@@ -733,8 +722,6 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
 {
   int rc = ensure_ready(ctx, who);
   if (rc) return rc;
-  if (part >= 0 && !(ctx->dma_stage && !ctx->plain_stage))
-    return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": split stages need the default stage kernel");
   std::vector<hipEvent_t> lu_joins;
   int n_lu = 0;
   for (auto &zn : ctx->zones) {
@@ -774,7 +761,6 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
           else fsk_sa_coe6(z, zn.dev[in], zn.dist, zn.coe, ctx->stream);
         }
       }
-      if (z.kflu == 2 && ctx->plain_stage && z.ityp != 0) fsk_wiggle(z, zn.dev[in], zn.wig, ctx->stream);
     }
     if (ctx->timing && opens) {
       if (!zn.ev_part) HIPCHK(ctx, hipEventCreate(&zn.ev_part));
@@ -794,11 +780,6 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     else if (z.ityp == 0)
       krc = fsk_stage_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
                            (unsigned char *)zn.wig, kbdf, zn.dist, ctx->stream);
-    else if (ctx->plain_stage)
-      krc = fsk_stage(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut, zn.wig, ctx->stream);
-    else if (!ctx->dma_stage)
-      krc = fsk_stage_tiled(z, coefH, coefW, nstep == 1, zn.dev[in], zn.dev[out], zn.drodm, zn.xmut,
-                            (unsigned char *)zn.wig, ctx->stream);
     else {
       const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
       const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
@@ -1134,17 +1115,11 @@ extern "C" int fs_debug_fetch(fs_ctx *ctx, int zone, int which, double *host, in
   if (rc) return rc;
   if (zone < 0 || zone >= (int)ctx->zones.size() || !host) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: bad argument");
   Zone &zn = ctx->zones[zone];
-  const double *src = which == 0 ? zn.drodm : (which == 1 ? zn.wig : zn.xmut);
-  long long n = which == 0 ? (long long)zn.z.neq * zn.z.nd : (which == 1 ? 3 * zn.z.nd : zn.z.nd);
+  if (which != 0 && which != 2) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: which must be 0 (drodm) or 2 (xmut)");
+  const double *src = which == 0 ? zn.drodm : zn.xmut;
+  long long n = which == 0 ? (long long)zn.z.neq * zn.z.nd : zn.z.nd;
   if (!src) return fail(ctx, FS_ERR_STATE, "fs_debug_fetch: array not allocated for this scheme");
   if (n_doubles != n) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: size mismatch");
-  if (which == 1 && (!ctx->plain_stage || zn.z.ityp == 0)) {  // byte sensors: widen on the host
-    std::vector<unsigned char> b((size_t)n);
-    HIPCHK(ctx, hipMemcpyAsync(b.data(), src, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (long long i = 0; i < n; i++) host[i] = (double)b[(size_t)i];
-    return FS_OK;
-  }
   HIPCHK(ctx, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FS_OK;

@@ -31,13 +31,8 @@ struct FsBcWin {
 // depth = ghost layers covered besides the interior: 1 for the explicit scheme (navier_stokes_struct.for:223,
 // range ind_grad), the whole ghost depth for the implicit one (:219, range ind_coe)
 void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s);
-void fsk_wiggle(const FsZone &z, const double *rop, double *wig, hipStream_t s);
-int fsk_stage(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-              double *drodm, const double *xmut, const double *wig, hipStream_t s);
-// tiled stage kernel (fasts_stage.hip); at the first stage it also evaluates and stores the sensor
-int fsk_stage_tiled(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                    double *drodm, const double *xmut, unsigned char *wig, hipStream_t s);
-// same contract, planes staged by LDS-DMA (fasts_stage_dma.hip).  The zone is cut in nti x ntj x ntk
+// stage kernel of Cartesian zones, planes staged by LDS-DMA (fasts_stage_dma.hip): flux balance + Runge-Kutta update
+// (or Newton residual); at the first stage it also evaluates and stores the sensor.  The zone is cut in nti x ntj x ntk
 // tiles of ti x tj x kchunk cells, numbered bi + nti*(bj + ntj*bk); blist (device, nlist entries)
 // restricts a launch to a subset of the tiles, NULL launches all of them.
 struct FsTiling { int nti, ntj, ntk, kchunk, ti, tj, pace; };

@@ -1,5 +1,5 @@
-// HIP kernels of the FastS explicit time step around the stage kernels (viscosity, ghost fill, joins,
-// residual norms) and the untiled stage kernel of Cartesian zones, gfx950 (MI355X).
+// HIP kernels of the FastS time step around the stage kernels (viscosity, ghost fill, joins, residual norms,
+// CFL diagnostic), gfx950 (MI355X).
 // Built with -ffp-contract=off (see fasts_flux.h for why results must be bit-reproducible).
 #include "fasts_kernels.h"
 #include "fasts_flux.h"
@@ -13,37 +13,9 @@ FS_DEV long long fs_inddm(const FsZone &z, int i, int j, int k)
   return (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
 }
 
-template <int DIR> FS_DEV long long fs_inc(const FsZone &z) { return DIR == 0 ? 1 : (DIR == 1 ? z.incj : z.inck); }
-
-// flux through the face between cell lc - inc(DIR) and cell lc, global-memory operands
-template <int KFLU, int IFLOW, int DIR>
-FS_DEV void face_flux_g(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
-                        const double *__restrict__ wig, long long lc, double *flu)
-{
-  const long long inc = fs_inc<DIR>(z), nd = z.nd;
-  double qm2[5], qm1[5], q0[5], qp1[5];
-#pragma unroll
-  for (int e = 0; e < 5; e++) {
-    const double *q = rop + e * nd + lc;
-    qm2[e] = q[-2 * inc]; qm1[e] = q[-inc]; q0[e] = q[0]; qp1[e] = q[inc];
-  }
-  double wg = 0.;
-  if (KFLU == 2) wg = wig[DIR * nd + lc];
-  fs_flux_inviscid<KFLU, DIR>(z, qm2, qm1, q0, qp1, wg, flu);
-  if (IFLOW == 2) {
-    const long long ia = DIR == 0 ? z.incj : 1;
-    const long long ib = DIR == 2 ? z.incj : z.inck;
-    auto q = [&](int e, int da, int db, int dn) -> double {
-      return rop[e * nd + lc + dn * inc + da * ia + db * ib];
-    };
-    fs_flux_viscous<DIR>(z, q, xmut[lc - inc], xmut[lc], flu);
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// stage-1 auxiliaries: laminar viscosity on interior + first ghost layer
-// (navier_stokes_struct.for:213-225 with ind_grad), sensor on all faces 1..N+1
-// (src_term.for:258-272, SENSOR/wiggle2001.for)
+// stage-1 auxiliary: laminar viscosity on interior + first ghost layer
+// (navier_stokes_struct.for:213-225 with ind_grad)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_invist(FsZone z, int depth, const double *__restrict__ rop,
                                                 double *__restrict__ xmut)
@@ -54,76 +26,6 @@ __global__ void __launch_bounds__(256) k_invist(FsZone z, int depth, const doubl
   if (i > z.iv + depth) return;
   long long l = fs_inddm(z, i, j, k);
   xmut[l] = fs_sutherland(z, rop[4 * z.nd + l]);
-}
-
-__global__ void __launch_bounds__(256) k_wiggle(FsZone z, const double *__restrict__ rop, double *__restrict__ wig)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;  // 1 .. iv+1
-  const int j = blockIdx.y + 1;                             // 1 .. jv+1
-  const int k = blockIdx.z + 1;                             // 1 .. kv+1
-  if (i > z.iv + 1) return;
-  const long long l = fs_inddm(z, i, j, k), nd = z.nd;
-  const bool in_i = i <= z.iv, in_j = j <= z.jv, in_k = k <= z.kv;
-  if (in_j && in_k) {
-    auto q = [&](int e, int o) -> double { return rop[e * nd + l + o]; };
-    wig[l] = fs_wiggle(q);
-  }
-  if (in_i && in_k) {
-    const long long inc = z.incj;
-    auto q = [&](int e, int o) -> double { return rop[e * nd + l + o * inc]; };
-    wig[nd + l] = fs_wiggle(q);
-  }
-  if (in_i && in_j) {
-    const long long inc = z.inck;
-    auto q = [&](int e, int o) -> double { return rop[e * nd + l + o * inc]; };
-    wig[2 * nd + l] = fs_wiggle(q);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// one Runge-Kutta stage: balance of the six face fluxes of a cell + update.
-// Accumulation order per cell = the order in which the reference's scatter loops reach it
-// with one cache block: +Fk-, +Fj-, +Fi-, -Fi+, -Fj+, -Fk+
-// (template_FluxAndBalance.for:192-271, assemble_drodm_plus_vec1.for).
-// ------------------------------------------------------------------------------------------
-template <int KFLU, int IFLOW>
-__global__ void __launch_bounds__(256) k_stage_ref(FsZone z, double coefH, double coefW, int first,
-                                                   const double *__restrict__ rop, double *__restrict__ rop_out,
-                                                   double *__restrict__ drodm, const double *__restrict__ xmut,
-                                                   const double *__restrict__ wig)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
-  const int j = blockIdx.y + 1;
-  const int k = blockIdx.z + 1;
-  if (i > z.iv) return;
-  const long long l = fs_inddm(z, i, j, k), nd = z.nd;
-  double d[5], f[5];
-#pragma unroll
-  for (int e = 0; e < 5; e++) d[e] = first ? 0. : drodm[e * nd + l] * coefH;
-  face_flux_g<KFLU, IFLOW, 2>(z, rop, xmut, wig, l, f);
-#pragma unroll
-  for (int e = 0; e < 5; e++) d[e] = d[e] + f[e];
-  face_flux_g<KFLU, IFLOW, 1>(z, rop, xmut, wig, l, f);
-#pragma unroll
-  for (int e = 0; e < 5; e++) d[e] = d[e] + f[e];
-  face_flux_g<KFLU, IFLOW, 0>(z, rop, xmut, wig, l, f);
-#pragma unroll
-  for (int e = 0; e < 5; e++) d[e] = d[e] + f[e];
-  face_flux_g<KFLU, IFLOW, 0>(z, rop, xmut, wig, l + 1, f);
-#pragma unroll
-  for (int e = 0; e < 5; e++) d[e] = d[e] - f[e];
-  face_flux_g<KFLU, IFLOW, 1>(z, rop, xmut, wig, l + z.incj, f);
-#pragma unroll
-  for (int e = 0; e < 5; e++) d[e] = d[e] - f[e];
-  face_flux_g<KFLU, IFLOW, 2>(z, rop, xmut, wig, l + z.inck, f);
-#pragma unroll
-  for (int e = 0; e < 5; e++) d[e] = d[e] - f[e];
-  double q[5], o[5];
-#pragma unroll
-  for (int e = 0; e < 5; e++) { q[e] = rop[e * nd + l]; drodm[e * nd + l] = d[e]; }
-  fs_rk_update(z, coefW, q, d, o);
-#pragma unroll
-  for (int e = 0; e < 5; e++) rop_out[e * nd + l] = o[e];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -676,35 +578,6 @@ void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hip
 {
   dim3 g(cdiv(z.iv + 2 * depth, 256), z.jv + 2 * depth, z.kv + 2 * (depth < z.ifick ? depth : z.ifick));
   hipLaunchKernelGGL(k_invist, g, dim3(256), 0, s, z, depth, rop, xmut);
-}
-
-void fsk_wiggle(const FsZone &z, const double *rop, double *wig, hipStream_t s)
-{
-  dim3 g(cdiv(z.iv + 1, 256), z.jv + 1, z.kv + 1);
-  hipLaunchKernelGGL(k_wiggle, g, dim3(256), 0, s, z, rop, wig);
-}
-
-template <int KFLU, int IFLOW>
-static void launch_stage_ref(const FsZone &z, double coefH, double coefW, int first, const double *rop,
-                             double *rop_out, double *drodm, const double *xmut, const double *wig, hipStream_t s)
-{
-  int bx = z.iv >= 256 ? 256 : (z.iv >= 128 ? 128 : 64);
-  dim3 g(cdiv(z.iv, bx), z.jv, z.kv);
-  hipLaunchKernelGGL((k_stage_ref<KFLU, IFLOW>), g, dim3(bx), 0, s, z, coefH, coefW, first, rop, rop_out, drodm,
-                     xmut, wig);
-}
-
-int fsk_stage(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-              double *drodm, const double *xmut, const double *wig, hipStream_t s)
-{
-#define FS_CASE(K, F)                                                                         \
-  if (z.kflu == K && z.iflow == F) {                                                          \
-    launch_stage_ref<K, F>(z, coefH, coefW, first, rop, rop_out, drodm, xmut, wig, s);        \
-    return 0;                                                                                 \
-  }
-  FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)
-#undef FS_CASE
-  return -1;
 }
 
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, int kinds, long long max_cells, double *rop,

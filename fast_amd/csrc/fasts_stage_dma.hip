@@ -279,7 +279,6 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
     double part[5] = {0., 0., 0., 0., 0.};   // +Fk- +Fj- +Fi- -Fi+ -Fj+ of cell k-1 (and xi*drodm)
     __syncthreads();
 
-#pragma unroll 2
     for (int k = k0; k <= k1 + 1; k++) {
       const bool last = k > k1;          // finishing step: only the k-face k1+1/2 and cell k1
       const int cur = k & 1;

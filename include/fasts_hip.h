@@ -188,7 +188,7 @@ int fs_sync(fs_ctx *ctx);
 int fs_stage_kernel_ms(fs_ctx *ctx, int reset, double *avg_ms, int *n_launch);
 
 /* Copy one raw device work array of a zone to the host (tests / diagnostics):
- * which = 0 drodm (neq*ndimdx), 1 wig (3*ndimdx), 2 xmut (ndimdx). */
+ * which = 0 drodm (neq*ndimdx), 2 xmut (ndimdx). */
 int fs_debug_fetch(fs_ctx *ctx, int zone, int which, double *host, int n_doubles);
 
 #ifdef __cplusplus
