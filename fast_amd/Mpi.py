@@ -189,6 +189,7 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     zones, metrics, dtloc = FastS._warmup_host(t, tc, Padding)
     torch.cuda.set_device(device)
     ctx, names = FastS._new_context(zones, metrics, dtloc, device)
+    ctx.set_first_it(FastC.FIRST_IT)
     # kernels and RCCL messages are ordered on ONE explicit (non-default) torch stream: the library
     # launches on it (fs_set_stream) and the messages are posted while it is torch's current stream,
     # so RCCL's event hand-shake orders them after the pack kernels and before the unpack kernels

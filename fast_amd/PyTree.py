@@ -18,7 +18,7 @@ from . import _capi
 from .FastC import Internal
 
 __all__ = ['warmup', '_compute', '_applyBC', '_fillGhostcells', 'allocate_metric', '_init_metric',
-           'display_temporal_criteria', 'sync_to_host', 'sync_to_device']
+           'display_temporal_criteria', '_createConvergenceHistory', 'sync_to_host', 'sync_to_device']
 
 
 def _lazy():
@@ -124,6 +124,7 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
         raise ValueError("fast_amd.warmup: ALE, adjoint and running statistics are not supported")
     zones, metrics, dtloc = _warmup_host(t, tc, Padding)
     ctx, names = _new_context(zones, metrics, dtloc, device)
+    ctx.set_first_it(FastC.FIRST_IT)     # 1 when the tree carries stored _M1 levels (restart): BDF2 from the first step
     for (rn, dn, rpts, dpts) in joins_from_tc(t, tc):
         if rn not in names or dn not in names:
             raise ValueError("warmup: join %s <- %s refers to a zone that is not in t "
@@ -154,9 +155,9 @@ def _compute(t, metrics, nitrun, tc=None, graph=None, tc2=None, graph2=None, lay
         # (Fast/FastS/FastS/PyTree.py:119-209); the last slot of an implicit step is the
         # verification pass, skipped like there (:123)
         for nstep in range(1, nitmax + 1):
+            ctx.stage(nitrun, nstep)      # the last slot of an implicit step only evaluates residual norms, on verification steps
             if implicit and nstep == nitmax:
                 continue
-            ctx.stage(nitrun, nstep)
             ctx.local_joins(nstep)
             ctx.bcs(nstep)
         if implicit or nitmax % 2 == 1:
@@ -215,30 +216,105 @@ def _fillGhostcells(zones, tc, metrics, timelevel_target, vars, nstep, omp_mode,
     return None
 
 
+def _createConvergenceHistory(t, nrecs):
+    """Create the nodes that store the zonal convergence histories (Fast/FastS/FastS/PyTree.py:2143-2181):
+    per zone a ZoneConvergenceHistory node (value = number of records held) with IterationNumber(nrecs) and
+    RSD_L2, RSD_oo, RSD_L2_diff, RSD_oo_diff (nrecs * neq each)."""
+    for z in Internal.getZones(t):
+        o = Internal.getNodeFromName1(z, '.Solver#ownData')
+        neq = 5
+        if o is not None and Internal.getNodeFromName1(o, 'Parameter_int') is not None:
+            neq = int(Internal.getNodeFromName1(o, 'Parameter_int')[1][36])
+        else:
+            m = Internal.getNodeFromName2(t, 'GoverningEquations')
+            if m is not None and Internal.getValue(m) in ('NSTurbulent', 'nsspalart'):
+                neq = 6
+        zch = Internal.createUniqueChild(z, 'ZoneConvergenceHistory', 'ConvergenceHistory_t',
+                                         value=numpy.zeros(1, dtype=numpy.int32))
+        Internal.createUniqueChild(zch, 'IterationNumber', 'DataArray_t', numpy.zeros(nrecs, dtype=numpy.int32))
+        for var in ('RSD_L2', 'RSD_L2_diff', 'RSD_oo', 'RSD_oo_diff'):
+            Internal.createUniqueChild(zch, var, 'DataArray_t', numpy.zeros(nrecs * neq, dtype=numpy.float64))
+    return None
+
+
+def _log10_floor(v):
+    # dpssiter.for:25,70-79: LOG10(max(rdm, cut0x)) with cut0x = 1e-30
+    return numpy.log10(numpy.maximum(v, 1.e-30))
+
+
 def display_temporal_criteria(t, metrics, nitrun, format=None, gmres=None, verbose='firstlast',
                               stopAtNan=True):
-    """Residual norms of the last verification iteration.  Returns {zone: (L2[5], Loo[5])}.
-    The reference prints these only for implicit zones
-    (Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:107); for the explicit scheme the same
-    norm is applied to the first-stage increment."""
+    """CFL and convergence information of the last verification step (Fast/FastS/FastS/PyTree.py:2030-2066 ->
+    Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp, dpssiter.for, conv2pytree.for).
+
+    Implicit zones (and explicit ones with a local time step in the reference): the L2 / Loo norms of the Newton
+    residual of every sub-iteration are printed as the reference prints them (log10; first sub-iteration, then the
+    drop between the first and the last, every sub-iteration when verbose != 'firstlast' or when the residual grew)
+    and, when the zone carries a ZoneConvergenceHistory node, recorded there.  Explicit zones: the same norm of the
+    first-stage increment (the reference tabulates nothing for them).
+
+    format: None / 'single' (short table), 'double' (long table), 'store' (tree only), 'none' (silent).
+    Returns {zone name: (L2[neq], Loo[neq])} of the first sub-iteration; the full table of a zone is
+    FastC.HOOK['residual_history'][zone name] = (L2, Loo)[sub-iteration][equation]."""
     ctx = _ctx()
+    own = Internal.getNodeFromName1(t, '.Solver#ownData')
+    nssiter = int(Internal.getNodeFromName1(own, '.Solver#dtloc')[1][0])
+    lft = 1
+    if format == 'double':
+        lft = 0
+    elif format in ('store', 'none'):
+        lft = 3
+    iverb = 0 if verbose == 'firstlast' else 2
     out = {}
+    table = FastC.HOOK.setdefault('residual_history', {})
     for nd, z in enumerate(Internal.getZones(t)):
-        l2, loo = ctx.residuals(nd)
-        out[z[0]] = (l2, loo)
+        o = Internal.getNodeFromName1(z, '.Solver#ownData')
+        pint = Internal.getNodeFromName1(o, 'Parameter_int')[1]
+        neq = int(pint[36])
+        implicit = int(pint[29]) <= 1
+        hl2, hloo = ctx.residual_history(nd, nssiter, neq)
+        table[z[0]] = (hl2, hloo)
+        out[z[0]] = (hl2[0], hloo[0])
         # CFL_minmaxmoy of the zone: filled by the compute call in the reference (computePT.cpp:610-643), here when
         # the norms are fetched, so that _compute does not have to wait for the device
         cfl = ctx.cfl(nd)
-        own = Internal.getNodeFromName1(z, '.Solver#ownData')
-        node = Internal.getNodeFromName1(own, 'CFL_minmaxmoy') if own is not None else None
+        node = Internal.getNodeFromName1(o, 'CFL_minmaxmoy') if o is not None else None
         if node is not None:
             node[1][0:3] = cfl
-        if format is None or format in ('single', 'double', 'flush'):
+        if lft < 3:
             # display_ss_iteration.cpp:104
             print("CFL_MOY_MAX_MIN(Zone= %32.32s, nitrun=%d) %f    %f    %f " % (z[0], nitrun, cfl[2], cfl[0], cfl[1]))
-            print("%-24s nitrun=%d  L2 = %s  Loo = %s" % (
-                z[0], nitrun, ' '.join('%.6e' % v for v in l2), ' '.join('%.6e' % v for v in loo)))
-        if stopAtNan and not numpy.all(numpy.isfinite(l2)):
+        last = hl2.shape[0]
+        l2log, loolog = _log10_floor(hl2), _log10_floor(hloo)
+        if lft < 3:
+            fmt = '%14.9f' if lft == 0 else '%7.2f'
+            every = iverb > 1 or bool(numpy.any(hloo[last - 1] > hloo[0]))     # dpssiter.for:32-36
+            for i in range(last):
+                if i == 0 or every:       # dpssiter.for:3010-4311
+                    print(" Res_L2 (zone=%s, ssiter=%3d %3d)" % (z[0], i + 1 if i + 1 < last or not implicit else nssiter, i + 1)
+                          + ''.join('  ' + fmt % v for v in l2log[i]))
+                    print(" Res_Loo(zone=%s, ssiter=%3d %3d)" % (z[0], i + 1 if i + 1 < last or not implicit else nssiter, i + 1)
+                          + ''.join('  ' + fmt % v for v in loolog[i]))
+            if last > 1:                  # dpssiter.for:3020-4321
+                print(" Res_L2 (zone=%s, Diff Ssi 1-%3d)" % (z[0], last) + ''.join('  ' + fmt % v for v in l2log[last - 1] - l2log[0]))
+                print(" Res_Loo(zone=%s, Diff Ssi 1-%3d)" % (z[0], last) + ''.join('  ' + fmt % v for v in loolog[last - 1] - loolog[0]))
+                for nm, d in (('L2 ', l2log[last - 1] - l2log[0]), ('Loo', loolog[last - 1] - loolog[0])):
+                    if d.max() > 0:
+                        print("Warning convergence %s Newton: dom=%s Pas de temps=%6d divergence=%12.5f" % (nm, z[0], nitrun, d.max()))
+        # conv2pytree.for:60-72: one record per call: log10 of the first sub-iteration and the drop to the last
+        zch = Internal.getNodeFromName1(z, 'ZoneConvergenceHistory')
+        if zch is not None:
+            itn = Internal.getNodeFromName1(zch, 'IterationNumber')[1]
+            rec = int(numpy.asarray(zch[1]).ravel()[0])
+            if rec < itn.size:
+                itn[rec] = nitrun
+                sl = slice(rec * neq, (rec + 1) * neq)
+                Internal.getNodeFromName1(zch, 'RSD_L2')[1][sl] = l2log[0]
+                Internal.getNodeFromName1(zch, 'RSD_oo')[1][sl] = loolog[0]
+                Internal.getNodeFromName1(zch, 'RSD_L2_diff')[1][sl] = l2log[last - 1] - l2log[0]
+                Internal.getNodeFromName1(zch, 'RSD_oo_diff')[1][sl] = loolog[last - 1] - loolog[0]
+                numpy.asarray(zch[1]).ravel()[0] = rec + 1
+        if stopAtNan and not numpy.all(numpy.isfinite(hl2)):
             raise FloatingPointError("NaN in the residual of zone %s at iteration %d" % (z[0], nitrun))
     return out
 

@@ -16,7 +16,7 @@ SYMBOLS = [
     "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif", "fs_set_first_it",
     "fs_zone_add", "fs_zone_set_distance", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
-    "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_cfl", "fs_sync",
+    "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
 ]
 
@@ -178,11 +178,18 @@ class Context:
     def apply_bc(self, nstep, level):
         self._chk(lib().fs_apply_bc(self._h, ctypes.c_int(nstep), ctypes.c_int(level)), "fs_apply_bc")
 
-    def residuals(self, zone=0):
-        l2 = numpy.zeros(5); loo = numpy.zeros(5)
-        self._chk(lib().fs_residuals(self._h, ctypes.c_int(zone), _pd(l2), _pd(loo), ctypes.c_int(5)),
+    def residuals(self, zone=0, neq=5):
+        l2 = numpy.zeros(neq); loo = numpy.zeros(neq)
+        self._chk(lib().fs_residuals(self._h, ctypes.c_int(zone), _pd(l2), _pd(loo), ctypes.c_int(neq)),
                   "fs_residuals")
         return l2, loo
+
+    def residual_history(self, zone=0, nslot=1, neq=5):
+        """(L2, Loo)[sub-iteration][equation] of the last verification step."""
+        l2 = numpy.zeros((nslot, neq)); loo = numpy.zeros((nslot, neq))
+        n = self._chk(lib().fs_residual_history(self._h, ctypes.c_int(zone), _pd(l2), _pd(loo), ctypes.c_int(nslot),
+                                                ctypes.c_int(neq)), "fs_residual_history")
+        return l2[:n], loo[:n]
 
     def cfl(self, zone=0):
         """[max, min, mean] local CFL number of the last verification step."""

@@ -38,7 +38,8 @@ struct Zone {
   FsBcWin *rhs_face_dev = nullptr, *rhs_bc_dev = nullptr;
   long long rhs_max_cells = 0;
   int lu[6] = {0, 0, 0, 0, 0, 0};
-  double *res_part = nullptr, *res_out = nullptr;   // res_out: 10 residual norms, then the CFL triple
+  double *res_part = nullptr, *res_out = nullptr;   // res_out: 12 residual sums / maxima per sub-iteration, then the CFL triple
+  int res_slots = 0;              // sub-iterations of the last verification step whose norms are in res_out
   bool have_cfl = false;
   hipEvent_t ev_lu_fork = nullptr, ev_lu_join = nullptr;
   FsBcWin *bc_dev = nullptr;
@@ -52,6 +53,7 @@ struct Zone {
   int *shell_dev = nullptr, *inner_dev = nullptr;
   int n_shell = 0, n_inner = 0;
   bool has_sends = false;         // some of its cells are donors of joins to other contexts
+  bool has_recvs = false;         // some of its ghost cells are filled from other contexts (fs_halo_unpack)
   // roe + walls: windows whose wall-face flux is corrected after the balance (BC/bfl3.for), in BC-table order
   struct RoeWall { int tag, idir, lo[3], hi[3]; };
   std::vector<RoeWall> roe_walls;
@@ -335,9 +337,15 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   const int pt_bcs = p[PT_BC];
   if (pt_bcs <= 0 || pt_bcs >= n_int) return fail(ctx, FS_ERR_ARG, "fs_zone_add: PT_BC out of range");
   const int nb = p[pt_bcs];
+  if (nb < 0 || (long long)pt_bcs + 1 + 2 * (long long)nb > n_int)
+    return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC table overruns Parameter_int");
+  for (int ndf = 0; ndf < nb; ndf++) {   // every window record lies inside Parameter_int, data sizes included
+    const int pt = p[pt_bcs + 1 + ndf];
+    if (pt <= 0 || (long long)pt + 9 > n_int || p[pt + 8] < 0 || (long long)pt + 9 + p[pt + 8] > n_int)
+      return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC table overruns Parameter_int");
+  }
   for (int ndf = 0; ndf < nb; ndf++) {
     const int pt = p[pt_bcs + 1 + ndf];
-    if (pt + 8 >= n_int) return fail(ctx, FS_ERR_ARG, "fs_zone_add: BC table overruns Parameter_int");
     FsBcWin w;
     w.type = p[pt]; w.idir = p[pt + 1];
     if (w.type == 22) continue;  // BCOverlap: filled by the join transfer
@@ -560,6 +568,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
   if (!ctx) return FS_ERR_ARG;
   if (ctx->zones.empty()) return fail(ctx, FS_ERR_STATE, "fs_upload: no zone registered");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->uploaded)   // every precondition before the first allocation: a refused call leaves nothing behind
+    for (auto &zn : ctx->zones)
+      if (zn.z.neq == 6 && !zn.dist_host)
+        return fail(ctx, FS_ERR_STATE, "fs_upload: a Spalart-Allmaras zone needs fs_zone_set_distance first");
   for (auto &zn : ctx->zones) {
     const size_t nb = sizeof(double) * (size_t)zn.z.neq * (size_t)zn.z.nd;
     if (!ctx->uploaded) {
@@ -576,7 +588,6 @@ extern "C" int fs_upload(fs_ctx *ctx)
         HIPCHK(ctx, hipMemsetAsync(zn.wig, 0, nw, ctx->stream));
       }
       if (zn.z.neq == 6) {
-        if (!zn.dist_host) return fail(ctx, FS_ERR_STATE, "fs_upload: a Spalart-Allmaras zone needs fs_zone_set_distance first");
         const size_t nbd = sizeof(double) * (size_t)zn.z.nd;
         HIPCHK(ctx, hipMalloc(&zn.dist, nbd));
         HIPCHK(ctx, hipMemsetAsync(zn.dist, 0, nbd, ctx->stream));
@@ -591,8 +602,8 @@ extern "C" int fs_upload(fs_ctx *ctx)
         HIPCHK(ctx, hipMalloc(&zn.scratch, nb));
         HIPCHK(ctx, hipMemsetAsync(zn.scratch, 0, nb, ctx->stream));
       }
-      HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 10 * (size_t)zn.z.jv * zn.z.kv));
-      HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * 13));
+      HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 12 * (size_t)zn.z.jv * zn.z.kv));
+      HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * (12 * (size_t)zn.z.nssiter + 3)));
       if (!zn.bc_data.empty()) {
         HIPCHK(ctx, hipMalloc(&zn.bc_data_dev, sizeof(double) * zn.bc_data.size()));
         HIPCHK(ctx, hipMemcpy(zn.bc_data_dev, zn.bc_data.data(), sizeof(double) * zn.bc_data.size(), hipMemcpyHostToDevice));
@@ -682,6 +693,7 @@ static int build_shell_lists(fs_ctx *ctx)
     Zone &zn = ctx->zones[nz];
     const FsZone &z = zn.z;
     for (auto &s : ctx->sends) if (s.donor_zone == (int)nz) zn.has_sends = true;
+    for (auto &j : ctx->joins) if (j.donor_zone < 0 && j.rcv_zone == (int)nz) zn.has_recvs = true;
     if (z.ityp == 0 || ctx->implicit || z.iflow == 3 || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1) continue;   // these zones run their stage in one piece
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
@@ -727,16 +739,23 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
   for (auto &zn : ctx->zones) {
     const FsZone &z = zn.z;
     if (nstep < 1 || nstep > z.nssiter) return fail(ctx, FS_ERR_ARG, std::string(who) + ": sub-iteration out of range");
-    // the last slot of an implicit step is the reference's verification pass (residual only,
-    // Fast/FastS/FastS/Compute/computePT.cpp:579-585): nothing to advance
-    if (ctx->implicit && nstep == z.nssiter) continue;
+    // the last slot of an implicit step is the reference's verification pass: skipped on ordinary steps
+    // (Fast/FastS/FastS/Compute/computePT.cpp:579-585); on a verification step it evaluates the Newton residual of
+    // the final iterate and its norms, and advances nothing (lexit_lu, Fast/FastC/FastC/Compute/souszones_list.cpp:81-83)
+    const bool verif = nitrun % ctx->modulo_verif == 0 || nitrun == 1 || ctx->modulo_verif == 1;
+    const bool slot = ctx->implicit && nstep == z.nssiter;
+    if (slot && !verif) continue;
     int in, out;
     stage_roles(ctx, nstep, in, out);
     double coefH, coefW;
     rk_coefs(z.rk, nstep, coefH, coefW);
     const bool split = part >= 0 && zn.n_shell > 0;
-    // a zone that cannot be split runs in one piece: in part 0 when messages wait for its cells, else in part 1
-    if (part >= 0 && !split && part != (zn.has_sends ? 0 : 1)) continue;
+    // a zone that cannot be split runs in one piece: in part 0 when messages wait for its cells, else in part 1.
+    // A zone whose ghost cells are filled from other contexts also runs in part 0 when its stage reads the level the
+    // messages are unpacked into (Newton sub-iterations after the first: input = output = P1), so that it never
+    // overlaps fs_halo_unpack on the other stream.
+    const bool early = zn.has_sends || (zn.has_recvs && in == out);
+    if (part >= 0 && !split && part != (early ? 0 : 1)) continue;
     const bool opens = part <= 0 || !split;      // this call starts the stage of this zone
     const bool closes = part != 0 || !split;     // this call ends it
     const bool dtloc = zn.pint[DTLOC] == 1;
@@ -812,18 +831,23 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       HIPCHK(ctx, hipEventRecord(ctx->ev[ctx->ev_used].second, ctx->stream));
       ctx->ev_used++;
     }
-    if (nstep == 1 && (nitrun % ctx->modulo_verif == 0 || nitrun == 1)) {
-      fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out, ctx->stream,
+    // residual norms (cprdu3s1.for): every Newton sub-iteration of a verification step; explicit scheme: the
+    // first-stage increment
+    if (verif && (ctx->implicit || nstep == 1)) {
+      fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out + 12 * (nstep - 1), ctx->stream,
                    (!ctx->implicit && dtloc) ? zn.coe : nullptr);
       zn.have_res = true;
+      zn.res_slots = nstep;
+    }
+    if (nstep == 1 && verif) {
       // local CFL number of the state the step starts from (cptst3.for:114-120: first sub-iteration of a
       // verification step), with the viscosity this stage has just evaluated
       const double *r = zn.preal.data();
       fsk_cfl(z, r[GAMMA] / r[PRANDT], r[GAMMA] * (r[CVINF] * (r[GAMMA] - 1.)), zn.dev[in], zn.xmut, zn.res_part,
-              zn.res_out + 10, ctx->stream);
+              zn.res_out + 12 * z.nssiter, ctx->stream);
       zn.have_cfl = true;
     }
-    if (ctx->implicit) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:53-68,135-161)
+    if (ctx->implicit && !slot) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:53-68,135-161)
       if (!zn.rhs_face.empty()) {   // wall faces: BCs on the residual, two ordered passes, then edges/corners
         fsk_bc_windows(z, (int)zn.rhs_face.size(), zn.rhs_face_dev, bc_kinds(zn.rhs_face), zn.rhs_max_cells, zn.drodm, ctx->stream);
         fsk_bc_windows(z, (int)zn.rhs_bc.size(), zn.rhs_bc_dev, bc_kinds(zn.rhs_bc), zn.rhs_max_cells, zn.drodm, ctx->stream);
@@ -1064,24 +1088,50 @@ extern "C" int fs_cfl(fs_ctx *ctx, int zone, double *cfl)
   if (zone < 0 || zone >= (int)ctx->zones.size() || !cfl) return fail(ctx, FS_ERR_ARG, "fs_cfl: bad argument");
   Zone &zn = ctx->zones[zone];
   if (!zn.have_cfl) return fail(ctx, FS_ERR_STATE, "fs_cfl: no verification sub-iteration has run yet");
-  HIPCHK(ctx, hipMemcpyAsync(cfl, zn.res_out + 10, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(cfl, zn.res_out + 12 * zn.z.nssiter, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FS_OK;
+}
+
+// L2 / Loo of one slot of the residual table, Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:98,137-141 (the
+// reciprocal of the cell count is evaluated in single precision there)
+static void residual_norms(const Zone &zn, const double *out, int neq, double *l2, double *loo)
+{
+  const double xpt_1 = 1. / (double)(float)((long long)zn.z.iv * zn.z.jv * zn.z.kv);
+  for (int e = 0; e < neq; e++) {
+    l2[e] = e < zn.z.neq ? std::sqrt(out[e] * xpt_1) / zn.z.dt : 0.;
+    loo[e] = e < zn.z.neq ? out[6 + e] / zn.z.dt : 0.;
+  }
 }
 
 extern "C" int fs_residuals(fs_ctx *ctx, int zone, double *l2, double *loo, int neq)
 {
   int rc = ensure_ready(ctx, "fs_residuals");
   if (rc) return rc;
-  if (zone < 0 || zone >= (int)ctx->zones.size() || !l2 || !loo || neq < 5) return fail(ctx, FS_ERR_ARG, "fs_residuals: bad argument");
+  if (zone < 0 || zone >= (int)ctx->zones.size() || !l2 || !loo || neq < 5 || neq > 6) return fail(ctx, FS_ERR_ARG, "fs_residuals: bad argument");
   Zone &zn = ctx->zones[zone];
   if (!zn.have_res) return fail(ctx, FS_ERR_STATE, "fs_residuals: no verification sub-iteration has run yet");
-  double out[10];
+  double out[12];
   HIPCHK(ctx, hipMemcpyAsync(out, zn.res_out, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  const double n = (double)zn.z.iv * zn.z.jv * zn.z.kv;
-  for (int e = 0; e < 5; e++) { l2[e] = std::sqrt(out[e] / n) / zn.z.dt; loo[e] = out[5 + e] / zn.z.dt; }
+  residual_norms(zn, out, neq, l2, loo);
   return FS_OK;
+}
+
+extern "C" int fs_residual_history(fs_ctx *ctx, int zone, double *l2, double *loo, int nslot, int neq)
+{
+  int rc = ensure_ready(ctx, "fs_residual_history");
+  if (rc) return rc;
+  if (zone < 0 || zone >= (int)ctx->zones.size() || !l2 || !loo || neq < 5 || neq > 6 || nslot < 1)
+    return fail(ctx, FS_ERR_ARG, "fs_residual_history: bad argument");
+  Zone &zn = ctx->zones[zone];
+  if (!zn.have_res) return fail(ctx, FS_ERR_STATE, "fs_residual_history: no verification step has run yet");
+  const int n = zn.res_slots < nslot ? zn.res_slots : nslot;
+  std::vector<double> out(12 * (size_t)n);
+  HIPCHK(ctx, hipMemcpyAsync(out.data(), zn.res_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n; i++) residual_norms(zn, out.data() + 12 * i, neq, l2 + (size_t)i * neq, loo + (size_t)i * neq);
+  return n;
 }
 
 extern "C" int fs_sync(fs_ctx *ctx)

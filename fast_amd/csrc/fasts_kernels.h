@@ -63,8 +63,9 @@ void fsk_join_copy(int npts, int neq, long long nd_r, long long nd_d, const int 
                    double *rop_r, const double *rop_d, hipStream_t s);
 void fsk_halo_pack(int npts, int neq, long long nd, const int *pts, const double *rop, double *buf, hipStream_t s);
 void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *rop, const double *buf, hipStream_t s);
-// use_coe = 1: norms of dt/vol * drodm (explicit balance); 0: norms of drodm (Newton residual, already scaled)
-// use_coe: norms of coe * drodm (explicit scheme); coe1 != NULL: the per-cell coe(:,1) of a local time step
+// use_coe = 1: norms of dt/vol * drodm (explicit balance); 0: norms of drodm (Newton residual, already scaled);
+// coe1 != NULL: the per-cell coe(:,1) of a local time step.  part: 12 doubles per (j,k) row of scratch;
+// out[0..5] = sums of squares, out[6..11] = largest magnitudes (5 or 6 equations)
 void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s,
                   const double *coe1 = nullptr);
 // out[3] = largest, smallest and mean local CFL number of the interior cells (cpcfl3.for); part = 3 doubles per

@@ -423,13 +423,15 @@ __global__ void __launch_bounds__(256) k_halo_unpack(int npts, int neq, long lon
 // residual norms: per-block partial sums in a fixed order, then one block folds the partials
 // in index order, so the result does not depend on scheduling.
 // ------------------------------------------------------------------------------------------
+// part: 12 doubles per (j,k) row, [0..5] sums of squares, [6..11] largest magnitudes (5 or 6 equations)
 __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, int use_coe, const double *__restrict__ drodm,
                                                           double *__restrict__ part, const double *__restrict__ coe1)
 {
-  __shared__ double ssum[5][256];
-  __shared__ double smax[5][256];
+  __shared__ double ssum[6][256];
+  __shared__ double smax[6][256];
   const int j = blockIdx.x + 1, k = blockIdx.y + 1;
-  double s[5] = {0, 0, 0, 0, 0}, m[5] = {0, 0, 0, 0, 0};
+  const int neq = z.neq;
+  double s[6] = {0, 0, 0, 0, 0, 0}, m[6] = {0, 0, 0, 0, 0, 0};
   for (int i = threadIdx.x + 1; i <= z.iv; i += blockDim.x) {
     long long l = fs_inddm(z, i, j, k);
     double coe = z.coe;
@@ -438,17 +440,17 @@ __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, int use_coe,
     else if (z.ityp == 0)   // dt/vol of the cell (tstb3_global.for:64-78)
       coe = z.dt / z.vol[(long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj +
                          (long long)(k + z.ifick - 1) * z.minck];
-    for (int e = 0; e < 5; e++) {
+    for (int e = 0; e < neq; e++) {
       double r = use_coe ? coe * drodm[e * z.nd + l] : drodm[e * z.nd + l];
       s[e] = s[e] + r * r;
       m[e] = fs_max(m[e], fabs(r));
     }
   }
-  for (int e = 0; e < 5; e++) { ssum[e][threadIdx.x] = s[e]; smax[e][threadIdx.x] = m[e]; }
+  for (int e = 0; e < 6; e++) { ssum[e][threadIdx.x] = s[e]; smax[e][threadIdx.x] = m[e]; }
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w)
-      for (int e = 0; e < 5; e++) {
+      for (int e = 0; e < 6; e++) {
         ssum[e][threadIdx.x] = ssum[e][threadIdx.x] + ssum[e][threadIdx.x + w];
         smax[e][threadIdx.x] = fs_max(smax[e][threadIdx.x], smax[e][threadIdx.x + w]);
       }
@@ -456,30 +458,30 @@ __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, int use_coe,
   }
   if (threadIdx.x == 0) {
     long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-    for (int e = 0; e < 5; e++) { part[b * 10 + e] = ssum[e][0]; part[b * 10 + 5 + e] = smax[e][0]; }
+    for (int e = 0; e < 6; e++) { part[b * 12 + e] = ssum[e][0]; part[b * 12 + 6 + e] = smax[e][0]; }
   }
 }
 
 __global__ void __launch_bounds__(256) k_residual_final(long long nblk, const double *__restrict__ part,
                                                         double *__restrict__ out)
 {
-  __shared__ double ssum[5][256];
-  __shared__ double smax[5][256];
-  double s[5] = {0, 0, 0, 0, 0}, m[5] = {0, 0, 0, 0, 0};
+  __shared__ double ssum[6][256];
+  __shared__ double smax[6][256];
+  double s[6] = {0, 0, 0, 0, 0, 0}, m[6] = {0, 0, 0, 0, 0, 0};
   for (long long b = threadIdx.x; b < nblk; b += blockDim.x)
-    for (int e = 0; e < 5; e++) { s[e] = s[e] + part[b * 10 + e]; m[e] = fs_max(m[e], part[b * 10 + 5 + e]); }
-  for (int e = 0; e < 5; e++) { ssum[e][threadIdx.x] = s[e]; smax[e][threadIdx.x] = m[e]; }
+    for (int e = 0; e < 6; e++) { s[e] = s[e] + part[b * 12 + e]; m[e] = fs_max(m[e], part[b * 12 + 6 + e]); }
+  for (int e = 0; e < 6; e++) { ssum[e][threadIdx.x] = s[e]; smax[e][threadIdx.x] = m[e]; }
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w)
-      for (int e = 0; e < 5; e++) {
+      for (int e = 0; e < 6; e++) {
         ssum[e][threadIdx.x] = ssum[e][threadIdx.x] + ssum[e][threadIdx.x + w];
         smax[e][threadIdx.x] = fs_max(smax[e][threadIdx.x], smax[e][threadIdx.x + w]);
       }
     __syncthreads();
   }
   if (threadIdx.x == 0)
-    for (int e = 0; e < 5; e++) { out[e] = ssum[e][0]; out[5 + e] = smax[e][0]; }
+    for (int e = 0; e < 6; e++) { out[e] = ssum[e][0]; out[6 + e] = smax[e][0]; }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -166,11 +166,20 @@ int fs_fill_ghostcells(fs_ctx *ctx, int level);
  * (Fast/FastS/FastS/BC/applyBC.cpp:37-39). */
 int fs_apply_bc(fs_ctx *ctx, int nstep, int level);
 
-/* Residual norms of the first sub-iteration of the last step of one zone, per equation:
- * l2[e] = sqrt(sum (coe*drodm)^2 / ncell)/dt, loo[e] = max|coe*drodm|/dt
+/* Residual norms of the first sub-iteration of the last verification step of one zone, per equation (neq = 5 or 6):
+ * l2[e] = sqrt(sum r^2 / ncell)/dt, loo[e] = max|r|/dt, r = Newton residual (implicit scheme) or dt/vol * balance of
+ * the first stage (explicit scheme, where the reference tabulates nothing)
  * (Fast/FastS/FastS/Compute/cprdu3s1_incl.for:47-71 +
  *  Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:128-141).  Synchronises. */
 int fs_residuals(fs_ctx *ctx, int zone, double *l2, double *loo, int neq);
+
+/* Residual history of the last verification step of one zone: the norms above for every Newton sub-iteration
+ * 1..NSSITER (the last slot is the verification pass on the final iterate), i.e. rdm(it_bloc, neq, 2) as
+ * Fast/FastS/FastS/Compute/residus_navier.h:12-43 -> cprdu3s1.for fills it and
+ * Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:112-146 reduces it over the sub-blocks, the table
+ * dpssiter.for:88-99 prints.  l2 / loo: [nslot][neq], sub-iteration major.  Returns the number of slots filled
+ * (1 for the explicit scheme) or an error code.  Synchronises. */
+int fs_residual_history(fs_ctx *ctx, int zone, double *l2, double *loo, int nslot, int neq);
 
 /* Largest, smallest and mean local CFL number of one zone, cfl[3] = {max, min, mean}, evaluated at the first
  * sub-iteration of the last verification step on the state that step started from: what the reference stores

@@ -1669,6 +1669,44 @@ void fo_residual(const i32 *p, const double *drodm, const double *coe, double *s
       }
 }
 
+/* Residual accumulation per sub-block, Fast/FastS/FastS/Compute/cprdu3s1.for:60-79 (one thread: every sub-block
+ * in turn) and cprdu3s1_incl.for:14-141 (all sub-blocks computed): the zone is cut in ijkv_lu(d) =
+ * max(1, IJKV(d) / SIZE_SSDOM(d)) sub-blocks per direction (Fast/FastS/FastS/Compute/residus_navier.h:12-16), the last
+ * one of a direction extended to the zone edge; sub-block no_rdm = i_lu + (j_lu-1)*ijkv_lu(1) + ... holds the sum of
+ * squares and the largest magnitude of drodm over its cells, cells visited k, j, i (i fastest).
+ * sums / maxs: [ndim_rdm][neq]. */
+#define SIZE_SSDOM 30
+void fo_cprdu3s1(const i32 *p, const double *drodm, double *sums, double *maxs)
+{
+  GEOM(p)
+  const int neq = p[NEQ];
+  int lu[3];
+  for (int d = 0; d < 3; d++) { lu[d] = p[IJKV + d] / p[SIZE_SSDOM + d]; if (lu[d] < 1) lu[d] = 1; }
+  for (int k_lu = 1; k_lu <= lu[2]; k_lu++)
+    for (int j_lu = 1; j_lu <= lu[1]; j_lu++)
+      for (int i_lu = 1; i_lu <= lu[0]; i_lu++) {
+        const int no = (i_lu - 1) + (j_lu - 1) * lu[0] + (k_lu - 1) * lu[0] * lu[1];
+        int lo[3] = {1 + (i_lu - 1) * p[SIZE_SSDOM], 1 + (j_lu - 1) * p[SIZE_SSDOM + 1], 1 + (k_lu - 1) * p[SIZE_SSDOM + 2]};
+        int hi[3] = {i_lu * p[SIZE_SSDOM], j_lu * p[SIZE_SSDOM + 1], k_lu * p[SIZE_SSDOM + 2]};
+        if (i_lu == lu[0]) hi[0] = p[IJKV];
+        if (j_lu == lu[1]) hi[1] = p[IJKV + 1];
+        if (k_lu == lu[2]) hi[2] = p[IJKV + 2];
+        double xs[6] = {0., 0., 0., 0., 0., 0.}, xm[6] = {0., 0., 0., 0., 0., 0.};
+        for (int k = lo[2]; k <= hi[2]; k++)
+          for (int j = lo[1]; j <= hi[1]; j++)
+            for (int i = lo[0]; i <= hi[0]; i++) {
+              long l = INDDM(i, j, k);
+              for (int e = 0; e < neq; e++) {
+                double v = drodm[l + e * nd];
+                double xp = fabs(v);
+                if (xp > xm[e]) xm[e] = xp;
+                xs[e] = xs[e] + v * v;
+              }
+            }
+        for (int e = 0; e < neq; e++) { sums[no * neq + e] = xs[e]; maxs[no * neq + e] = xm[e]; }
+      }
+}
+
 /* =====================================================================================
  * Implicit time step: BDF Newton residual + LU-SGS (nb_relax = 1, lu_match = 0, 5 equations,
  * fixed mesh, global time step).  The LU range is the zone interior (no wall boundary).
@@ -2140,11 +2178,13 @@ int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *t
  * Fast/FastS/FastS/Compute/lhs.cpp:53-68,135-161 (BCs on the residual, invlu).  rop_ss = current Newton
  * iterate (ro at the first sub-iteration, ro_p1 afterwards); the new iterate is written to ro_p1.
  * newton_rhs (may be NULL) receives the Newton residual before the LU solve, the array whose norms the
- * reference tabulates (Fast/FastS/FastS/Compute/residus_navier.h, cprdu3s1_incl.for:47-71). */
+ * reference tabulates (Fast/FastS/FastS/Compute/residus_navier.h, cprdu3s1_incl.for:47-71).
+ * rhs_only != 0: the verification slot of a step (last of the NSSITER slots on a verification step,
+ * Fast/FastC/FastC/Compute/souszones_list.cpp:81-83 lexit_lu): the residual is evaluated and the LU solve skipped. */
 int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it, const double *ro,
                         const double *ro_m1, double *ro_p1, double *drodm, double *coe, double *xmut,
                         double *wig, const double *ti, const double *tj, const double *tk, const double *vol,
-                        double *newton_rhs)
+                        double *newton_rhs, int rhs_only)
 {
   const int iv = p[IJKV], jv = p[IJKV + 1], kv = p[IJKV + 2];
   const int f = p[NIJK + 3], fk = p[NIJK + 4];
@@ -2170,6 +2210,7 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   fo_bfl3(p, pr, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);
   fo_core3as2(p, pr, nitcfg, first_it, sdm, rop_ss, ro, ro_m1, drodm, coe);
   if (newton_rhs) memcpy(newton_rhs, drodm, sizeof(double) * p[NEQ] * (size_t)p[NDIMDX]);
+  if (rhs_only) return 0;
   i32 lu[6];
   if (fo_bczone_rhs(p, drodm, ti, tj, tk, lu)) return -1;
   fo_invlu(p, pr, lu, drodm, rop_ss, ro_p1, ti, tj, tk, coe);

@@ -13,7 +13,35 @@ LIB_PATH = os.path.join(HERE, "libfasts_oracle.so")
 _lib = None
 
 NIJK = 0; IJKV = 20; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NDIMDX = 41; NDIMDX_MTR = 43
-NSSITER = 58; DTC = 0; ITYPCP = 29; NEQ_COE = 39; IFLOW = 27
+NSSITER = 58; DTC = 0; ITYPCP = 29; NEQ_COE = 39; IFLOW = 27; SIZE_SSDOM = 30
+
+
+def residual_blocks(pint):
+    """Sub-blocks per direction of the residual table (Fast/FastS/FastS/Compute/residus_navier.h:12-16)."""
+    return [max(1, int(pint[IJKV + d]) // int(pint[SIZE_SSDOM + d])) for d in range(3)]
+
+
+def assemble_rdm(pint, preal, rdm, nssiter, it_bloc):
+    """L2 and Loo norms per Newton sub-iteration from the per-sub-block table rdm(nssiter, neq, 2, nblk) (Fortran
+    order, as cprdu3s1 fills it), the loop of Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:112-146: sums of
+    squares added over the sub-blocks k_lu, j_lu, i_lu (i fastest), L2 = sqrt(sum / ncell) / dt with
+    1 / ncell evaluated in single precision (:98), Loo = largest magnitude / dt.  Returns (l2, loo)[it_bloc][neq]."""
+    neq = int(pint[NEQ])
+    lu = residual_blocks(pint)
+    nblk = lu[0] * lu[1] * lu[2]
+    r = np.asarray(rdm).reshape(nblk, 2, neq, nssiter)      # C view of rdm(nssiter, neq, 2, nblk)
+    xpt_1 = 1. / float(np.float32(int(pint[IJKV]) * int(pint[IJKV + 1]) * int(pint[IJKV + 2])))
+    dt = float(preal[DTC])
+    l2 = np.zeros((it_bloc, neq)); loo = np.zeros((it_bloc, neq))
+    for ne in range(neq):
+        for i in range(it_bloc):
+            rmax = 0.; rmoy = 0.
+            for b in range(nblk):
+                rmax = max(rmax, float(r[b, 1, ne, i]))
+                rmoy = rmoy + float(r[b, 0, ne, i])
+            l2[i, ne] = np.sqrt(rmoy * xpt_1) / dt
+            loo[i, ne] = rmax / dt
+    return l2, loo
 
 
 def build():
@@ -63,6 +91,9 @@ class OracleZone:
             d = np.ascontiguousarray(np.asarray(dist).reshape(-1, order='F'), dtype=np.float64)
             self.xmut[self.ndimdx:self.ndimdx + d.size] = d
         self.stage1_rhs = np.zeros(n)
+        # residual table of a verification step: rdm(nssiter, neq, 2, nblk) and the number of slots filled
+        self.verif = False
+        self.rdm = None; self.it_bloc = 0
 
     def fill_ghostcells(self):
         if lib().fo_bczone(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ti), _p(self.tj), _p(self.tk)) != 0:
@@ -79,6 +110,7 @@ class OracleZone:
             for nstep in range(1, self.nsub() + 1):
                 self.stage(nstep)
                 self.bcs(nstep)
+            self.verification_slot()
             return self.rotate()
         rc = lib().fo_step(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ro_p1), _p(self.drodm),
                            _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj),
@@ -127,14 +159,39 @@ class OracleZone:
             return (self.ro if nstep == 1 else self.ro_p1, self.ro_p1)
         return (self.ro, self.ro_p1) if nstep % 2 == 1 else (self.ro_p1, self.ro)
 
+    def _record_residual(self, nstep, rhs):
+        """cprdu3s1 on a verification step: slot it_bloc = nstep of the residual table."""
+        nssiter = int(self.pint[NSSITER]); neq = self.neq
+        lu = residual_blocks(self.pint); nblk = lu[0] * lu[1] * lu[2]
+        if nstep == 1:
+            self.rdm = np.zeros((nblk, 2, neq, nssiter))
+        sums = np.zeros((nblk, neq)); maxs = np.zeros((nblk, neq))
+        lib().fo_cprdu3s1(_p(self.pint), _p(rhs), _p(sums), _p(maxs))
+        self.rdm[:, 0, :, nstep - 1] = sums
+        self.rdm[:, 1, :, nstep - 1] = maxs
+        self.it_bloc = nstep
+
+    def residual_history(self):
+        """(L2, Loo)[sub-iteration][equation] of the last verification step."""
+        return assemble_rdm(self.pint, self.preal, self.rdm, int(self.pint[NSSITER]), self.it_bloc)
+
+    def verification_slot(self):
+        """Last of the NSSITER slots of an implicit step: run only on verification steps, residual only."""
+        if self.implicit and self.verif:
+            self.stage(int(self.pint[NSSITER]))
+
     def stage(self, nstep):
         if self.implicit:
+            rhs_only = nstep == int(self.pint[NSSITER])
+            keep = self.stage1_rhs if nstep == 1 else (self.drodm_keep() if self.verif else None)
             rc = lib().fo_subiter_implicit(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), ctypes.c_int(self.first_it),
                                            _p(self.ro), _p(self.ro_m1), _p(self.ro_p1), _p(self.drodm), _p(self.coe),
                                            _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj), _p(self.tk), _p(self.vol),
-                                           _p(self.stage1_rhs) if nstep == 1 else None)
+                                           _p(keep) if keep is not None else None, ctypes.c_int(int(rhs_only)))
             if rc != 0:
                 raise NotImplementedError("oracle: implicit options outside LU-SGS nb_relax=1 / lu_match=0 / no wall")
+            if self.verif:
+                self._record_residual(nstep, keep)
             return
         rin, rout = self.roles(nstep)
         lib().fo_subiter(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), _p(rin), _p(rout),
@@ -142,6 +199,11 @@ class OracleZone:
                          _p(self.tj), _p(self.tk), _p(self.vol))
         if nstep == 1:
             self.stage1_rhs[:] = self.drodm
+
+    def drodm_keep(self):
+        if getattr(self, '_keep', None) is None:
+            self._keep = np.zeros(self.neq * self.ndimdx)
+        return self._keep
 
     def bcs(self, nstep):
         if lib().fo_bczone(_p(self.pint), _p(self.preal), _p(self.roles(nstep)[1]), _p(self.ti), _p(self.tj),
@@ -185,5 +247,7 @@ class OracleSolver:
             self.transfers([z.roles(nstep)[1] for z in self.zones])
             for z in self.zones:
                 z.bcs(nstep)
+        for z in self.zones:
+            z.verification_slot()
         for z in self.zones:
             z.rotate()

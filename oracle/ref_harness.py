@@ -55,7 +55,7 @@ def _p(a):
 # Parameter_int / Parameter_real slots used here (Fast/FastS/FastS/param_solver.h)
 NIJK = 0; IJKV = 20; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NEQ_COE = 39; NDIMDX = 41
 NDIMDX_MTR = 43; ITYPCP = 29; KFLUDOM = 33; PT_BC = 70; ITYPZONE = 25; NSSITER = 58
-IFLOW = 27; SLOPE = 64
+IFLOW = 27; SLOPE = 64; ILES = 28; SIZE_SSDOM = 30; MXSSDOM_LU = 24; EPSI_NEWTON = 14
 DTC = 0; GAMMA = 1; ROINF = 3; PINF = 4; VXINF = 19; VYINF = 20; VZINF = 21; RONUTILDEINF = 8
 
 
@@ -186,6 +186,9 @@ class RefSolver:
         self.zones = zones
         self.joins = joins or []   # list of (rcv_zone, rcv_idx int32[n], dnr_zone, dnr_idx int32[n])
         self.first_it = 0
+        # verif: every time step is treated as a verification step (modulo_verif = 1): the residual table of
+        # cprdu3s1 is filled at every Newton sub-iteration and the last slot (residual only) is run
+        self.verif = False
         self.mx_synchro = 1000
         self.lok = np.zeros(self.mx_synchro * 4, dtype=np.int32)
         self.timer = np.zeros(64)
@@ -440,6 +443,39 @@ class RefSolver:
                  _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),
                  _p(zn.coe), _p(dummy), _i(1))
 
+    def _cprdu3s1(self, nd, zn, nitrun, nstep):
+        """Residual table of one zone at sub-iteration nstep of a verification step: cprdu3s1_ as called by
+        Fast/FastS/FastS/Compute/residus_navier.h:12-43 (one thread, every sub-block computed: no_lu and
+        nisdom_residu as Fast/FastC/FastC/Compute/init_ssiter_bloc.for fills them without 'implicit_local'; it_bloc
+        reset at the first sub-iteration and incremented before each, init_ssiter_bloc.for + Compute/ssor.cpp:14-20)."""
+        L = lib()
+        p = zn.pint
+        nssiter = int(p[NSSITER]); neq = zn.neq
+        ijkv = np.ascontiguousarray(p[IJKV:IJKV + 3])
+        ss = np.ascontiguousarray(p[SIZE_SSDOM:SIZE_SSDOM + 3])
+        ijkv_lu = np.array([max(1, int(ijkv[d]) // int(ss[d])) for d in range(3)], dtype=np.int32)
+        ndim_rdm = int(ijkv_lu[0]) * int(ijkv_lu[1]) * int(ijkv_lu[2])
+        mx = max(int(p[MXSSDOM_LU]), ndim_rdm)
+        if nstep == 1:
+            zn.rdm = np.zeros(nssiter * neq * 2 * ndim_rdm)
+            zn.it_lu = [np.zeros(mx, dtype=np.int32) for _ in range(4)]
+            zn.no_lu = np.zeros(mx, dtype=np.int32); zn.no_lu[:ndim_rdm] = np.arange(1, ndim_rdm + 1)
+            zn.nisdom_residu = np.full(nssiter, ndim_rdm, dtype=np.int32)
+            zn.it_bloc = 0
+        zn.it_bloc += 1
+        L.cprdu3s1_(_i(nd), _i(nstep), _i(nssiter), _i(neq), _i(zn.ndimdx), _i(ndim_rdm), _i(nitrun),
+                    _i(p[IFLOW]), _i(p[ILES]), _i(1), _i(1), _i(0),
+                    _i(mx), _i(zn.it_bloc), _d(zn.preal[EPSI_NEWTON]),
+                    _p(ss), _p(zn.nisdom_residu), _p(np.ascontiguousarray(p[NIJK:NIJK + 5])), _p(ijkv), _p(ijkv_lu),
+                    _p(zn.ind_dm), _p(zn.it_lu[0]), _p(zn.it_lu[1]), _p(zn.it_lu[2]), _p(zn.it_lu[3]), _p(zn.no_lu),
+                    _p(zn.drodm), _p(zn.rdm))
+
+    def residual_history(self):
+        """Per zone (L2, Loo)[sub-iteration][equation] of the last verification step, assembled from the table of
+        cprdu3s1_ as Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:112-146 does."""
+        from .oracle import assemble_rdm
+        return [assemble_rdm(zn.pint, zn.preal, zn.rdm, int(zn.pint[NSSITER]), zn.it_bloc) for zn in self.zones]
+
     def step_implicit(self, nitrun):
         """One implicit time step: nssiter-1 Newton sub-iterations (the last slot of nssiter is the
         verification pass, skipped when lssiter_verif = 0: Fast/FastS/FastS/Compute/computePT.cpp:579-585),
@@ -449,12 +485,16 @@ class RefSolver:
         z0 = self.zones[0]
         nssiter = int(z0.pint[NSSITER])
         assert z0.pint[ITYPCP] == 1
-        for nstep in range(1, nssiter):
+        for nstep in range(1, nssiter + (1 if self.verif else 0)):
             for nd, zn in enumerate(self.zones):
                 ssiter = zn.ro if nstep == 1 else zn.ro_p1
                 self._navier_stokes(nd, zn, nitrun, nstep, ssiter)
                 if nstep == 1:
                     zn.stage1_rhs = zn.drodm.copy()
+                if self.verif:     # lhs.cpp:90: the residual of the interior, before the LU solve
+                    self._cprdu3s1(nd, zn, nitrun, nstep)
+            if nstep == nssiter:   # verification slot: lexit_lu = 1 (souszones_list.cpp:83), nothing is advanced
+                break
             for nd, zn in enumerate(self.zones):
                 ssiter = zn.ro if nstep == 1 else zn.ro_p1
                 self._invlu(nd, zn, nitrun, nstep, ssiter)

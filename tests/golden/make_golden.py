@@ -7,7 +7,9 @@ lie in the reference tree) driven by oracle/ref_harness.py.
 
 Each file holds the inputs (Parameter_int, Parameter_real, metrics, initial field without
 ghost fill, join tables) and the reference's outputs (field after 1, 3 and `nit` time steps and
-the per-step residual norms of the first sub-iteration).  Cases marked 'single' run the
+the per-step residual norms of the first sub-iteration; for the implicit scheme `reshist` holds the norms of
+every Newton sub-iteration of every step, out of the reference's own cprdu3s1 with every step treated as a
+verification step).  Cases marked 'single' run the
 reference with one cache block per zone (cache_blocking_I/J/K larger than the zone), the
 configuration in which its floating-point operation order is reproducible by a plain loop nest;
 'default' keeps the reference's default cache blocking (2048,2,7), whose results differ from
@@ -160,19 +162,30 @@ def main():
                 out['join%d_rcv' % q] = r
                 out['join%d_dnr' % q] = d
         s = R.RefSolver(rz, joins)
+        implicit = int(rz[0].pint[29]) == 1
+        s.verif = implicit
         s.fill_ghostcells('ro')
         for b in range(nb):
             out['ghost_%d' % b] = rz[b].ro.copy()
             rz[b].ro_m1[:] = rz[b].ro; rz[b].ro_p1[:] = rz[b].ro      # the three levels start equal
         res = np.zeros((nit, nb, 2, 5))
+        nssiter = int(rz[0].pint[58]); neq = rz[0].neq
+        hist = np.zeros((nit, nb, nssiter, 2, neq))
         for it in range(1, nit + 1):
             s.step(it)
-            for b, (l2, loo) in enumerate(s.residuals()):
-                res[it - 1, b, 0] = l2[:5]; res[it - 1, b, 1] = loo[:5]
+            if implicit:     # norms of every Newton sub-iteration, from cprdu3s1_ of the compiled reference
+                for b, (l2, loo) in enumerate(s.residual_history()):
+                    hist[it - 1, b, :, 0] = l2; hist[it - 1, b, :, 1] = loo
+                    res[it - 1, b, 0] = l2[0, :5]; res[it - 1, b, 1] = loo[0, :5]
+            else:            # explicit scheme: the reference tabulates nothing; the same norm of the first-stage increment
+                for b, (l2, loo) in enumerate(s.residuals()):
+                    res[it - 1, b, 0] = l2[:5]; res[it - 1, b, 1] = loo[:5]
             if it in (1, 3, nit):
                 for b in range(nb):
                     out['ro_it%d_%d' % (it, b)] = rz[b].ro.copy()
         out['residuals'] = res
+        if implicit:
+            out['reshist'] = hist
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **out)
         print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024.))

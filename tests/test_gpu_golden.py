@@ -48,11 +48,21 @@ def test_gpu_equals_reference_golden(name):
     # last bit: 1e-12 relative instead of equality (tolerance of the path: 1e-11 after 100 iterations)
     sa = model in ('NSTurbulent',)
     nit = int(g['nit'])
+    hist = g['reshist'] if 'reshist' in g.files else None
+    ctx = FastC.HOOK['ctx']
     for it in range(1, nit + 1):
         FastS._compute(t, metrics, it, tc)
         res = FastS.display_temporal_criteria(t, metrics, it, format='none')
         for b, z in enumerate(zones):
             l2, loo = res[z[0]]
+            if hist is not None:
+                # residual history of every Newton sub-iteration (verification slot included) against the table
+                # cprdu3s1_ of the compiled reference produced; the device sums in another order: 1e-11
+                nss, neq = hist.shape[2], hist.shape[4]
+                hl2, hloo = ctx.residual_history(b, nss, neq)
+                assert hl2.shape == (nss, neq)
+                np.testing.assert_allclose(hl2, hist[it - 1, b, :, 0], rtol=1e-11, atol=1e-300)
+                np.testing.assert_allclose(hloo, hist[it - 1, b, :, 1], rtol=1e-11 if sa else 1e-14, atol=1e-300)
             np.testing.assert_allclose(l2[:5], g['residuals'][it - 1, b, 0], rtol=1e-11, atol=1e-300)
             np.testing.assert_allclose(loo[:5], g['residuals'][it - 1, b, 1], rtol=1e-11 if sa else 1e-12, atol=1e-300)
             key = 'ro_it%d_%d' % (it, b)

@@ -172,6 +172,37 @@ def test_implicit_lusgs_bit_exact(scheme, model, perturb, bcs, blocks):
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
 
 
+@pytest.mark.parametrize("nn,scheme,model,perturb,bcs,nblk", [
+    ((10, 8, 8), 'ausmpred', 'NSLaminar', 0., None, 1),
+    ((12, 23, 21), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'imax': 'BCFarfield'}, 4),   # 1 x 2 x 2 sub-blocks
+    ((9, 24, 31), 'roe', 'NSTurbulent', 0., {'jmin': 'BCWall'}, 6),                              # 1 x 2 x 3, 6 equations
+])
+def test_residual_history_vs_cprdu3s1(nn, scheme, model, perturb, bcs, nblk):
+    """Residual table of a verification step: the L2 / Loo norms of every Newton sub-iteration (verification slot
+    included) from cprdu3s1_ of the compiled reference (per sub-block sums of Compute/cprdu3s1_incl.for:47-141,
+    reduced as DISPLAY/display_ss_iteration.cpp:112-146) against the restatement: same sub-blocks, same summation
+    order, equality."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    t = cases.tgv(nn, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 4}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb)
+    so, sr = _pair(t)
+    assert int(np.prod(O.residual_blocks(so.zones[0].pint))) == nblk     # sub-blocks of 100 x 10 x 10 cells
+    sr.verif = True
+    for z in so.zones:
+        z.verif = True
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    for it in range(1, 4):
+        so.step(); sr.step(it)
+        l2r, loor = sr.residual_history()[0]
+        l2o, looo = so.zones[0].residual_history()
+        assert l2r.shape == (5, so.zones[0].neq)
+        assert np.array_equal(l2o, l2r) and np.array_equal(looo, loor), "step %d" % it
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    assert l2r[4, 0] < l2r[0, 0]       # the Newton iterations converge
+
+
 @pytest.mark.parametrize("scheme,model,perturb,bcs", [
     ('ausmpred', 'NSLaminar', 0., None),
     ('senseur', 'Euler', 0., None),
