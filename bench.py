@@ -76,8 +76,8 @@ def cpu_baseline(scheme, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--cells', dest='n', type=int, default=256, help='cells per direction per GPU block')
     ap.add_argument('--scheme', default='senseur', choices=['senseur', 'ausmpred', 'roe'])
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
