@@ -18,7 +18,7 @@ from . import _capi
 from .FastC import Internal
 
 __all__ = ['warmup', '_compute', '_applyBC', '_fillGhostcells', 'allocate_metric', '_init_metric',
-           'display_temporal_criteria', '_createConvergenceHistory', 'sync_to_host', 'sync_to_device']
+           'display_temporal_criteria', '_createConvergenceHistory', '_computeEnstrophy', 'sync_to_host', 'sync_to_device']
 
 
 def _lazy():
@@ -177,6 +177,13 @@ def _compute(t, metrics, nitrun, tc=None, graph=None, tc2=None, graph2=None, lay
     if vtune is None:
         return None
     return 0., 0.
+
+
+def _computeEnstrophy(t, metrics):
+    """(enstrophy, kinetic energy) per unit volume of the current state (Fast/FastS/FastS/PyTree.py:1869-1882),
+    reduced on the device."""
+    s = _ctx().tgv_sums(_capi.FS_LEVEL_N)
+    return (s[0] / s[2], s[1] / s[2])
 
 
 def sync_to_host(t=None, levels=_capi.FS_LEVEL_N | _capi.FS_LEVEL_M1 | _capi.FS_LEVEL_P1):

@@ -81,6 +81,7 @@ struct fs_ctx {
   std::vector<Join> joins;
   std::vector<Send> sends;
   bool uploaded = false;
+  double *diag_out = nullptr;   // device: the three sums of fs_tgv_sums
   int modulo_verif = 200;
   // LU-SGS sweeps of different zones are independent and latency-bound (one small launch per hyperplane): they run
   // on a few streams of their own, forked from and joined back into the context's stream by events
@@ -167,6 +168,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     if (zn.ev_lu_fork) (void)hipEventDestroy(zn.ev_lu_fork);
     if (zn.ev_lu_join) (void)hipEventDestroy(zn.ev_lu_join);
   }
+  (void)hipFree(ctx->diag_out);
   for (hipStream_t st : ctx->lu_streams) (void)hipStreamDestroy(st);
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
   for (auto &s : ctx->sends) (void)hipFree(s.pts_dev);
@@ -627,6 +629,7 @@ extern "C" int fs_upload(fs_ctx *ctx)
       HIPCHK(ctx, hipMemcpyAsync(zn.dev[r], zn.host[r], nb, hipMemcpyHostToDevice, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (!ctx->diag_out) HIPCHK(ctx, hipMalloc(&ctx->diag_out, sizeof(double) * 3));
   if (!ctx->uploaded) {
     int rc = build_shell_lists(ctx);
     if (rc) return rc;
@@ -1132,6 +1135,34 @@ extern "C" int fs_residual_history(fs_ctx *ctx, int zone, double *l2, double *lo
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < n; i++) residual_norms(zn, out.data() + 12 * i, neq, l2 + (size_t)i * neq, loo + (size_t)i * neq);
   return n;
+}
+
+// Kinetic energy and enstrophy (Fast/FastS/FastS/POST/computePT_enstrophy.cpp:176-218): sums over the zones of the
+// context; the caller divides by the volume (after adding the sums of the other ranks of a multi-GPU job).
+static int tgv_sums_on(fs_ctx *ctx, int role, double *dev_out, double *scratch, long long scratch_rows, const char *who)
+{
+  for (auto &zn : ctx->zones) {
+    if (zn.z.ityp != 2 || zn.z.twod) return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": Cartesian zones only");
+    if (scratch && (long long)zn.z.jv * zn.z.kv > scratch_rows)
+      return fail(ctx, FS_ERR_ARG, std::string(who) + ": zone has more (j,k) rows than the static scratch buffer holds");
+  }
+  HIPCHK(ctx, hipMemsetAsync(dev_out, 0, sizeof(double) * 3, ctx->stream));
+  for (auto &zn : ctx->zones) fsk_tgv_sums(zn.z, zn.dev[role], scratch ? scratch : zn.res_part, dev_out, ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  return FS_OK;
+}
+
+extern "C" int fs_tgv_sums(fs_ctx *ctx, int level, double *sums)
+{
+  int rc = ensure_ready(ctx, "fs_tgv_sums");
+  if (rc) return rc;
+  const int role = level_role(level);
+  if (role < 0 || !sums) return fail(ctx, FS_ERR_ARG, "fs_tgv_sums: bad argument");
+  rc = tgv_sums_on(ctx, role, ctx->diag_out, nullptr, 0, "fs_tgv_sums");
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(sums, ctx->diag_out, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FS_OK;
 }
 
 extern "C" int fs_sync(fs_ctx *ctx)

@@ -72,6 +72,9 @@ void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *par
 // (j,k) row of scratch; gam1 = gamma / Prandtl, gam2 = gamma * R
 void fsk_cfl(const FsZone &z, double gam1, double gam2, const double *rop, const double *xmut, double *part, double *out,
              hipStream_t s);
+// kinetic energy / enstrophy sums of a Cartesian zone added to out[3] = {enstrophy, kinetic energy, volume};
+// part = 2 doubles per (j,k) row of scratch
+void fsk_tgv_sums(const FsZone &z, const double *rop, double *part, double *out, hipStream_t s);
 // implicit scheme (fasts_lusgs.hip)
 void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, double gamma, double prandtl, double rgp,
                       const double *rop, const double *xmut, double *coe, hipStream_t s);

@@ -574,6 +574,67 @@ __global__ void __launch_bounds__(256) k_cfl_final(long long nblk, double inv_ce
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// kinetic energy and enstrophy of a Cartesian zone (POST/post.for:30-62, cp_gradu_3dcart.for, cptaylor.for): per
+// (j,k) row [enstrophy, kinetic energy] summed over i in a fixed order, then one block folds the rows in index order
+// and ADDS the zone's three sums to out = {enstrophy sum, kinetic-energy sum, volume}.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tgv_partial(FsZone z, const double *__restrict__ rop, double *__restrict__ part)
+{
+  __shared__ double se[256], st[256];
+  const int j = blockIdx.x + 1, k = blockIdx.y + 1;
+  const double c1 = 7. / 12, c2 = 1. / 12;       // post.for:26-27
+  const double t[3] = {z.tcx, z.tcy, z.tcz};
+  const long long inc[3] = {1, z.incj, z.inck};
+  const double vol = z.vol0, volinv = 1. / vol;
+  double e = 0., tk = 0.;
+  for (int i = threadIdx.x + 1; i <= z.iv; i += blockDim.x) {
+    const long long l = fs_inddm(z, i, j, k);
+    double g[3][3];   // g[component][direction]: velocity gradient (cp_gradu_3dcart.for:72-120, cp_gradu.for:88-101)
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const double *q = rop + (c + 1) * z.nd;
+        const double um = (q[l] + q[l - inc[d]]) * c1 - (q[l + inc[d]] + q[l - 2 * inc[d]]) * c2;
+        const long long lp = l + inc[d];
+        const double up = (q[lp] + q[lp - inc[d]]) * c1 - (q[lp + inc[d]] + q[lp - 2 * inc[d]]) * c2;
+        double a = 0. - um * t[d];
+        a = a + up * t[d];
+        g[c][d] = a * volinv;
+      }
+    const double rho = rop[l], u1 = rop[l + z.nd], u2 = rop[l + 2 * z.nd], u3 = rop[l + 3 * z.nd];
+    tk = tk + 0.5 * rho * (u1 * u1 + u2 * u2 + u3 * u3) * vol;      // cptaylor.for:62
+    const double w1 = g[2][1] - g[1][2], w2 = g[0][2] - g[2][0], w3 = g[1][0] - g[0][1];
+    e = e + 0.5 * rho * (w1 * w1 + w2 * w2 + w3 * w3) * vol;         // cptaylor.for:68
+  }
+  se[threadIdx.x] = e; st[threadIdx.x] = tk;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { se[threadIdx.x] = se[threadIdx.x] + se[threadIdx.x + w]; st[threadIdx.x] = st[threadIdx.x] + st[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    part[2 * b] = se[0]; part[2 * b + 1] = st[0];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tgv_final(long long nrow, double zone_volume, const double *__restrict__ part,
+                                                   double *__restrict__ out)
+{
+  __shared__ double se[256], st[256];
+  double e = 0., tk = 0.;
+  for (long long b = threadIdx.x; b < nrow; b += blockDim.x) { e = e + part[2 * b]; tk = tk + part[2 * b + 1]; }
+  se[threadIdx.x] = e; st[threadIdx.x] = tk;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { se[threadIdx.x] = se[threadIdx.x] + se[threadIdx.x + w]; st[threadIdx.x] = st[threadIdx.x] + st[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = out[0] + se[0]; out[1] = out[1] + st[0]; out[2] = out[2] + zone_volume; }
+}
+
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s)
@@ -638,4 +699,13 @@ void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *par
 {
   hipLaunchKernelGGL(k_residual_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, use_coe, drodm, part, coe1);
   hipLaunchKernelGGL(k_residual_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv, part, out);
+}
+
+void fsk_tgv_sums(const FsZone &z, const double *rop, double *part, double *out, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_tgv_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, rop, part);
+  // the reference adds the cell volume once per cell (cptaylor.for:54); on a Cartesian zone that is cells * volume up
+  // to the rounding of the running sum
+  hipLaunchKernelGGL(k_tgv_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv,
+                     (double)((long long)z.iv * z.jv * z.kv) * z.vol0, part, out);
 }

@@ -188,6 +188,13 @@ int fs_residual_history(fs_ctx *ctx, int zone, double *l2, double *loo, int nslo
  * Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:100-105.  Synchronises. */
 int fs_cfl(fs_ctx *ctx, int zone, double *cfl);
 
+/* Kinetic energy and enstrophy of the Taylor-Green diagnostics, summed over the (Cartesian) zones of the context on
+ * the given time level: sums[3] = {sum 0.5 rho |curl u|^2 vol, sum 0.5 rho |u|^2 vol, sum vol}.  The reference returns
+ * sums[0]/sums[2] and sums[1]/sums[2] (fasts.computePT_enstrophy, Fast/FastS/FastS/POST/computePT_enstrophy.cpp:176-227
+ * -> POST/post.for, cp_gradu_3dcart.for with the 4-point face average, cptaylor.for; FastS.PyTree._computeEnstrophy,
+ * Fast/FastS/FastS/PyTree.py:1869-1882); a multi-GPU caller adds the sums of its ranks first.  Synchronises. */
+int fs_tgv_sums(fs_ctx *ctx, int level, double *sums);
+
 /* Block until everything enqueued on the context's stream has finished. */
 int fs_sync(fs_ctx *ctx);
 

@@ -1669,6 +1669,47 @@ void fo_residual(const i32 *p, const double *drodm, const double *coe, double *s
       }
 }
 
+/* Kinetic energy and enstrophy sums of a Cartesian zone, Fast/FastS/FastS/POST/post.for:30-62 with one thread and one
+ * cache block: velocity gradient * volume by the scatter of cp_gradu_3dcart.for:72-120 (every face between cells l-inc
+ * and l carries the 4-point average (q(l)+q(l-inc))*c1 - (q(l+inc)+q(l-2inc))*c2, c1 = 7/12, c2 = 1/12
+ * (post.for:26-27, grad_{i,j,k}_3dcart.for), taken from cell l and given to cell l-inc), divided by the volume
+ * (cp_gradu.for:88-101), then cptaylor.for:52-74: sums over the interior cells, k, j, i with i fastest, of
+ * vol, 0.5*rho*|u|^2*vol and 0.5*rho*|curl u|^2*vol.  out = {enstrophy sum, kinetic-energy sum, volume}. */
+int fo_tgv_sums(const i32 *p, const double *rop, const double *ti, const double *tj, const double *tk,
+                const double *vol, double *out)
+{
+  GEOM(p)
+  if (p[ITYPZONE] != 2) return -1;
+  const double c1 = 7. / 12, c2 = 1. / 12;
+  const double t[3] = {ti[0], tj[0], tk[0]};
+  const long inc[3] = {1, ni, ninj};
+  const double volinv = 1. / vol[0];
+  double tke = 0., enst = 0., cpt = 0.;
+  for (int k = 1; k <= p[IJKV + 2]; k++)
+    for (int j = 1; j <= p[IJKV + 1]; j++)
+      for (int i = 1; i <= p[IJKV]; i++) {
+        long l = INDDM(i, j, k);
+        double g[3][3];   /* g[component][direction] */
+        for (int c = 0; c < 3; c++)
+          for (int d = 0; d < 3; d++) {
+            const double *q = rop + (c + 1) * nd;
+            double um = (q[l] + q[l - inc[d]]) * c1 - (q[l + inc[d]] + q[l - 2 * inc[d]]) * c2;
+            long lp = l + inc[d];
+            double up = (q[lp] + q[lp - inc[d]]) * c1 - (q[lp + inc[d]] + q[lp - 2 * inc[d]]) * c2;
+            double a = 0. - um * t[d];
+            a = a + up * t[d];
+            g[c][d] = a * volinv;
+          }
+        cpt = cpt + vol[0];
+        double rho = rop[l], u1 = rop[l + nd], u2 = rop[l + 2 * nd], u3 = rop[l + 3 * nd];
+        tke = tke + 0.5 * rho * (u1 * u1 + u2 * u2 + u3 * u3) * vol[0];
+        double w1 = g[2][1] - g[1][2], w2 = g[0][2] - g[2][0], w3 = g[1][0] - g[0][1];
+        enst = enst + 0.5 * rho * (w1 * w1 + w2 * w2 + w3 * w3) * vol[0];
+      }
+  out[0] = enst; out[1] = tke; out[2] = cpt;
+  return 0;
+}
+
 /* Residual accumulation per sub-block, Fast/FastS/FastS/Compute/cprdu3s1.for:60-79 (one thread: every sub-block
  * in turn) and cprdu3s1_incl.for:14-141 (all sub-blocks computed): the zone is cut in ijkv_lu(d) =
  * max(1, IJKV(d) / SIZE_SSDOM(d)) sub-blocks per direction (Fast/FastS/FastS/Compute/residus_navier.h:12-16), the last

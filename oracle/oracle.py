@@ -137,6 +137,13 @@ class OracleZone:
         dt = self.preal[DTC]
         return np.sqrt(s / n) / dt, m / dt
 
+    def tgv_sums(self):
+        """[enstrophy sum, kinetic-energy sum, volume] of the current state (POST/post.for, cptaylor.for)."""
+        out = np.zeros(3)
+        if lib().fo_tgv_sums(_p(self.pint), _p(self.ro), _p(self.ti), _p(self.tj), _p(self.tk), _p(self.vol), _p(out)) != 0:
+            raise NotImplementedError("oracle: kinetic energy / enstrophy on Cartesian zones only")
+        return out
+
     def cfl(self):
         """[max, min, mean] of the local CFL number of the current state: what the first sub-iteration of a
         verification step stores in CFL_minmaxmoy (cptst3.for:114-120, computePT.cpp:519,627-643)."""

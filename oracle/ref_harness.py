@@ -476,6 +476,29 @@ class RefSolver:
         from .oracle import assemble_rdm
         return [assemble_rdm(zn.pint, zn.preal, zn.rdm, int(zn.pint[NSSITER]), zn.it_bloc) for zn in self.zones]
 
+    def tgv_sums(self):
+        """Per zone [enstrophy sum, kinetic-energy sum, volume] of the current state: post_ of the compiled reference
+        (POST/post.for: velocity gradient of cp_gradu with the 4-point face average c1 = 7/12, c2 = 1/12, then
+        cptaylor.for), called as Fast/FastS/FastS/POST/computePT_enstrophy.cpp:176-204 does for one thread."""
+        L = lib()
+        out = []
+        for nd, zn in enumerate(self.zones):
+            p = zn.pint
+            ijkv_sdm = np.zeros(3, dtype=np.int32)
+            ind_dm_socket = np.zeros(12, dtype=np.int32)
+            topo_socket = np.ones(3, dtype=np.int32)
+            topo_omp = np.ones(3, dtype=np.int32)
+            L.indice_boucle_lu_(_i(nd), _i(1), _i(1), _i(4), _p(zn.ind_dm), _p(topo_socket), _p(ind_dm_socket))
+            self.lok[:] = 0
+            grad = np.zeros(9 * zn.ndimdx)
+            tke = ctypes.c_double(0.); enst = ctypes.c_double(0.); cpt = ctypes.c_double(0.)
+            L.post_(_i(nd), _i(1), _i(1), _i(1), _i(1), _i(self.mx_synchro), _i(3),
+                    _p(p), _p(zn.preal), ctypes.byref(tke), ctypes.byref(enst), ctypes.byref(cpt),
+                    _p(ijkv_sdm), _p(zn.ind_dm), _p(ind_dm_socket), _p(zn.ind_dm), _p(topo_omp), _p(topo_socket),
+                    _p(self.lok), _p(zn.ro), _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.vol), _p(grad))
+            out.append(np.array([enst.value, tke.value, cpt.value]))
+        return out
+
     def step_implicit(self, nitrun):
         """One implicit time step: nssiter-1 Newton sub-iterations (the last slot of nssiter is the
         verification pass, skipped when lssiter_verif = 0: Fast/FastS/FastS/Compute/computePT.cpp:579-585),

@@ -184,6 +184,9 @@ def main():
                 for b in range(nb):
                     out['ro_it%d_%d' % (it, b)] = rz[b].ro.copy()
         out['residuals'] = res
+        if kind == 'tgv' and all(int(z.pint[25]) == 2 for z in rz):
+            # kinetic energy / enstrophy sums of the final state, per zone, from post_ of the compiled reference
+            out['tgvsums'] = np.array(s.tgv_sums())
         if implicit:
             out['reshist'] = hist
         path = os.path.join(HERE, name + '.npz')

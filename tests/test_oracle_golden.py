@@ -63,6 +63,20 @@ def test_oracle_bit_exact_single_cache_block(path):
                     it, b, np.abs(z.ro - g[key]).max())
 
 
+@pytest.mark.parametrize("name", ['tgv12_senseur_lamin', 'tgv12_ausmpred_lamin', 'tgv_2x2_senseur_lamin'])
+def test_tgv_sums_against_reference_post(name):
+    """Kinetic energy / enstrophy sums of the final state against post_ of the compiled reference (POST/post.for,
+    cp_gradu_3dcart.for, cptaylor.for).  The reference's i loop is an OpenMP SIMD reduction, so its summation order
+    is the vector unit's: 1e-12 relative, not equality."""
+    g, zones, joins = load(os.path.join(HERE, 'golden', name + '.npz'))
+    s = O.OracleSolver(zones, joins)
+    s.fill_ghostcells()
+    for it in range(int(g['nit'])):
+        s.step()
+    for b, z in enumerate(zones):
+        np.testing.assert_allclose(z.tgv_sums(), g['tgvsums'][b], rtol=1e-12)
+
+
 def _rel(a, b, nd):
     a = a.reshape(5, nd); b = b.reshape(5, nd)
     sc = np.abs(b).max(axis=1); sc[1:4] = sc[1:4].max(); sc[sc == 0] = 1.
