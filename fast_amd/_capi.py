@@ -16,7 +16,7 @@ SYMBOLS = [
     "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif", "fs_set_first_it",
     "fs_zone_add", "fs_zone_set_distance", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
-    "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_sync",
+    "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_tgv_sums_static", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
 ]
 
@@ -202,6 +202,10 @@ class Context:
         out = numpy.zeros(3)
         self._chk(lib().fs_tgv_sums(self._h, ctypes.c_int(level), _pd(out)), "fs_tgv_sums")
         return out
+
+    def tgv_sums_static(self, dev_ptr, level=FS_LEVEL_N):
+        """Allocation-free form: the three sums go to the device buffer at dev_ptr (3 doubles), asynchronously."""
+        self._chk(lib().fs_tgv_sums_static(self._h, ctypes.c_int(level), ctypes.c_void_p(dev_ptr)), "fs_tgv_sums_static")
 
     def sync(self):
         self._chk(lib().fs_sync(self._h), "fs_sync")

@@ -98,6 +98,14 @@ struct fs_ctx {
 
 static std::string g_create_err;
 
+// Scratch of the allocation-free entry point fs_tgv_sums_static: two doubles per (j,k) row of the largest zone it
+// accepts (4 MiB).  Every GPU the library runs on holds its own copy at its own address, looked up once per device in
+// fs_create; host code uses that address, never the array's name.
+#define FS_STATIC_ROWS (1 << 18)
+#define FS_MAX_DEVICES 64
+static __device__ __align__(256) double fs_static_scratch[2 * FS_STATIC_ROWS];
+static double *g_static_scratch[FS_MAX_DEVICES];
+
 #define HIPCHK(ctx, call)                                                                   \
   do {                                                                                      \
     hipError_t e_ = (call);                                                                 \
@@ -142,6 +150,11 @@ extern "C" int fs_create(fs_ctx **out, int device)
   fs_ctx *c = new fs_ctx;
   c->device = device;
   e = hipSetDevice(device);
+  if (e == hipSuccess && device < FS_MAX_DEVICES && !g_static_scratch[device]) {
+    void *sp = nullptr;
+    e = hipGetSymbolAddress(&sp, HIP_SYMBOL(fs_static_scratch));   // this device's copy of the array
+    if (e == hipSuccess) g_static_scratch[device] = (double *)sp;
+  }
   if (e == hipSuccess) e = hipStreamCreate(&c->own_stream);
   if (e != hipSuccess) {
     g_create_err = std::string("fs_create: ") + hipGetErrorString(e);
@@ -1163,6 +1176,17 @@ extern "C" int fs_tgv_sums(fs_ctx *ctx, int level, double *sums)
   HIPCHK(ctx, hipMemcpyAsync(sums, ctx->diag_out, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FS_OK;
+}
+
+extern "C" int fs_tgv_sums_static(fs_ctx *ctx, int level, double *dev_sums)
+{
+  int rc = ensure_ready(ctx, "fs_tgv_sums_static");
+  if (rc) return rc;
+  const int role = level_role(level);
+  if (role < 0 || !dev_sums) return fail(ctx, FS_ERR_ARG, "fs_tgv_sums_static: bad argument");
+  double *scratch = ctx->device < FS_MAX_DEVICES ? g_static_scratch[ctx->device] : nullptr;
+  if (!scratch) return fail(ctx, FS_ERR_STATE, "fs_tgv_sums_static: no static scratch buffer on this device");
+  return tgv_sums_on(ctx, role, dev_sums, scratch, FS_STATIC_ROWS, "fs_tgv_sums_static");
 }
 
 extern "C" int fs_sync(fs_ctx *ctx)

@@ -195,6 +195,15 @@ int fs_cfl(fs_ctx *ctx, int zone, double *cfl);
  * Fast/FastS/FastS/PyTree.py:1869-1882); a multi-GPU caller adds the sums of its ranks first.  Synchronises. */
 int fs_tgv_sums(fs_ctx *ctx, int level, double *sums);
 
+/* fs_tgv_sums without any allocation, for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The three sums are written to dev_sums,
+ * a DEVICE pointer to 3 doubles owned by the caller; the per-row partial sums go through a file-scope device array
+ * of the library (4 MiB per GPU, held until the process ends) instead of the context's own scratch.  Limit: every
+ * zone of the context at most 262144 (j,k) rows (jv * kv), else FS_ERR_ARG.  Asynchronous on the context's stream:
+ * no synchronisation, no hipMalloc / hipFree.  All contexts of one GPU share the array: calls that overlap on one
+ * GPU (different streams) race; calls on one stream are ordered. */
+int fs_tgv_sums_static(fs_ctx *ctx, int level, double *dev_sums);
+
 /* Block until everything enqueued on the context's stream has finished. */
 int fs_sync(fs_ctx *ctx);
 
