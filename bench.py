@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mcell-iter/s of the fp64 RK3 Taylor-Green step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment)
 
 Workload (N = 1): Taylor-Green vortex Re = 1600, M = 0.1, one Cartesian block of 256^3 cells
 (+2 ghost layers), NSLaminar, scheme 'senseur' (the scheme of Fast/FastS/test/tgvMpi.py:272),
@@ -9,7 +9,7 @@ explicit RK3, 6 x BCautoperiod, synthetic deterministic initial field.  One step
 time step = 3 sub-iterations (flux balance + RK update + ghost fill each).  Fields are
 resident in HBM before the timed region; nothing is copied to the host inside it.
 N > 1: weak scaling, one 256^3 block per GPU of a (bx,by,bz)-split periodic box, match joins
-exchanged with RCCL send/recv (torch.distributed) between the ranks.
+exchanged with RCCL send/recv inside libfasts_hip.so (fs_comm_*) between the ranks.
 
 Prints ONE JSON line (rank 0) with the whole-job throughput, the roofline of the dominant
 kernel (RK-stage kernel; HIP events on the launch stream) and a CPU baseline measured on a
@@ -98,23 +98,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
 
     os.environ['FASTS_HIP_LAZY_SYNC'] = '1'
-    import torch
     from fast_amd import cases, FastC, Internal
     import fast_amd.PyTree as FastS
+    import fast_amd.Mpi as FastSmpi
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        # one rank per GPU over RCCL; FASTS_DIST_BACKEND=gloo (messages staged through the host)
-        # lets several ranks share one GPU for rehearsals on a single-GPU machine
-        backend = os.environ.get('FASTS_DIST_BACKEND', 'nccl')
-        if backend != 'nccl':
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend)
     model = 'Euler' if a.scheme == 'roe' else 'NSLaminar'
 
     if (a.perturb or a.implicit) and world > 1:
@@ -146,7 +133,6 @@ def main():
         run_step = lambda it: ctx.compute(it, 1, nss, 1)
         ncell_total = a.n ** 3
     else:
-        import fast_amd.Mpi as FastSmpi
         blocks = split_for(world)
         if blocks is None:
             raise SystemExit("bench.py: --gpus must be 1, 2, 4 or 8")
@@ -155,12 +141,7 @@ def main():
         run_step = job.step
         ncell_total = a.n ** 3 * world
 
-    def barrier():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    barrier = FastSmpi.barrier     # this rank's stream drained, then an all-reduce over the ranks (RCCL)
 
     for it in range(1, a.warmup + 1):
         run_step(it)
@@ -171,10 +152,7 @@ def main():
         run_step(it)
     barrier()
     el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    el = float(FastSmpi.allreduce([el], 'max')[0])
     k_ms, k_n = ctx.stage_kernel_ms(reset=False)
 
     # sanity: the field must still be finite
@@ -222,9 +200,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mcell-iter/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %s" % e}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    barrier()
+    ctx.close()
 
 
 if __name__ == '__main__':

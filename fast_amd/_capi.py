@@ -18,7 +18,11 @@ SYMBOLS = [
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_tgv_sums_static", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
+    "fs_comm_unique_id", "fs_comm_init", "fs_zone_set_global_id", "fs_send_add_remote", "fs_comm_setup", "fs_halo_exchange",
+    "fs_comm_allreduce",
 ]
+
+COMM_ID_BYTES = 128
 
 
 class FastsHipError(RuntimeError):
@@ -35,13 +39,6 @@ def lib():
             raise FastsHipError(
                 "fast_amd: native library %s is missing; build it with "
                 "`make -C fast_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-        # PyTorch-ROCm ships its own copy of the HIP runtime.  When both live in one process the
-        # copy loaded first must be torch's, or torch finds no GPU afterwards; the library then
-        # binds to that same runtime (same soname).
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
         L = ctypes.CDLL(LIB_PATH)
         L.fs_version.restype = ctypes.c_char_p
         L.fs_last_error.restype = ctypes.c_char_p
@@ -62,6 +59,15 @@ def _pi(a):
 
 def _pd(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def comm_unique_id():
+    """Identifier of a new communicator (bytes); one rank makes it, every rank passes it to Context.comm_init."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().fs_comm_unique_id(buf, ctypes.c_int(COMM_ID_BYTES))
+    if rc != 0:
+        raise FastsHipError("fs_comm_unique_id failed (%d)" % rc)
+    return buf.raw
 
 
 class Context:
@@ -128,6 +134,37 @@ class Context:
         d = numpy.ascontiguousarray(donor_pts, dtype=numpy.int32)
         self._chk(lib().fs_send_add(self._h, ctypes.c_int(donor_zone), ctypes.c_int(peer_tag), _pi(d),
                                     ctypes.c_int(d.size)), "fs_send_add")
+
+    def zone_set_global_id(self, zone, gid):
+        self._chk(lib().fs_zone_set_global_id(self._h, ctypes.c_int(zone), ctypes.c_int(gid)), "fs_zone_set_global_id")
+
+    def send_add_remote(self, donor_zone, peer_rank, donor_pts, rcv_gid, rcv_pts):
+        d = numpy.ascontiguousarray(donor_pts, dtype=numpy.int32)
+        r = numpy.ascontiguousarray(rcv_pts, dtype=numpy.int32)
+        if d.size != r.size:
+            raise FastsHipError("send_add_remote: donor and receiver lists differ in length")
+        self._chk(lib().fs_send_add_remote(self._h, ctypes.c_int(donor_zone), ctypes.c_int(peer_rank), _pi(d),
+                                           ctypes.c_int(rcv_gid), _pi(r), ctypes.c_int(d.size)), "fs_send_add_remote")
+
+    def comm_init(self, rank, world, comm_id):
+        if len(comm_id) != COMM_ID_BYTES:
+            raise FastsHipError("comm_init: the communicator id has %d bytes" % COMM_ID_BYTES)
+        buf = ctypes.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        self._chk(lib().fs_comm_init(self._h, ctypes.c_int(rank), ctypes.c_int(world), buf, ctypes.c_int(COMM_ID_BYTES)),
+                  "fs_comm_init")
+
+    def comm_setup(self):
+        self._chk(lib().fs_comm_setup(self._h), "fs_comm_setup")
+
+    def halo_exchange(self, nstep):
+        self._chk(lib().fs_halo_exchange(self._h, ctypes.c_int(nstep)), "fs_halo_exchange")
+
+    def allreduce(self, vals, op='sum'):
+        """vals reduced over the ranks of the job (after the context's stream has drained)."""
+        v = numpy.ascontiguousarray(numpy.atleast_1d(vals), dtype=numpy.float64).copy()
+        self._chk(lib().fs_comm_allreduce(self._h, _pd(v), ctypes.c_int(v.size), ctypes.c_int({'sum': 0, 'max': 1, 'min': 2}[op])),
+                  "fs_comm_allreduce")
+        return v
 
     def upload(self):
         self._chk(lib().fs_upload(self._h), "fs_upload")

@@ -1,7 +1,6 @@
 // C ABI of libfasts_hip.so: context, zones, the sub-iteration sequence and data movement.
 // Declarations and the reference interfaces they replace: include/fasts_hip.h.
-#include "../../include/fasts_hip.h"
-#include "fasts_kernels.h"
+#include "fasts_ctx.h"
 
 #include <cmath>
 #include <cstdio>
@@ -20,81 +19,7 @@ enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10
        RONUTILDEINF = 8, CFL = 15, SA_RATIOM_R = 18, PRANDT_TUR = 38, VXINF = 19, VYINF = 20, VZINF = 21,
        PSIROE = 34 };
 
-struct Zone {
-  FsZone z;
-  std::vector<int32_t> pint;
-  std::vector<double> preal;
-  double *host[3] = {nullptr, nullptr, nullptr};  // roles: 0 = N, 1 = M1, 2 = P1
-  double *dev[3] = {nullptr, nullptr, nullptr};
-  double *drodm = nullptr, *xmut = nullptr, *wig = nullptr;
-  double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]
-  // implicit scheme: coe(nd,5) = dt/vol, spectral radii i/j/k, LU diagonal; one spare time level
-  double *coe = nullptr, *scratch = nullptr;
-  double *dist = nullptr;      // SA model: wall distance of every cell (fs_zone_set_distance)
-  const double *dist_host = nullptr;
-  // implicit scheme with wall BCs: windows applied to the Newton residual before the LU solve (whole-face
-  // extrapolation first, then the BCs of the wall faces) and the LU range (one ghost layer over wall faces)
-  std::vector<FsBcWin> rhs_face, rhs_bc;
-  FsBcWin *rhs_face_dev = nullptr, *rhs_bc_dev = nullptr;
-  long long rhs_max_cells = 0;
-  int lu[6] = {0, 0, 0, 0, 0, 0};
-  double *res_part = nullptr, *res_out = nullptr;   // res_out: 12 residual sums / maxima per sub-iteration, then the CFL triple
-  int res_slots = 0;              // sub-iterations of the last verification step whose norms are in res_out
-  bool have_cfl = false;
-  hipEvent_t ev_lu_fork = nullptr, ev_lu_join = nullptr;
-  FsBcWin *bc_dev = nullptr;
-  std::vector<double> bc_data;          // window data of the BCs that carry their own, concatenated
-  std::vector<long long> bc_data_off;   // per entry of bc: offset in bc_data, -1 without data
-  double *bc_data_dev = nullptr;
-  std::vector<FsBcWin> bc;
-  long long bc_max_cells = 0;
-  bool have_res = false;
-  // stage-kernel tiles that hold donor cells of joins to other contexts ("shell") and the others
-  int *shell_dev = nullptr, *inner_dev = nullptr;
-  int n_shell = 0, n_inner = 0;
-  bool has_sends = false;         // some of its cells are donors of joins to other contexts
-  bool has_recvs = false;         // some of its ghost cells are filled from other contexts (fs_halo_unpack)
-  // roe + walls: windows whose wall-face flux is corrected after the balance (BC/bfl3.for), in BC-table order
-  struct RoeWall { int tag, idir, lo[3], hi[3]; };
-  std::vector<RoeWall> roe_walls;
-  hipEvent_t ev_part = nullptr;   // start of a split stage (timing)
-};
-
-struct Join {
-  int rcv_zone, donor_zone, peer_tag, npts;
-  int *rcv_dev = nullptr, *dnr_dev = nullptr;
-};
-
-struct Send {
-  int donor_zone, peer_tag, npts;
-  int *pts_dev = nullptr;
-  std::vector<int32_t> pts_host;
-};
-
 }  // namespace
-
-struct fs_ctx {
-  int device = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
-  hipStream_t comm_stream = nullptr;   // halo pack / unpack launch here when set (fs_set_comm_stream)
-  std::vector<Zone> zones;
-  std::vector<Join> joins;
-  std::vector<Send> sends;
-  bool uploaded = false;
-  double *diag_out = nullptr;   // device: the three sums of fs_tgv_sums
-  int modulo_verif = 200;
-  // LU-SGS sweeps of different zones are independent and latency-bound (one small launch per hyperplane): they run
-  // on a few streams of their own, forked from and joined back into the context's stream by events
-  std::vector<hipStream_t> lu_streams;
-  int lu_nstreams = -1;    // -1: not decided yet (FASTS_HIP_LU_STREAMS, default 4; 0 or 1 = everything on one stream)
-  bool implicit = false;      // ITYPCP 1: BDF + LU-SGS Newton sub-iterations (all zones of a context agree)
-  int first_it = 0;           // FIRST_IT of the reference: 0 until one time step is complete (BDF1, xid = 1)
-  std::string err;
-  // stage-kernel timing
-  bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-  size_t ev_used = 0;
-};
 
 static std::string g_create_err;
 
@@ -106,27 +31,12 @@ static std::string g_create_err;
 static __device__ __align__(256) double fs_static_scratch[2 * FS_STATIC_ROWS];
 static double *g_static_scratch[FS_MAX_DEVICES];
 
-#define HIPCHK(ctx, call)                                                                   \
-  do {                                                                                      \
-    hipError_t e_ = (call);                                                                 \
-    if (e_ != hipSuccess) {                                                                 \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
-      return FS_ERR_HIP;                                                                    \
-    }                                                                                       \
-  } while (0)
-
 static int bc_kinds(const std::vector<FsBcWin> &v)
 {
   int k = 0;
   for (auto &w : v)
     k |= (w.type == FS_BC_PERIODIC || w.type == FS_BC_EXTRAPOLATE || w.type == FS_BC_ZERO || w.type == FS_BC_EXTRAP_NUT) ? 1 : 2;
   return k;
-}
-
-static int fail(fs_ctx *ctx, int code, const std::string &msg)
-{
-  ctx->err = msg;
-  return code;
 }
 
 extern "C" const char *fs_version(void) { return "fasts_hip 0.1 gfx950 fp64 contract=off"; }
@@ -182,6 +92,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     if (zn.ev_lu_join) (void)hipEventDestroy(zn.ev_lu_join);
   }
   (void)hipFree(ctx->diag_out);
+  fs_comm_release(ctx);
   for (hipStream_t st : ctx->lu_streams) (void)hipStreamDestroy(st);
   for (auto &j : ctx->joins) { (void)hipFree(j.rcv_dev); (void)hipFree(j.dnr_dev); }
   for (auto &s : ctx->sends) (void)hipFree(s.pts_dev);
@@ -1050,14 +961,38 @@ extern "C" int fs_compute(fs_ctx *ctx, int nitrun, int nstep_deb, int nstep_fin,
   const int nssiter = ctx->zones[0].z.nssiter;
   if (nstep_deb < 1 || nstep_fin > nssiter || nstep_deb > nstep_fin || nit_c < 1)
     return fail(ctx, FS_ERR_ARG, "fs_compute: bad sub-iteration range");
-  for (auto &j : ctx->joins)
-    if (j.donor_zone < 0) return fail(ctx, FS_ERR_STATE, "fs_compute: joins to other contexts need the split calls (fs_stage / fs_halo_* / fs_bcs)");
+  bool remote = false;
+  for (auto &j : ctx->joins) if (j.donor_zone < 0) remote = true;
+  for (auto &sd : ctx->sends) { (void)sd; remote = true; }
+  if (remote && !fs_comm_active(ctx))
+    return fail(ctx, FS_ERR_STATE, "fs_compute: joins to other contexts need fs_comm_init / fs_comm_setup, or the split calls "
+                "(fs_stage / fs_halo_* / fs_bcs) with a transport of the caller's");
+  static const bool overlap = !(getenv("FASTS_HIP_OVERLAP") && strcmp(getenv("FASTS_HIP_OVERLAP"), "0") == 0);
   for (int it = 0; it < nit_c; it++) {
     const int nitrun_loc = nitrun * nit_c + it;  // computePT.cpp:543
     for (int nstep = nstep_deb; nstep <= nstep_fin; nstep++) {
-      rc = fs_stage(ctx, nitrun_loc, nstep);
+      const bool slot = ctx->implicit && nstep == nssiter;
+      if (remote && !slot) {
+        // stage in two parts: the tiles that feed halo messages first; pack -> RCCL send/recv -> unpack run on the
+        // comm stream while the rest of the stage runs here (the reference transfers after the whole stage,
+        // Fast/FastS/FastS/Compute/gsdr3.cpp:251-349)
+        if (overlap) {
+          rc = stage_impl(ctx, nitrun_loc, nstep, 0, "fs_compute");
+          if (rc) return rc;
+          rc = fs_comm_exchange_begin(ctx, nstep);  // ordered after part 0 by an event, returns at once
+          if (rc) return rc;
+          rc = stage_impl(ctx, nitrun_loc, nstep, 1, "fs_compute");
+        } else {
+          rc = stage_impl(ctx, nitrun_loc, nstep, -1, "fs_compute");
+          if (rc) return rc;
+          rc = fs_comm_exchange_begin(ctx, nstep);
+        }
+        if (rc) return rc;
+        rc = fs_comm_exchange_end(ctx);             // the context's stream waits for the unpack
+      } else
+        rc = fs_stage(ctx, nitrun_loc, nstep);
       if (rc) return rc;
-      if (ctx->implicit && nstep == nssiter) continue;   // verification slot: no update, no ghost fill
+      if (slot) continue;   // verification slot: no update, no ghost fill
       NstepArg a = {ctx, nstep};
       local_joins_on(ctx, role_from_nstep, &a);
       int in, out;
@@ -1227,5 +1162,29 @@ extern "C" int fs_debug_fetch(fs_ctx *ctx, int zone, int which, double *host, in
   if (n_doubles != n) return fail(ctx, FS_ERR_ARG, "fs_debug_fetch: size mismatch");
   HIPCHK(ctx, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FS_OK;
+}
+
+// ---- shared with fasts_comm.hip --------------------------------------------------------------------------------
+int fs_stage_roles_out(const fs_ctx *ctx, int nstep) { int in, out; stage_roles(ctx, nstep, in, out); return out; }
+int fs_level_role(int level) { return level_role(level); }
+int fs_ensure_ready(fs_ctx *ctx, const char *who) { return ensure_ready(ctx, who); }
+
+extern "C" int fs_zone_set_global_id(fs_ctx *ctx, int zone, int gid)
+{
+  if (!ctx) return FS_ERR_ARG;
+  if (zone < 0 || zone >= (int)ctx->zones.size() || gid < 0) return fail(ctx, FS_ERR_ARG, "fs_zone_set_global_id: bad argument");
+  ctx->zones[zone].gid = gid;
+  return FS_OK;
+}
+
+extern "C" int fs_send_add_remote(fs_ctx *ctx, int donor_zone, int peer_rank, const int32_t *donor_pts, int rcv_gid,
+                                  const int32_t *rcv_pts, int npts)
+{
+  if (!ctx || !rcv_pts || rcv_gid < 0) return ctx ? fail(ctx, FS_ERR_ARG, "fs_send_add_remote: bad argument") : FS_ERR_ARG;
+  int rc = fs_send_add(ctx, donor_zone, peer_rank, donor_pts, npts);
+  if (rc) return rc;
+  ctx->sends.back().rcv_gid = rcv_gid;
+  ctx->sends.back().rcv_host.assign(rcv_pts, rcv_pts + npts);
   return FS_OK;
 }

@@ -158,6 +158,39 @@ int fs_local_joins(fs_ctx *ctx, int nstep);
 int fs_bcs(fs_ctx *ctx, int nstep);
 int fs_rotate(fs_ctx *ctx);
 
+/* ---- halo transport inside the library: RCCL send/recv between the contexts of a job (one per GPU) --------------
+ * Replaces the MPI side of K_FASTC::setInterpTransfersInter / getTransfersInter
+ * (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:944-1582 pack + isend, :1590-1719 recv + scatter, driven by
+ * Fast/FastS/FastS/Mpi.py:117-233 once per sub-iteration).  With a communicator set up, fs_compute runs the whole
+ * sub-iteration: part 0 of the stage -> pack / ncclSend+ncclRecv (one group) / unpack on a stream of its own, while
+ * part 1 runs on the context's stream -> local joins -> BCs.  librccl is opened at run time by the first of these
+ * calls; a job of one context never loads it.
+ *
+ *   fs_comm_unique_id    128 bytes identifying a new communicator; one rank creates them, the caller carries them to
+ *                        the others (file, socket, MPI broadcast: the library opens no connection of its own)
+ *   fs_comm_init         join the communicator as `rank` of `world` (collective, blocks until every rank has called)
+ *   fs_zone_set_global_id  job-wide number of a local zone (the same numbering on every rank, e.g. the position of
+ *                        the zone name in the sorted graph['procDict'], Fast/FastS/test/tgvMpi.py:198-256)
+ *   fs_send_add_remote   fs_send_add + the receiver side of the join: zone (global id) and ghost cells on
+ *                        `peer_rank` that take the values (PointListDonor); the reference ships that list with every
+ *                        message (setInterpTransfersFast.cpp:1185-1206), here it travels once, in fs_comm_setup
+ *   fs_comm_setup        after fs_upload, collective: exchanges the receiver lists, creates the ghost-cell joins fed
+ *                        by each peer and the message buffers
+ *   fs_halo_exchange     one round of messages outside fs_compute: nstep >= 1 on the output level of that
+ *                        sub-iteration, nstep <= 0 on time level -nstep (ghost cells of the initial field,
+ *                        Fast/FastS/FastS/Mpi.py:934)
+ *   fs_comm_allreduce    n <= 64 host doubles reduced over the ranks in place, op 0 sum / 1 max / 2 min, after waiting
+ *                        for the context's stream: the barrier and the max-over-ranks clock of a benchmark, the global
+ *                        sums of diagnostics (the reference reduces over MPI the same way, Fast/FastS/FastS/Mpi.py:473,954)   */
+int fs_comm_unique_id(void *id, int nbytes);
+int fs_comm_init(fs_ctx *ctx, int rank, int world, const void *id, int nbytes);
+int fs_zone_set_global_id(fs_ctx *ctx, int zone, int gid);
+int fs_send_add_remote(fs_ctx *ctx, int donor_zone, int peer_rank, const int32_t *donor_pts, int rcv_gid,
+                       const int32_t *rcv_pts, int npts);
+int fs_comm_setup(fs_ctx *ctx);
+int fs_halo_exchange(fs_ctx *ctx, int nstep);
+int fs_comm_allreduce(fs_ctx *ctx, double *vals, int n, int op);
+
 /* Joins then BCs then edge/corner fix on one time level: replaces
  * FastS.PyTree._fillGhostcells (Fast/FastS/FastS/PyTree.py:1153-1218) for local joins. */
 int fs_fill_ghostcells(fs_ctx *ctx, int level);

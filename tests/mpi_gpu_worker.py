@@ -1,9 +1,11 @@
 """One rank of the multi-rank GPU test (started by test_gpu_mpi.py): the product path
-fast_amd.Mpi (warmup / _compute over torch.distributed) with every rank on GPU 0 and the
-messages staged through the host by the gloo backend.  Each rank compares its block with a
-serial run of the whole job by the CPU restatement.
+fast_amd.Mpi (warmup / _compute) with every rank on GPU 0; RCCL wants one GPU per rank, so the
+messages travel over gloo, staged through the host, through the transport hook of warmup and
+the split native calls.  The blocks are dealt to the ranks in consecutive runs (several blocks
+per rank: local joins next to messages).  Each rank compares its blocks with a serial run of
+the whole job by the CPU restatement.
 
-    python mpi_gpu_worker.py <bi> <bj> <bk> <n> <nsteps> [explicit|implicit|curvilinear|sa]
+    python mpi_gpu_worker.py <bi> <bj> <bk> <n> <nsteps> [explicit|implicit|curvilinear|sa|walls|walls_implicit]
 """
 import os
 import sys
@@ -21,6 +23,7 @@ from fast_amd import cases, connect, FastC, Internal
 import fast_amd.Mpi as FastSmpi
 from oracle import oracle as O
 from common import prepare, zone_arrays, wall_distance, rel_err
+from halo_gloo import GlooTransport
 
 SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
 
@@ -35,13 +38,18 @@ def main():
         opts = {'time_step': 0.02, 'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': 3}}
     elif mode == 'curvilinear':
         opts['perturb'] = 0.15
+    elif mode.startswith('walls'):   # curvilinear blocks between two walls: the i direction must not be split
+        opts['perturb'] = 0.15
+        opts['bcs'] = {'imin': 'BCWall', 'imax': 'BCFarfield'}
+        if mode == 'walls_implicit':
+            opts.update({'time_step': 0.01, 'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': 3}})
     model = 'NSTurbulent' if mode == 'sa' else 'NSLaminar'    # 6 variables per cell in the messages
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
-    job = FastSmpi.tgv_job(n, blocks, 'senseur', model, rank, world, 0, **opts)
+    job = FastSmpi.tgv_job(n, blocks, 'senseur', model, rank, world, 0, transport=GlooTransport(0), **opts)
     for it in range(1, nsteps + 1):
         FastSmpi._compute(job.t, job.metrics, it, job.tc, job.graph)
-    got = FastC.level_buffer(Internal.getZones(job.t)[0])
+    got = [FastC.level_buffer(z) for z in Internal.getZones(job.t)]
 
     tt = cases.tgv(nn, 'senseur', model=model, blocks=blocks, **opts)
     mm = prepare(tt)
@@ -53,12 +61,15 @@ def main():
     s.fill_ghostcells()
     for it in range(nsteps):
         s.step()
-    if mode == 'sa':    # the device pow of the destruction term differs from the host pow in the last bit
-        ok = bool(rel_err(got, zs[rank].ro, int(zs[rank].pint[41]), neq=6).max() < 1e-12)
-    else:
-        ok = np.array_equal(got, zs[rank].ro)
-    if not ok:
-        print("rank %d: max abs diff %g" % (rank, np.abs(got - zs[rank].ro).max()), flush=True)
+    ok = True
+    for g, b in zip(got, job.blocks_here):
+        if mode == 'sa':    # the device pow of the destruction term differs from the host pow in the last bit
+            okb = bool(rel_err(g, zs[b].ro, int(zs[b].pint[41]), neq=6).max() < 1e-12)
+        else:
+            okb = np.array_equal(g, zs[b].ro)
+        if not okb:
+            print("rank %d block %d: max abs diff %g" % (rank, b, np.abs(g - zs[b].ro).max()), flush=True)
+        ok = ok and okb
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

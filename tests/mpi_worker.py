@@ -1,9 +1,9 @@
 """One rank of the multi-rank halo-exchange test (started by test_mpi_gloo.py; gloo, CPU).
 
-The exchange schedule under test is the product's (fast_amd.Mpi.HaloPlan / HaloExchange over
-torch.distributed); the zone update between the messages is done by the CPU restatement, which
+The join split under test is the product's (fast_amd.Mpi.HaloPlan); the messages travel over gloo
+(halo_gloo.HaloExchange); the zone update between the messages is done by the CPU restatement, which
 stands in for the GPU here.  Every rank also advances the whole multi-block job serially and
-compares its own block bit for bit.
+compares its own blocks bit for bit (several blocks per rank: local joins next to messages).
 
     python mpi_worker.py <bi> <bj> <bk> <niv> <njv> <nkv> <nsteps>
 """
@@ -25,6 +25,7 @@ import fast_amd.PyTree as FastS
 import fast_amd.Mpi as FastSmpi
 from oracle import oracle as O
 from common import prepare, zone_arrays
+from halo_gloo import HaloExchange
 
 SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
 
@@ -36,56 +37,72 @@ def main():
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     nb = blocks[0] * blocks[1] * blocks[2]
-    assert nb == world
+    assert nb % world == 0
+    per = nb // world
+    owner = [b // per for b in range(nb)]
+    mine = [b for b in range(nb) if owner[b] == rank]
     nn = tuple(nv[d] * blocks[d] for d in range(3))
     names = ['cart%d' % b for b in range(nb)]
 
-    # ---- this rank's block, its donor-side joins, the graph ----
-    t = cases.tgv(nn, 'senseur', blocks=blocks, only=[rank], extra_numz=SINGLE)
+    # ---- this rank's blocks, their donor-side joins, the graph ----
+    t = cases.tgv(nn, 'senseur', blocks=blocks, only=mine, extra_numz=SINGLE)
     tc = C.node2Center(t)
     all_joins = connect.periodic_block_joins(blocks, nv)
-    connect.add_joins_to_tc(tc, [j for j in all_joins if j[1] == rank], names)
-    graph = connect.graph_of(blocks, names, list(range(nb)))
+    connect.add_joins_to_tc(tc, [j for j in all_joins if owner[j[1]] == rank], names)
+    graph = connect.graph_of(blocks, names, owner)
     metrics = prepare(t)
-    z = Internal.getZones(t)[0]
-    pint, preal, _ = zone_arrays(z)
-    oz = O.OracleZone(pint, preal, FastC.level_buffer(z), metrics[0][0])
-    plan = FastSmpi.HaloPlan(FastS.joins_from_tc(t, tc), graph['procDict'], rank, world)
-    assert not plan.local
-    halo = FastSmpi.HaloExchange(plan, torch.device('cpu'))
-    nd = oz.ndimdx
+    ozs = {}
+    for z, m in zip(Internal.getZones(t), metrics):
+        pint, preal, _ = zone_arrays(z)
+        ozs[z[0]] = O.OracleZone(pint, preal, FastC.level_buffer(z), m[0])
+    plan = FastSmpi.HaloPlan(FastS.joins_from_tc(t, tc), graph['procDict'], rank, world, dist.all_gather_object)
+    assert bool(plan.local) == (per > 1)
+    halo = HaloExchange(plan, torch.device('cpu'))
 
-    def pack_from(arr):
+    def pack_from(arr_of):
         def pack(peer, buf):
             out = buf.numpy()
             off = 0
-            for (dn, dpts) in plan.sends[peer]:
-                assert dn == names[rank]
+            for (dn, dpts, _, _) in plan.sends[peer]:
+                arr, nd = arr_of(dn), ozs[dn].ndimdx
                 for v in range(5):
                     out[off + v * dpts.size: off + (v + 1) * dpts.size] = arr[v * nd + dpts]
                 off += 5 * dpts.size
         return pack
 
-    def unpack_to(arr):
+    def unpack_to(arr_of):
         def unpack(peer, buf):
             src = buf.numpy()
             off = 0
             for (rn, rpts) in plan.recvs[peer]:
-                assert rn == names[rank]
+                arr, nd = arr_of(rn), ozs[rn].ndimdx
                 for v in range(5):
                     arr[v * nd + rpts] = src[off + v * rpts.size: off + (v + 1) * rpts.size]
                 off += 5 * rpts.size
         return unpack
 
-    halo.run(pack_from(oz.ro), unpack_to(oz.ro))
-    oz.fill_ghostcells()
+    def local_joins(arr_of):
+        for (rn, dn, rpts, dpts) in plan.local:
+            ar, ad = arr_of(rn), arr_of(dn)
+            for v in range(5):
+                ar[v * ozs[rn].ndimdx + rpts] = ad[v * ozs[dn].ndimdx + dpts]
+
+    level_n = lambda name: ozs[name].ro
+    halo.run(pack_from(level_n), unpack_to(level_n))
+    local_joins(level_n)
+    for oz in ozs.values():
+        oz.fill_ghostcells()
     for it in range(nsteps):
         for nstep in (1, 2, 3):
-            oz.stage(nstep)
-            out = oz.roles(nstep)[1]
+            for oz in ozs.values():
+                oz.stage(nstep)
+            out = lambda name: ozs[name].roles(nstep)[1]
             halo.run(pack_from(out), unpack_to(out))
-            oz.bcs(nstep)
-        oz.rotate()
+            local_joins(out)
+            for oz in ozs.values():
+                oz.bcs(nstep)
+        for oz in ozs.values():
+            oz.rotate()
 
     # ---- serial run of the whole job ----
     tt = cases.tgv(nn, 'senseur', blocks=blocks, extra_numz=SINGLE)
@@ -98,7 +115,7 @@ def main():
     s.fill_ghostcells()
     for it in range(nsteps):
         s.step()
-    ok = np.array_equal(oz.ro, zs[rank].ro)
+    ok = all(np.array_equal(ozs[names[b]].ro, zs[b].ro) for b in mine)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

@@ -60,3 +60,20 @@ def test_compute_before_warmup_is_an_error(monkeypatch):
     monkeypatch.setattr(FastC, 'HOOK', None)
     with pytest.raises(_capi.FastsHipError):
         FastS._compute(None, None, 1)
+
+
+def test_product_path_has_no_tensor_framework():
+    """The package and the benchmark drive the GPU through libfasts_hip.so alone (RCCL inside the library)."""
+    import glob
+    files = glob.glob(os.path.join(ROOT, 'fast_amd', '**', '*'), recursive=True) + [os.path.join(ROOT, 'bench.py')]
+    for f in files:
+        if os.path.isfile(f) and f.endswith(('.py', '.hip', '.h', 'Makefile')):
+            assert 'torch' not in open(f).read(), f
+
+
+def test_comm_calls_without_a_context_fail_cleanly():
+    L = _capi.lib()
+    assert L.fs_comm_setup(None) < 0
+    assert L.fs_halo_exchange(None, 1) < 0
+    assert L.fs_comm_allreduce(None, None, 1, 0) < 0
+    assert L.fs_comm_init(None, 0, 1, None, 128) < 0
