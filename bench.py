@@ -13,7 +13,7 @@ exchanged with RCCL send/recv inside libfasts_hip.so (fs_comm_*) between the ran
 
 Prints ONE JSON line (rank 0) with the whole-job throughput, the roofline of the dominant
 kernel (RK-stage kernel; HIP events on the launch stream) and a CPU baseline measured on a
-bounded sample with the compiled reference (or, when absent, the C restatement).
+bounded sample: the compiled reference on all host cores of the job (one thread beside it).
 """
 import argparse
 import json
@@ -34,12 +34,8 @@ def split_for(n):
     return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n)
 
 
-def cpu_baseline(scheme, budget_s=12.0):
-    """Reference FastS (compiled Fortran, one thread) on a bounded sample of the same workload:
-    the same TGV case at 96^3, as many steps as fit the budget (at least 2)."""
+def _cpu_case(n, scheme):
     from fast_amd import cases, FastC, Internal
-    from oracle import ref_harness as R
-    n = 96
     t = cases.tgv(n, scheme)
     FastC._buildOwnData(t, None); FastC._build_omp(t)
     dtloc = Internal.getNodeFromName2(t, '.Solver#dtloc')[1]
@@ -48,19 +44,10 @@ def cpu_baseline(scheme, budget_s=12.0):
     FastC._BCcompact(t); FastC._createPrimVars(t)
     pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
     preal = Internal.getNodeFromName2(z, 'Parameter_real')[1]
-    ro = FastC.level_buffer(z)
-    if R.available():
-        g = Internal.getNodeFromName1(z, 'GridCoordinates')
-        xyz = [Internal.getNodeFromName1(g, c)[1] for c in ('CoordinateX', 'CoordinateY', 'CoordinateZ')]
-        zn = R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], ro, metrics[0])
-        s = R.RefSolver([zn]); s.fill_ghostcells('ro')
-        step = lambda it: s.step(it)
-        kind = 'reference'
-    else:
-        from oracle import oracle as O
-        oz = O.OracleZone(pint, preal, ro, metrics[0]); oz.fill_ghostcells()
-        step = lambda it: oz.step()
-        kind = 'port'
+    return z, pint, preal, FastC.level_buffer(z), metrics
+
+
+def _timed(step, n, budget_s):
     step(1)
     t0 = time.time(); it = 0
     while True:
@@ -69,8 +56,47 @@ def cpu_baseline(scheme, budget_s=12.0):
         el = time.time() - t0
         if (el > budget_s and it >= 2) or it >= 50:
             break
-    return {"value": n ** 3 * it / el / 1e6, "unit": "Mcell-iter/s", "cores": 1, "kind": kind,
-            "sample": "TGV %d^3 %s RK3, %d steps, one thread, default cache blocking" % (n, scheme, it)}
+    return n ** 3 * it / el / 1e6, it
+
+
+def _ref_solver(n, scheme, threads):
+    from fast_amd import Internal
+    from oracle import ref_harness as R
+    z, pint, preal, ro, metrics = _cpu_case(n, scheme)
+    g = Internal.getNodeFromName1(z, 'GridCoordinates')
+    xyz = [Internal.getNodeFromName1(g, c)[1] for c in ('CoordinateX', 'CoordinateY', 'CoordinateZ')]
+    zn = R.RefZone(pint, preal, xyz[0], xyz[1], xyz[2], ro, metrics[0])
+    s = R.RefSolver([zn]); s.threads = threads; s.fill_ghostcells('ro')
+    return s
+
+
+def cpu_baseline(scheme, budget_s=10.0):
+    """CPU legs on bounded samples of the same workload (the same TGV case, smaller box).
+    value = the compiled reference Fortran on every host core given to the job: its own thread decomposition
+            (indice_boucle_lu) and lock protocol, driven like its parallel region (oracle/ref_mt.c); BCs on one thread.
+    single_thread = the same on one thread.  Without the compiled reference: the C restatement on OpenMP threads."""
+    from oracle import oracle as O
+    from oracle import ref_harness as R
+    cores = max(1, min(int(os.environ.get('OMP_NUM_THREADS', '0') or 0) or (os.cpu_count() or 1), os.cpu_count() or 1))
+    n = 160
+    if R.available():
+        s = _ref_solver(n, scheme, cores)
+        v, it = _timed(lambda i: s.step(i), n, budget_s)
+        out = {"value": v, "unit": "Mcell-iter/s", "cores": cores, "kind": "reference",
+               "sample": "TGV %d^3 %s RK3, %d steps, compiled reference Fortran on %d OpenMP threads, default cache blocking"
+                         % (n, scheme, it, cores)}
+        n1 = 96
+        s1 = _ref_solver(n1, scheme, 1)
+        v1, it1 = _timed(lambda i: s1.step(i), n1, budget_s * 0.6)
+        out["single_thread"] = {"value": v1, "unit": "Mcell-iter/s", "cores": 1, "kind": "reference",
+                                "sample": "TGV %d^3 %s RK3, %d steps, one thread" % (n1, scheme, it1)}
+        return out
+    z, pint, preal, ro, metrics = _cpu_case(n, scheme)
+    oz = O.OracleZone(pint, preal, ro, metrics[0]); oz.fill_ghostcells()
+    oz.threads = cores
+    v, it = _timed(lambda i: oz.step(), n, budget_s)
+    return {"value": v, "unit": "Mcell-iter/s", "cores": cores, "kind": "port",
+            "sample": "TGV %d^3 %s RK3, %d steps, C restatement on %d OpenMP threads (k-slabs)" % (n, scheme, it, cores)}
 
 
 def main():

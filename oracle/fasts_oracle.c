@@ -18,6 +18,9 @@
  * Fast/FastS/FastS/param_solver.h:77-306.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -665,9 +668,22 @@ static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const doubl
 /* Flux balance over the range ind (one cache block, no neighbouring thread): order of the
  * face loops and of the += / -= pairs as Fast/FastS/FastS/Compute/template_FluxAndBalance.for:192-271,
  * assemble_drodm_plus_vec1.for, flu_send_scater_vec1.for */
+static void flux_own(const i32 *p, const double *pr, const i32 *ind, const double *rop, double *drodm,
+                     const double *wig, const double *xmut, const double *ti, const double *tj,
+                     const double *tk, const double *vol, int own_lo, int own_hi);
 void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, double *drodm,
              const double *wig, const double *xmut, const double *ti, const double *tj,
              const double *tk, const double *vol)
+{
+  flux_own(p, pr, ind, rop, drodm, wig, xmut, ti, tj, tk, vol, -(1 << 30), 1 << 30);
+}
+
+/* fo_flux on a k-slab of a zone shared between threads: contributions to cells whose k lies outside
+ * [own_lo, own_hi] are left to the thread that owns them (it evaluates the same face), so every cell receives
+ * its six contributions in the order of the single-thread sweep. */
+static void flux_own(const i32 *p, const double *pr, const i32 *ind, const double *rop, double *drodm,
+                     const double *wig, const double *xmut, const double *ti, const double *tj,
+                     const double *tk, const double *vol, int own_lo, int own_hi)
 {
   GEOM(p)
   fluxctx c;
@@ -686,9 +702,10 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
         for (int i = ind[0]; i <= ind[1]; i++) {
           long l = INDDM(i, j, k), l0 = l - c.inc[dir];
           FACE(l, i, j, k, dir);
+          const int below = dir != 2 || k - 1 >= own_lo;
           for (int e = 0; e < neq; e++) {
             drodm[l + e * nd] = drodm[l + e * nd] + f[e];
-            drodm[l0 + e * nd] = drodm[l0 + e * nd] - f[e];
+            if (below) drodm[l0 + e * nd] = drodm[l0 + e * nd] - f[e];
           }
         }
       {
@@ -715,7 +732,7 @@ void fo_flux(const i32 *p, const double *pr, const i32 *ind, const double *rop, 
       FACE(l, i, j, ind[5] + 1, 2);
       for (int e = 0; e < neq; e++) {
         drodm[ls + e * nd] = drodm[ls + e * nd] - f[e];
-        drodm[l + e * nd] = drodm[l + e * nd] + f[e];
+        if (ind[5] + 1 <= own_hi) drodm[l + e * nd] = drodm[l + e * nd] + f[e];
       }
     }
 #undef FACE
@@ -1644,6 +1661,73 @@ int fo_step(const i32 *p, const double *pr, double *ro, double *ro_p1, double *d
     double *in = (nstep % 2 == 1) ? ro : ro_p1;
     double *out = (nstep % 2 == 1) ? ro_p1 : ro;
     fo_subiter(p, pr, nstep, in, out, drodm, coe, xmut, wig, ti, tj, tk, vol);
+    if (nstep == 1 && stage1_rhs) memcpy(stage1_rhs, drodm, sizeof(double) * p[NEQ] * (size_t)p[NDIMDX]);
+    if (fo_bczone(p, pr, out, ti, tj, tk)) return -1;
+  }
+  return 0;
+}
+
+/* fo_subiter with the k-planes dealt to `nthreads` OpenMP threads in contiguous slabs (the decomposition the
+ * reference's OpenMP layer would make for a thread topology (1,1,n), Fast/FastC/FastC/HPC_LAYER/WORK_DISTRIBUTION_BEGIN.for):
+ * every phase of the sub-iteration is cell-local except the flux balance, whose scatter is restricted to the
+ * slab (flux_own), so the result equals fo_subiter's bit for bit.  Global time step only. */
+void fo_subiter_mt(const i32 *p, const double *pr, int nitcfg, const double *rop_in, double *rop_out,
+                   double *drodm, double *coe, double *xmut, double *wig, const double *ti,
+                   const double *tj, const double *tk, const double *vol, int nthreads)
+{
+  const int iv = p[IJKV], jv = p[IJKV + 1], kv = p[IJKV + 2];
+  if (nthreads <= 1 || kv < 2 * nthreads || p[46] == 1 || p[ITYPZONE] == 3) {
+    fo_subiter(p, pr, nitcfg, rop_in, rop_out, drodm, coe, xmut, wig, ti, tj, tk, vol);
+    return;
+  }
+  const int gk = p[NIJK + 4] > 0;
+  const int f = p[NIJK + 3], fk = p[NIJK + 4];
+  GEOM(p)
+#pragma omp parallel num_threads(nthreads)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    const int t = 0, nt = 1;
+#endif
+    const int klo = 1 + (int)((long)kv * t / nt), khi = (int)((long)kv * (t + 1) / nt);
+    /* slab extended to the ghost planes on the first and last thread */
+    const int glo = t == 0 ? 1 - gk : klo, ghi = t == nt - 1 ? kv + gk : khi;
+    const int alo = t == 0 ? 1 - fk : klo, ahi = t == nt - 1 ? kv + fk : khi;
+    const i32 sdm[6] = {1, iv, 1, jv, klo, khi};
+    if (nitcfg == 1) {
+      const i32 grad[6] = {0, iv + 1, 0, jv + 1, glo, ghi};
+      const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, alo, ahi};
+      if (p[IFLOW] == 2) fo_invist(p, pr, grad, rop_in, xmut);
+      if (p[IFLOW] == 3) fo_vispalart(p, pr, all, rop_in, xmut);
+      const double volinv = pr[DTC] / vol[0];
+      for (int k = klo; k <= khi; k++)
+        for (int j = 1; j <= jv; j++)
+          for (int i = 1; i <= iv; i++)
+            coe[INDDM(i, j, k)] = p[ITYPZONE] != 2 ? pr[DTC] / vol[INDMTR(p, i, j, k)] : volinv;
+    }
+    fo_init_rhs(p, nitcfg, sdm, drodm);
+#pragma omp barrier
+    if (p[IFLOW] == 3) fo_spsource_SA(p, pr, nitcfg, sdm, rop_in, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
+    if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_in, wig);
+#pragma omp barrier
+    flux_own(p, pr, sdm, rop_in, drodm, wig, xmut, ti, tj, tk, vol, klo, khi);
+#pragma omp barrier
+#pragma omp single
+    fo_bfl3(p, pr, rop_in, drodm, wig, xmut, ti, tj, tk, vol);
+    fo_core3ark3(p, pr, nitcfg, sdm, rop_out, rop_in, drodm, coe);
+  }
+}
+
+int fo_step_mt(const i32 *p, const double *pr, double *ro, double *ro_p1, double *drodm, double *coe,
+               double *xmut, double *wig, const double *ti, const double *tj, const double *tk,
+               const double *vol, double *stage1_rhs, int nthreads)
+{
+  const int nssiter = p[NSSITER];
+  for (int nstep = 1; nstep <= nssiter; nstep++) {
+    double *in = (nstep % 2 == 1) ? ro : ro_p1;
+    double *out = (nstep % 2 == 1) ? ro_p1 : ro;
+    fo_subiter_mt(p, pr, nstep, in, out, drodm, coe, xmut, wig, ti, tj, tk, vol, nthreads);
     if (nstep == 1 && stage1_rhs) memcpy(stage1_rhs, drodm, sizeof(double) * p[NEQ] * (size_t)p[NDIMDX]);
     if (fo_bczone(p, pr, out, ti, tj, tk)) return -1;
   }

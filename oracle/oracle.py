@@ -57,6 +57,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.fo_step.restype = ctypes.c_int
+        _lib.fo_step_mt.restype = ctypes.c_int
         _lib.fo_bczone.restype = ctypes.c_int
         _lib.fo_subiter_implicit.restype = ctypes.c_int
     return _lib
@@ -94,6 +95,8 @@ class OracleZone:
         # residual table of a verification step: rdm(nssiter, neq, 2, nblk) and the number of slots filled
         self.verif = False
         self.rdm = None; self.it_bloc = 0
+        # OpenMP threads of the explicit sub-iteration (k-slabs; same result bit for bit)
+        self.threads = 1
 
     def fill_ghostcells(self):
         if lib().fo_bczone(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ti), _p(self.tj), _p(self.tk)) != 0:
@@ -112,9 +115,9 @@ class OracleZone:
                 self.bcs(nstep)
             self.verification_slot()
             return self.rotate()
-        rc = lib().fo_step(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ro_p1), _p(self.drodm),
-                           _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj),
-                           _p(self.tk), _p(self.vol), _p(self.stage1_rhs))
+        rc = lib().fo_step_mt(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ro_p1), _p(self.drodm),
+                              _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj),
+                              _p(self.tk), _p(self.vol), _p(self.stage1_rhs), ctypes.c_int(self.threads))
         if rc != 0:
             raise NotImplementedError("oracle: unsupported BC tag")
         if int(self.pint[NSSITER]) % 2 == 1:
@@ -201,9 +204,9 @@ class OracleZone:
                 self._record_residual(nstep, keep)
             return
         rin, rout = self.roles(nstep)
-        lib().fo_subiter(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), _p(rin), _p(rout),
-                         _p(self.drodm), _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti),
-                         _p(self.tj), _p(self.tk), _p(self.vol))
+        lib().fo_subiter_mt(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), _p(rin), _p(rout),
+                            _p(self.drodm), _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti),
+                            _p(self.tj), _p(self.tk), _p(self.vol), ctypes.c_int(self.threads))
         if nstep == 1:
             self.stage1_rhs[:] = self.drodm
 

@@ -193,6 +193,8 @@ class RefSolver:
         self.lok = np.zeros(self.mx_synchro * 4, dtype=np.int32)
         self.timer = np.zeros(64)
         self.stage1_rhs = None
+        # OpenMP threads of the RHS + update (oracle/ref_mt.c drives the reference's own thread decomposition and locks)
+        self.threads = 1
 
     # -- one sub-iteration of one zone: RHS + update -------------------------------------
     def _navier_stokes(self, nd, zn, nitrun, nstep, ro_ssiter):
@@ -209,6 +211,23 @@ class RefSolver:
         self.lok[:] = 0
         norm_kry = ctypes.c_double(0.)
         alias = zn.ro
+        if self.threads > 1:
+            from . import oracle as _O
+            n = self.threads
+            if getattr(self, '_mt', None) is None or self._mt[0] != n:
+                self._mt = (n, np.zeros(self.mx_synchro * n, dtype=np.int32), np.zeros(64 * n, dtype=np.int32),
+                            np.zeros(2 * n), np.zeros(3 * n))
+            _, lok, work, timer, cfl = self._mt
+            f = _O.lib().fo_ref_mt_subiter
+            f.restype = ctypes.c_int
+            vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+            f(ctypes.cast(L.navier_stokes_struct_, ctypes.c_void_p), ctypes.cast(L.indice_boucle_lu_, ctypes.c_void_p),
+              ctypes.c_int(n), ctypes.c_int(nd), ctypes.c_int(nstep), ctypes.c_int(nssiter), ctypes.c_int(nitrun),
+              ctypes.c_int(self.first_it), vp(p), vp(zn.preal), ctypes.c_double(temps), vp(zn.ind_dm), vp(lok),
+              ctypes.c_int(self.mx_synchro), vp(work), vp(timer), vp(cfl), vp(alias), vp(zn.x), vp(zn.y), vp(zn.z),
+              vp(zn.ro), vp(zn.ro_m1), vp(zn.ro_p1), vp(ro_ssiter), vp(zn.xmut), vp(zn.ti), vp(zn.tj), vp(zn.tk),
+              vp(zn.vol), vp(zn.wig), vp(zn.drodm), vp(zn.coe))
+            return
         L.navier_stokes_struct_(
             _i(nd), _i(1), _i(1), _i(1), _i(0), _i(1), _i(1), _i(1), _i(self.mx_synchro),
             _i(0), _i(0), _i(1), _i(nstep), _i(nssiter), _i(nitrun), _i(self.first_it),

@@ -3,6 +3,7 @@ restatement, and size-independent properties of the scheme on a periodic Cartesi
 translation invariance of the inviscid scheme (bit-exact: every cell runs the same arithmetic
 wherever the tile and chunk boundaries fall; the viscous cross derivatives are excluded because
 next to the box boundary they read edge ghost cells, which the reference fills with averages) and conservation of mass, momentum and total energy."""
+import os
 import numpy as np
 import pytest
 
@@ -31,6 +32,7 @@ def test_one_full_size_step_bit_exact_vs_oracle():
     z = Internal.getZones(t)[0]
     p, pr, _ = zone_arrays(z)
     oz = O.OracleZone(p, pr, FastC.level_buffer(z), metrics[0][0])
+    oz.threads = max(1, min(16, os.cpu_count() or 1))
     FastS._compute(t, metrics, 1, None)
     oz.step()
     got = FastC.level_buffer(z)
