@@ -188,235 +188,8 @@ FS_DEV void lu_neighbour(const FsZone &z, const LuConst &c, long long l, long lo
                             NE == 6 ? dw[l1 + 5 * nd] : 0.);
 }
 
-// cell of hyperplane h handled by this thread: threads run over j (x) and k (y, offset kbase)
-FS_DEV bool plane_cell(const LuRange &r, int h, int kbase, int &i, int &j, int &k)
-{
-  j = r.j0 + blockIdx.x * blockDim.x + threadIdx.x;
-  k = kbase + blockIdx.y;
-  i = r.i0 + h - (j - r.j0) - (k - r.k0);
-  return j <= r.j1 && k <= r.k1 && i >= r.i0 && i <= r.i1;
-}
-
-// Lower sweep, hyperplane h: dW*(l) = [dW(l) + xal*(sum of neighbour terms)] / diag, neighbours in
-// the reference's order (Cartesian: j, k, i; curvilinear: k, j, i).
-template <bool FULL>
-__global__ void __launch_bounds__(64) k_lu_lower(FsZone z, LuConst c, LuRange r, int h, int kbase,
-                                                 const double *__restrict__ rop, double *__restrict__ dw,
-                                                 const double *__restrict__ coe)
-{
-  int i, j, k;
-  if (!plane_cell(r, h, kbase, i, j, k)) return;
-  const long long nd = z.nd, l = lcell(z, i, j, k), lt = FULL ? lmtr(z, i, j, k) : 0;
-  const double xal = coe[l] * 0.5;
-  double a[5], b[5];
-#pragma unroll
-  for (int e = 0; e < 5; e++) a[e] = dw[l + e * nd];
-  if (FULL) {
-    if (k > r.k0) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-    if (j > r.j0) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-  } else {
-    if (j > r.j0) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-    if (k > r.k0) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-  }
-  if (i > r.i0) { lu_neighbour<FULL, 0, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-  const double diag = 1. / coe[l + 4 * nd];
-#pragma unroll
-  for (int e = 0; e < 5; e++) dw[l + e * nd] = a[e] * diag;
-}
-
-// Upper sweep, hyperplane h, followed by the Newton update of the cell:
-//   dW(l) = [diag*dW*(l) - xal'*(neighbour terms k+1, j+1, i+1)] / diag,   W_new = W(rop) + dW -> rop_new.
-// rop_kn = state array of the k+1 neighbour: the reference updates rop plane by plane while it sweeps,
-// so when the iterate is updated in place (sub-iterations after the first) the k+1 neighbour already
-// holds the new state, the j+1 and i+1 neighbours the old one.
-template <bool FULL>
-__global__ void __launch_bounds__(64) k_lu_upper(FsZone z, LuConst c, LuRange r, int h, int kbase,
-                                                 const double *__restrict__ rop, const double *rop_kn,
-                                                 double *rop_new, double *__restrict__ dw,
-                                                 const double *__restrict__ coe)
-{
-  int i, j, k;
-  if (!plane_cell(r, h, kbase, i, j, k)) return;
-  const long long nd = z.nd, l = lcell(z, i, j, k), lt = FULL ? lmtr(z, i, j, k) : 0;
-  const double xal = coe[l] * -0.5;
-  const double c5 = coe[l + 4 * nd];
-  double a[5], b[5];
-#pragma unroll
-  for (int e = 0; e < 5; e++) a[e] = dw[l + e * nd] * c5;
-  if (k < r.k1) { lu_neighbour<FULL, 2, -1>(z, c, l, lt, rop_kn, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-  if (j < r.j1) { lu_neighbour<FULL, 1, -1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-  if (i < r.i1) { lu_neighbour<FULL, 0, -1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) a[e] = a[e] + b[e] * xal; }
-  const double diag = 1. / c5;
-#pragma unroll
-  for (int e = 0; e < 5; e++) { a[e] = a[e] * diag; dw[l + e * nd] = a[e]; }
-  // Newton update (mjr_newton.for)
-  const double ro_old = rop[l], u_old = rop[l + nd], v_old = rop[l + 2 * nd], w_old = rop[l + 3 * nd];
-  const double t_old = rop[l + 4 * nd];
-  const double rn = ro_old + a[0];
-  const double r_1 = 1. / rn;
-  const double un = (ro_old * u_old + a[1]) * r_1;
-  const double vn = (ro_old * v_old + a[2]) * r_1;
-  const double wn = (ro_old * w_old + a[3]) * r_1;
-  const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
-  rop_new[l] = rn; rop_new[l + nd] = un; rop_new[l + 2 * nd] = vn; rop_new[l + 3 * nd] = wn;
-  rop_new[l + 4 * nd] = (roe_old + a[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
-}
-
 // ------------------------------------------------------------------------------------------------------
-// Chunked sweeps: a thread owns CH consecutive cells of one i-line (one or two cache lines per array,
-// read in full) and runs the i recurrence over them serially, as the reference does over the whole
-// line.  The unit (c, j, k), c = chunk number along i, depends on (c-1, j, k), (c, j-1, k), (c, j, k-1):
-// units of a hyperplane c + j + k = const are independent.  Far fewer, shorter launches than one
-// hyperplane of single cells per launch, and no partially used cache lines.
-// ------------------------------------------------------------------------------------------------------
-FS_DEV bool plane_unit(const LuRange &r, int nchunk, int h, int kbase, int &c, int &j, int &k)
-{
-  j = r.j0 + blockIdx.x * blockDim.x + threadIdx.x;
-  k = kbase + blockIdx.y;
-  c = h - (j - r.j0) - (k - r.k0);
-  return j <= r.j1 && k <= r.k1 && c >= 0 && c < nchunk;
-}
-
-// Three phases per unit so that no memory access sits in the serial chain: (A) every load of the unit and
-// the j/k neighbour terms, all independent; (B) the i recurrence over the CH cells, registers only;
-// (C) the stores.
-template <bool FULL, int CH>
-__global__ void __launch_bounds__(64) k_lu_lower_chunk(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
-                                                       const double *__restrict__ rop, double *__restrict__ dw,
-                                                       const double *__restrict__ coe)
-{
-  int cn, j, k;
-  if (!plane_unit(r, nchunk, h, kbase, cn, j, k)) return;
-  const long long nd = z.nd;
-  const int ia = r.i0 + cn * CH;
-  const int n = (ia + CH - 1 < r.i1 ? CH : r.i1 - ia + 1);   // cells of this unit
-  const long long l0 = lcell(z, ia, j, k), lt0 = FULL ? lmtr(z, ia, j, k) : 0;
-  const bool has_j = j > r.j0, has_k = k > r.k0, has_i0 = ia > r.i0;
-  double A[CH][5], S[CH][4], CR[CH], XAL[CH], DG[CH];
-  double p[5] = {0., 0., 0., 0., 0.};   // increment of the cell before the unit, final
-  if (has_i0) {
-#pragma unroll
-    for (int e = 0; e < 5; e++) p[e] = dw[l0 - 1 + e * nd];
-  }
-#pragma unroll
-  for (int m = 0; m < CH; m++) {
-    if (m < n) {
-      const long long l = l0 + m, lt = lt0 + (FULL ? m : 0);
-      const double xal = coe[l] * 0.5;
-      double b[5];
-#pragma unroll
-      for (int e = 0; e < 5; e++) A[m][e] = dw[l + e * nd];
-      if (FULL) {
-        if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
-        if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
-      } else {
-        if (has_j) { lu_neighbour<FULL, 1, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
-        if (has_k) { lu_neighbour<FULL, 2, 1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
-      }
-      XAL[m] = xal;
-      DG[m] = 1. / coe[l + 4 * nd];
-      if (m > 0 || has_i0) {
-        S[m][0] = rop[l - 1 + nd]; S[m][1] = rop[l - 1 + 2 * nd]; S[m][2] = rop[l - 1 + 3 * nd]; S[m][3] = rop[l - 1 + 4 * nd];
-        CR[m] = coe[l - 1 + nd];
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < CH; m++) {
-    if (m < n) {
-      if (m > 0 || has_i0) {
-        double b[5];
-        lu_term<FULL, 0, 1>(z, c, lt0 + (FULL ? m : 0), S[m][0], S[m][1], S[m][2], S[m][3], p[0], p[1], p[2], p[3], p[4], CR[m], b);
-#pragma unroll
-        for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * XAL[m];
-      }
-#pragma unroll
-      for (int e = 0; e < 5; e++) { p[e] = A[m][e] * DG[m]; A[m][e] = p[e]; }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < CH; m++) {
-    if (m < n) {
-#pragma unroll
-      for (int e = 0; e < 5; e++) dw[l0 + m + e * nd] = A[m][e];
-    }
-  }
-}
-
-template <bool FULL, int CH>
-__global__ void __launch_bounds__(64) k_lu_upper_chunk(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
-                                                       const double *__restrict__ rop, const double *rop_kn,
-                                                       double *rop_new, double *__restrict__ dw,
-                                                       const double *__restrict__ coe)
-{
-  int cn, j, k;
-  if (!plane_unit(r, nchunk, h, kbase, cn, j, k)) return;
-  const long long nd = z.nd;
-  const int ia = r.i0 + cn * CH;
-  const int n = (ia + CH - 1 < r.i1 ? CH : r.i1 - ia + 1);
-  const long long l0 = lcell(z, ia, j, k), lt0 = FULL ? lmtr(z, ia, j, k) : 0;
-  const bool has_j = j < r.j1, has_k = k < r.k1, has_in = ia + n - 1 < r.i1;   // a cell after the unit exists
-  double A[CH][5], S[CH][4], CR[CH], XAL[CH], DG[CH];
-  double p[5] = {0., 0., 0., 0., 0.};   // increment of the cell after the unit, final
-  if (has_in) {
-#pragma unroll
-    for (int e = 0; e < 5; e++) p[e] = dw[l0 + n + e * nd];
-  }
-#pragma unroll
-  for (int m = 0; m < CH; m++) {
-    if (m < n) {
-      const long long l = l0 + m, lt = lt0 + (FULL ? m : 0);
-      const double xal = coe[l] * -0.5;
-      const double c5 = coe[l + 4 * nd];
-      double b[5];
-#pragma unroll
-      for (int e = 0; e < 5; e++) A[m][e] = dw[l + e * nd] * c5;
-      if (has_k) { lu_neighbour<FULL, 2, -1>(z, c, l, lt, rop_kn, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
-      if (has_j) { lu_neighbour<FULL, 1, -1>(z, c, l, lt, rop, dw, coe, b); for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * xal; }
-      XAL[m] = xal;
-      DG[m] = 1. / c5;
-      if (m < n - 1 || has_in) {
-        S[m][0] = rop[l + 1 + nd]; S[m][1] = rop[l + 1 + 2 * nd]; S[m][2] = rop[l + 1 + 3 * nd]; S[m][3] = rop[l + 1 + 4 * nd];
-        CR[m] = coe[l + 1 + nd];
-      }
-    }
-  }
-#pragma unroll
-  for (int m = CH - 1; m >= 0; m--) {
-    if (m < n) {
-      if (m < n - 1 || has_in) {
-        double b[5];
-        lu_term<FULL, 0, -1>(z, c, lt0 + (FULL ? m : 0), S[m][0], S[m][1], S[m][2], S[m][3], p[0], p[1], p[2], p[3], p[4], CR[m], b);
-#pragma unroll
-        for (int e = 0; e < 5; e++) A[m][e] = A[m][e] + b[e] * XAL[m];
-      }
-#pragma unroll
-      for (int e = 0; e < 5; e++) { p[e] = A[m][e] * DG[m]; A[m][e] = p[e]; }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < CH; m++) {
-    if (m < n) {
-      const long long l = l0 + m;
-#pragma unroll
-      for (int e = 0; e < 5; e++) dw[l + e * nd] = A[m][e];
-      // Newton update (mjr_newton.for)
-      const double ro_old = rop[l], u_old = rop[l + nd], v_old = rop[l + 2 * nd], w_old = rop[l + 3 * nd];
-      const double t_old = rop[l + 4 * nd];
-      const double rn = ro_old + A[m][0];
-      const double r_1 = 1. / rn;
-      const double un = (ro_old * u_old + A[m][1]) * r_1;
-      const double vn = (ro_old * v_old + A[m][2]) * r_1;
-      const double wn = (ro_old * w_old + A[m][3]) * r_1;
-      const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
-      rop_new[l] = rn; rop_new[l + nd] = un; rop_new[l + 2 * nd] = vn; rop_new[l + 3 * nd] = wn;
-      rop_new[l + 4 * nd] = (roe_old + A[m][4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Wave-cooperative form of the chunked sweeps: a wave handles 8 units of 8 cells, lane = (unit, cell).
+// Sweeps over hyperplanes of (8-cell unit of an i-line, j, k): a wave handles 8 units of 8 cells, lane = (unit, cell).
 // The loads and the j/k neighbour terms are done one cell per lane (8 lanes read 64 contiguous bytes of
 // every array); the i recurrence then runs in 8 steps, the increment of cell m-1 reaching cell m through
 // a shuffle inside each group of 8 lanes.
@@ -606,74 +379,33 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
   LuRange r = {range[0], range[1], range[2], range[3], range[4], range[5]};
   const int ni = r.i1 - r.i0 + 1, nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
   if (ni < 1 || nj < 1 || nk < 1) return -1;
-  const int nh = ni + nj + nk - 2;
   const bool full = z.ityp == 0;
   const bool inplace = rop_out == rop;
   if (inplace && !scratch) return -1;
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
-  const unsigned gx = (unsigned)((nj + 63) / 64);
-  // FASTS_HIP_LU = cell | chunk selects the simpler forms of the sweeps (debugging aids)
-  static const bool per_cell = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "cell") == 0;
-  static const bool per_chunk = getenv("FASTS_HIP_LU") && strcmp(getenv("FASTS_HIP_LU"), "chunk") == 0;
   const bool sa = z.neq == 6;
-  if (sa || (!per_cell && !per_chunk)) {
-    const int nchunk = (ni + 7) / 8;
-    const int nhc = nchunk + nj + nk - 2;
-    const unsigned gx8 = (unsigned)((nj + 7) / 8);
-    for (int pass = 0; pass < 2; pass++)
-      for (int n = 0; n < nhc; n++) {
-        const int h = pass == 0 ? n : nhc - 1 - n;
-        int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
-        int khi = h < nk - 1 ? h : nk - 1;
-        dim3 g(gx8, (unsigned)(khi - klo + 1));
-        if (pass == 0) {
-          if (sa && full) hipLaunchKernelGGL((k_lu_lower_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-          else if (sa) hipLaunchKernelGGL((k_lu_lower_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-          else if (full) hipLaunchKernelGGL((k_lu_lower_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-          else hipLaunchKernelGGL((k_lu_lower_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-        } else {
-          if (sa && full) hipLaunchKernelGGL((k_lu_upper_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-          else if (sa) hipLaunchKernelGGL((k_lu_upper_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-          else if (full) hipLaunchKernelGGL((k_lu_upper_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-          else hipLaunchKernelGGL((k_lu_upper_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-        }
-      }
-  } else if (per_cell) {
-    for (int h = 0; h < nh; h++) {
-      // k values that can hold a cell of this plane
-      int klo = h - (ni - 1) - (nj - 1); if (klo < 0) klo = 0;
+  const int nchunk = (ni + 7) / 8;
+  const int nhc = nchunk + nj + nk - 2;
+  const unsigned gx8 = (unsigned)((nj + 7) / 8);
+  for (int pass = 0; pass < 2; pass++)
+    for (int n = 0; n < nhc; n++) {
+      const int h = pass == 0 ? n : nhc - 1 - n;
+      int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
       int khi = h < nk - 1 ? h : nk - 1;
-      dim3 g(gx, (unsigned)(khi - klo + 1));
-      if (full) hipLaunchKernelGGL((k_lu_lower<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
-      else hipLaunchKernelGGL((k_lu_lower<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, dw, coe);
-    }
-    for (int h = nh - 1; h >= 0; h--) {
-      int klo = h - (ni - 1) - (nj - 1); if (klo < 0) klo = 0;
-      int khi = h < nk - 1 ? h : nk - 1;
-      dim3 g(gx, (unsigned)(khi - klo + 1));
-      if (full) hipLaunchKernelGGL((k_lu_upper<true>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-      else hipLaunchKernelGGL((k_lu_upper<false>), g, dim3(64), 0, s, z, c, r, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-    }
-  } else {
-    constexpr int CH = 8;
-    const int nchunk = (ni + CH - 1) / CH;
-    const int nhc = nchunk + nj + nk - 2;
-    for (int pass = 0; pass < 2; pass++)
-      for (int n = 0; n < nhc; n++) {
-        const int h = pass == 0 ? n : nhc - 1 - n;
-        int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
-        int khi = h < nk - 1 ? h : nk - 1;
-        dim3 g(gx, (unsigned)(khi - klo + 1));
-        if (pass == 0) {
-          if (full) hipLaunchKernelGGL((k_lu_lower_chunk<true, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-          else hipLaunchKernelGGL((k_lu_lower_chunk<false, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-        } else {
-          if (full) hipLaunchKernelGGL((k_lu_upper_chunk<true, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-          else hipLaunchKernelGGL((k_lu_upper_chunk<false, CH>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-        }
+      dim3 g(gx8, (unsigned)(khi - klo + 1));
+      if (pass == 0) {
+        if (sa && full) hipLaunchKernelGGL((k_lu_lower_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+        else if (sa) hipLaunchKernelGGL((k_lu_lower_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+        else if (full) hipLaunchKernelGGL((k_lu_lower_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+        else hipLaunchKernelGGL((k_lu_lower_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+      } else {
+        if (sa && full) hipLaunchKernelGGL((k_lu_upper_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+        else if (sa) hipLaunchKernelGGL((k_lu_upper_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+        else if (full) hipLaunchKernelGGL((k_lu_upper_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+        else hipLaunchKernelGGL((k_lu_upper_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
       }
-  }
+    }
   if (inplace) {
     dim3 g((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
     hipLaunchKernelGGL(k_copy_range, g, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
