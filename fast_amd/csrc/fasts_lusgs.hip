@@ -200,10 +200,11 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
                                                       const double *__restrict__ coe)
 {
   const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
-  const int j = r.j0 + blockIdx.x * 8 + u, k = kbase + blockIdx.y;
-  const int cn = h - (j - r.j0) - (k - r.k0);
+  // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
+  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int j = r.j0 + h - cn - (k - r.k0);
   const int i = r.i0 + cn * 8 + m;
-  const bool active = j <= r.j1 && k <= r.k1 && cn >= 0 && cn < nchunk && i <= r.i1;
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
@@ -267,10 +268,11 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
                                                       const double *__restrict__ coe)
 {
   const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
-  const int j = r.j0 + blockIdx.x * 8 + u, k = kbase + blockIdx.y;
-  const int cn = h - (j - r.j0) - (k - r.k0);
+  // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
+  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int j = r.j0 + h - cn - (k - r.k0);
   const int i = r.i0 + cn * 8 + m;
-  const bool active = j <= r.j1 && k <= r.k1 && cn >= 0 && cn < nchunk && i <= r.i1;
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
@@ -387,7 +389,7 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
   const bool sa = z.neq == 6;
   const int nchunk = (ni + 7) / 8;
   const int nhc = nchunk + nj + nk - 2;
-  const unsigned gx8 = (unsigned)((nj + 7) / 8);
+  const unsigned gx8 = (unsigned)((nchunk + 7) / 8);
   for (int pass = 0; pass < 2; pass++)
     for (int n = 0; n < nhc; n++) {
       const int h = pass == 0 ? n : nhc - 1 - n;
