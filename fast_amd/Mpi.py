@@ -202,10 +202,19 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     ctx, names = FastS._new_context(zones, metrics, dtloc, device)
     ctx.set_first_it(FastC.FIRST_IT)
     native = getattr(tr, 'native', False)
-    plan = HaloPlan(FastS.joins_from_tc(t, tc), procDict, r, n,
+    flat = FastS.flat_tc(tc) if native else None
+    plan = HaloPlan([] if flat is not None else FastS.joins_from_tc(t, tc), procDict, r, n,
                     None if native else tr.all_gather_object, loopback)
-    messages = native and (n > 1 or bool(plan.sends))
-    if native:
+    messages = native and (n > 1 or bool(plan.sends) or (flat is not None and loopback))
+    if flat is not None:
+        # flattened connectivity: blocks for this rank become local joins, the others sends; the receiver zone
+        # numbers in the arrays are indices on the destination rank, so a zone's global id is its own index
+        for nd in names.values():
+            ctx.zone_set_global_id(nd, nd)
+        if messages:
+            tr.init(ctx)
+        ctx.joins_set(flat[0], flat[1], -1 if loopback else r)   # loopback: no block counts as local
+    elif native:
         for (rn, dn, rpts, dpts) in plan.local:
             ctx.join_add(names[rn], names[dn], rpts, dpts)
         if messages:
@@ -323,7 +332,7 @@ class tgv_job:
     Fast/FastS/test/tgvMpi.py:29-50; several per rank gives local joins next to the messages)."""
 
     def __init__(self, n, blocks, scheme, model, my_rank=None, world=None, local_rank_=None, time_step=None,
-                 transport=None, loopback=False, **case_options):
+                 transport=None, loopback=False, flat=False, **case_options):
         from . import cases, connect
         from . import pytree_lite as C
         my_rank = rank() if my_rank is None else my_rank
@@ -343,6 +352,12 @@ class tgv_job:
         joins = [j for j in connect.periodic_block_joins(blocks, (n, n, n)) if owner[j[1]] == my_rank]
         connect.add_joins_to_tc(self.tc, joins, names)
         self.graph = connect.graph_of(blocks, names, owner)
+        if flat:     # hand the joins over as the flattened connectivity arrays (tc/Parameter_int, tc/Parameter_real)
+            local = {names[b]: mine.index(b) for b in mine}
+            on_owner = {names[b]: b % per for b in range(nb)}
+            pint, preal = connect.flatten_joins(FastS.joins_from_tc(self.t, self.tc), local, self.graph['procDict'],
+                                                my_rank, on_owner)
+            connect.add_flat_to_tc(self.tc, pint, preal)
         self.blocks_here = mine
         (self.t, self.tc, self.metrics) = warmup(self.t, self.tc, self.graph, device=local_rank_,
                                                  transport=transport, loopback=loopback)

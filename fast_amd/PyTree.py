@@ -70,6 +70,18 @@ def joins_from_tc(t, tc):
     return out
 
 
+def flat_tc(tc):
+    """(Parameter_int, Parameter_real) of the connectivity tree when it carries the flat arrays
+    (Fast/FastS/FastS/PyTree.py:486-489), else None."""
+    if tc is None:
+        return None
+    pi = Internal.getNodeFromName1(tc, 'Parameter_int')
+    pr = Internal.getNodeFromName1(tc, 'Parameter_real')
+    if pi is None or pr is None or pi[1] is None or pr[1] is None:
+        return None
+    return (pi[1], pr[1])
+
+
 def _warmup_host(t, tc, Padding=None):
     """Host part of warmup: solver data, metrics, BC table, three compacted time levels."""
     FastC._reorder(t, tc)
@@ -125,13 +137,20 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     zones, metrics, dtloc = _warmup_host(t, tc, Padding)
     ctx, names = _new_context(zones, metrics, dtloc, device)
     ctx.set_first_it(FastC.FIRST_IT)     # 1 when the tree carries stored _M1 levels (restart): BDF2 from the first step
-    for (rn, dn, rpts, dpts) in joins_from_tc(t, tc):
-        if rn not in names or dn not in names:
-            raise ValueError("warmup: join %s <- %s refers to a zone that is not in t "
-                             "(zones on other ranks need fast_amd.Mpi.warmup)" % (rn, dn))
-        ctx.join_add(names[rn], names[dn], rpts, dpts)
+    flat = flat_tc(tc)
+    if flat is not None:
+        # flattened connectivity (what the reference's transfer routines read): every join in one native call
+        ctx.joins_set(flat[0], flat[1], 0)
+    else:
+        for (rn, dn, rpts, dpts) in joins_from_tc(t, tc):
+            if rn not in names or dn not in names:
+                raise ValueError("warmup: join %s <- %s refers to a zone that is not in t "
+                                 "(zones on other ranks need fast_amd.Mpi.warmup)" % (rn, dn))
+            ctx.join_add(names[rn], names[dn], rpts, dpts)
     ctx.upload()
-    _set_hook(ctx, dtloc, names)
+    hook = _set_hook(ctx, dtloc, names)
+    if flat is not None:
+        hook['param_int_tc'], hook['param_real_tc'] = flat
     # ghost cells of the initial field: joins, BCs, edges (Fast/FastS/FastS/PyTree.py:520-527)
     ctx.fill_ghostcells(_capi.FS_LEVEL_N)
     ctx.download(_capi.FS_LEVEL_N)

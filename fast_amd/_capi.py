@@ -19,7 +19,7 @@ SYMBOLS = [
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_tgv_sums_static", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
     "fs_comm_unique_id", "fs_comm_init", "fs_zone_set_global_id", "fs_send_add_remote", "fs_comm_setup", "fs_halo_exchange",
-    "fs_comm_allreduce",
+    "fs_comm_allreduce", "fs_joins_set",
 ]
 
 COMM_ID_BYTES = 128
@@ -165,6 +165,13 @@ class Context:
         self._chk(lib().fs_comm_allreduce(self._h, _pd(v), ctypes.c_int(v.size), ctypes.c_int({'sum': 0, 'max': 1, 'min': 2}[op])),
                   "fs_comm_allreduce")
         return v
+
+    def joins_set(self, pint_tc, preal_tc, rank=0):
+        """Every join of the flat connectivity arrays (tc/Parameter_int, tc/Parameter_real)."""
+        pi = numpy.ascontiguousarray(pint_tc, dtype=numpy.int32)
+        pr = numpy.ascontiguousarray(preal_tc, dtype=numpy.float64)
+        self._chk(lib().fs_joins_set(self._h, _pi(pi), ctypes.c_int(pi.size), _pd(pr), ctypes.c_int(pr.size),
+                                     ctypes.c_int(int(rank))), "fs_joins_set")
 
     def upload(self):
         self._chk(lib().fs_upload(self._h), "fs_upload")

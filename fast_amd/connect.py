@@ -156,3 +156,62 @@ def graph_of(blocks, zone_names, owner):
                     lst.append(zone_names[br])
     procList = [[zone_names[b] for b in range(nb) if owner[b] == r] for r in range(nranks)]
     return {'graphID': graphID, 'graphIBCD': {}, 'procDict': procDict, 'procList': procList}
+
+
+def flatten_joins(joins, zone_index, owner, rank=0, index_on_owner=None):
+    """tc/Parameter_int and tc/Parameter_real of a set of match joins, the flat layout the reference's transfer
+    routines read (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:114-118,220,469-478,522-528,646-653,748-758;
+    in the reference Cassiopee's miseAPlatDonorTree__ produces it from the ZoneSubRegion_t nodes of tc):
+
+        [0] 0 (not initialised)   [1] number of point-to-point blocks   [2] 0 (no IBC graph)   [3] 0 (no ID graph)
+        [4 ...] pointer of every block; a block = [destination rank, nrac, 0, 0] + 16 arrays of nrac entries (one
+        spare entry after the tenth) + 27 entries per rac (local time stepping levels, unused) + per rac the
+        donor points, the receiver points and the type table [1, npts, 1 x npts]; coefficients (1.) in Parameter_real.
+
+    joins = [(receiver zone name, donor zone name, receiver points, donor points)] with the donor on this rank;
+    zone_index = {name: index on this rank}; owner = {name: rank}; index_on_owner = {name: index on its own rank}
+    (default: zone_index).  One block per destination rank, this rank first."""
+    if index_on_owner is None:
+        index_on_owner = zone_index
+    by_dest = {}
+    for j in joins:
+        by_dest.setdefault(owner.get(j[0], rank) if owner else rank, []).append(j)
+    dests = sorted(by_dest, key=lambda d: (d != rank, d))
+    np2p = len(dests)
+    pint = [0, np2p, 0, 0] + [0] * np2p
+    preal = []
+    for n, d in enumerate(dests):
+        racs = by_dest[d]
+        nrac = len(racs)
+        ech = len(pint)
+        pint[4 + n] = ech
+        pint += [d, nrac, 0, 0]
+        base = len(pint)                       # shift_rac of irac 0
+        pint += [0] * (16 * nrac + 1 + 27 * nrac)
+        for irac, (rn, dn, rpts, dpts) in enumerate(racs):
+            rp = numpy.asarray(rpts, dtype=numpy.int32).ravel()
+            dp = numpy.asarray(dpts, dtype=numpy.int32).ravel()
+            if rp.size != dp.size:
+                raise ValueError("flatten_joins: join %s <- %s: lists differ in length" % (rn, dn))
+            sr = base + irac
+            pint[sr] = int(dp.size)                                  # donor points
+            pint[sr + nrac] = int(rp.size)                           # NbInterpD: coefficients of the rac
+            pint[sr + 3 * nrac] = -1                                 # ibcType < 0: interpolation data
+            pint[sr + 5 * nrac] = int(zone_index[dn])
+            pint[sr + 6 * nrac] = len(pint); pint += dp.tolist()
+            pint[sr + 7 * nrac] = len(pint); pint += [1, int(rp.size)] + [1] * int(rp.size)
+            pint[sr + 8 * nrac] = len(preal); preal += [1.] * int(rp.size)
+            pint[sr + 10 * nrac + 1] = int(rp.size)
+            pint[sr + 11 * nrac + 1] = int(index_on_owner[rn])
+            pint[sr + 12 * nrac + 1] = len(pint); pint += rp.tolist()
+            pint[sr + 13 * nrac + 1] = 5
+            pint[sr + 14 * nrac + 1] = 0
+    return numpy.array(pint, dtype=numpy.int32), numpy.array(preal if preal else [0.], dtype=numpy.float64)
+
+
+def add_flat_to_tc(tc, pint, preal):
+    """Store the flat arrays in the connectivity tree under the names the reference uses (tc/Parameter_int,
+    tc/Parameter_real, read back at Fast/FastS/FastS/PyTree.py:107,488)."""
+    Internal.createUniqueChild(tc, 'Parameter_int', 'DataArray_t', pint)
+    Internal.createUniqueChild(tc, 'Parameter_real', 'DataArray_t', preal)
+    return tc

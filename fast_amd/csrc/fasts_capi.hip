@@ -1188,3 +1188,72 @@ extern "C" int fs_send_add_remote(fs_ctx *ctx, int donor_zone, int peer_rank, co
   ctx->sends.back().rcv_host.assign(rcv_pts, rcv_pts + npts);
   return FS_OK;
 }
+
+// ---- joins from the flat connectivity arrays ------------------------------------------------------------------------
+// tc/Parameter_int and tc/Parameter_real as the reference reads them (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp):
+//   [0] initialised flag, [1] number of point-to-point blocks, [2] sizecomIBC + that many entries, then sizecomID + that
+//   many entries (:114-118); the pointer `ech` of block ip2p = 1.. sits at [ip2p + sizecomIBC + sizecomID + 3] (:220);
+//   a block: [ech] destination rank, [ech+1] nrac, [ech+2] nrac_inst, [ech+3] timelevel, 2*timelevel entries, then
+//   arrays of nrac entries read at shift_rac + nrac*k, shift_rac = ech + 4 + 2*timelevel + irac (:474-478,522-528):
+//   k = 1 NbInterpD, 3 ibcType (< 0: interpolation data, no immersed boundary), 5 donor zone, 6 -> donor points,
+//   7 -> [ntype, counts..., types...], 8 -> coefficients (Parameter_real), and one entry further on 10 receiver
+//   points count, 11 receiver zone, 12 -> receiver points, 13 nvars, 14 rotation (:646-653,748-758).
+// Only what a match join needs is accepted: steady racs, ibcType < 0, types 0 / 1 with unit coefficients, no rotation.
+extern "C" int fs_joins_set(fs_ctx *ctx, const int32_t *pint_tc, int n_int, const double *preal_tc, int n_real, int rank)
+{
+  if (!ctx) return FS_ERR_ARG;
+  if (!pint_tc || !preal_tc || n_int < 4) return fail(ctx, FS_ERR_ARG, "fs_joins_set: bad argument");
+  if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_joins_set: call before fs_upload");
+  auto at = [&](long long i, int &v) { if (i < 0 || i >= n_int) return false; v = pint_tc[i]; return true; };
+  int np2p, szibc, szid;
+  if (!at(1, np2p) || !at(2, szibc) || szibc < 0 || !at(3 + (long long)szibc, szid) || szid < 0)
+    return fail(ctx, FS_ERR_ARG, "fs_joins_set: truncated header");
+  const long long shift_graph = (long long)szibc + szid + 3;
+  const int nz = (int)ctx->zones.size();
+  for (int ip2p = 1; ip2p <= np2p; ip2p++) {
+    int ech, dest, nrac, nrac_inst, timelevel;
+    if (!at(ip2p + shift_graph, ech) || !at(ech, dest) || !at((long long)ech + 1, nrac) || !at((long long)ech + 2, nrac_inst) ||
+        !at((long long)ech + 3, timelevel) || nrac < 0 || timelevel < 0)
+      return fail(ctx, FS_ERR_ARG, "fs_joins_set: truncated point-to-point block");
+    if (nrac_inst != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_joins_set: unsteady joins (nrac_inst > 0) are not supported");
+    for (int irac = 0; irac < nrac; irac++) {
+      const long long sr = (long long)ech + 4 + 2LL * timelevel + irac;
+      int ninterp, ibctype, nod, pdon, ptyp, pcoef, nrcv, nor, prcv, nvars, rot;
+      if (!at(sr + nrac, ninterp) || !at(sr + 3LL * nrac, ibctype) || !at(sr + 5LL * nrac, nod) || !at(sr + 6LL * nrac, pdon) ||
+          !at(sr + 7LL * nrac, ptyp) || !at(sr + 8LL * nrac, pcoef) || !at(sr + 10LL * nrac + 1, nrcv) ||
+          !at(sr + 11LL * nrac + 1, nor) || !at(sr + 12LL * nrac + 1, prcv) || !at(sr + 13LL * nrac + 1, nvars) ||
+          !at(sr + 14LL * nrac + 1, rot))
+        return fail(ctx, FS_ERR_ARG, "fs_joins_set: truncated rac table");
+      if (ibctype >= 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_joins_set: immersed-boundary racs are not supported");
+      if (rot != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_joins_set: azimuthal periodicity (rotation) is not supported");
+      if (nvars != 5 && nvars != 6) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_joins_set: only 5 or 6 variables per point");
+      if (nrcv <= 0 || pdon < 0 || prcv < 0 || ptyp < 0 || (long long)pdon + nrcv > n_int || (long long)prcv + nrcv > n_int)
+        return fail(ctx, FS_ERR_ARG, "fs_joins_set: point lists outside the array");
+      if (nod < 0 || nod >= nz) return fail(ctx, FS_ERR_ARG, "fs_joins_set: donor zone index outside the zones of the context");
+      // interpolation types: [ntype, points per type..., type of every point]; a match join copies one donor
+      int ntype;
+      if (!at(ptyp, ntype) || ntype < 1 || (long long)ptyp + 1 + ntype + nrcv > n_int)
+        return fail(ctx, FS_ERR_ARG, "fs_joins_set: type table outside the array");
+      long long tot = 0;
+      for (int t = 0; t < ntype; t++) tot += pint_tc[ptyp + 1 + t];
+      if (tot != nrcv) return fail(ctx, FS_ERR_ARG, "fs_joins_set: type counts do not add up to the number of points");
+      const int32_t *types = pint_tc + ptyp + 1 + ntype;
+      for (int i = 0; i < nrcv; i++)
+        if (types[i] != 0 && types[i] != 1) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_joins_set: only match joins (one donor per point)");
+      if (ninterp != nrcv || pcoef < 0 || (long long)pcoef + ninterp > n_real)
+        return fail(ctx, FS_ERR_ARG, "fs_joins_set: coefficient list outside the array");
+      for (int i = 0; i < ninterp; i++)
+        if (preal_tc[pcoef + i] != 1.) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_joins_set: only match joins (unit coefficients)");
+      int rc;
+      if (dest == rank) {
+        if (nor < 0 || nor >= nz) return fail(ctx, FS_ERR_ARG, "fs_joins_set: receiver zone index outside the zones of the context");
+        rc = fs_join_add(ctx, nor, nod, pint_tc + prcv, pint_tc + pdon, nrcv);
+      } else {
+        // receiver zone = its index on the destination rank, as the reference ships it (setInterpTransfersFast.cpp:1185-1206)
+        rc = fs_send_add_remote(ctx, nod, dest, pint_tc + pdon, nor, pint_tc + prcv, nrcv);
+      }
+      if (rc) return rc;
+    }
+  }
+  return FS_OK;
+}

@@ -116,6 +116,15 @@ int fs_join_add(fs_ctx *ctx, int rcv_zone, int donor_zone, const int32_t *rcv_pt
  * (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:944-1582). */
 int fs_send_add(fs_ctx *ctx, int donor_zone, int peer_tag, const int32_t *donor_pts, int npts);
 
+/* All joins at once from the flat connectivity arrays tc/Parameter_int and tc/Parameter_real, in the layout
+ * K_FASTC::setInterpTransfersIntra / Inter read (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:114-118,220,
+ * 469-478,522-528,646-653,748-758): blocks whose destination is `rank` become local joins (fs_join_add), the others
+ * sends to that rank (fs_send_add_remote; the receiver zone number in the arrays is the zone's index on the
+ * destination rank, so every rank gives its zones their own index as global id).  Zone numbers are the indices
+ * fs_zone_add returned.  Accepted: steady match joins (one donor per point, unit coefficient, 5 or 6 variables, no
+ * rotation, no immersed boundary); anything else returns FS_ERR_UNSUPPORTED.  Call before fs_upload. */
+int fs_joins_set(fs_ctx *ctx, const int32_t *pint_tc, int n_int, const double *preal_tc, int n_real, int rank);
+
 /* Host -> device copy of the three time levels of every zone; allocates device storage on
  * first call. */
 int fs_upload(fs_ctx *ctx);

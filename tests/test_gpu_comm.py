@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 SINGLE = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
 
 
-def _run(n, blocks, model, loopback, nsteps, opts):
-    job = FastSmpi.tgv_job(n, blocks, 'senseur', model, 0, 1, 0, loopback=loopback, extra_numz=SINGLE, **opts)
+def _run(n, blocks, model, loopback, nsteps, opts, flat=False):
+    job = FastSmpi.tgv_job(n, blocks, 'senseur', model, 0, 1, 0, loopback=loopback, flat=flat, extra_numz=SINGLE, **opts)
     assert bool(FastC.HOOK['messages']) == loopback
     first = [FastC.level_buffer(z).copy() for z in job.zones]
     for it in range(1, nsteps + 1):
@@ -42,6 +42,15 @@ def test_self_send_matches_local_joins(blocks, n, model, opts):
     assert np.array_equal(job.ctx.allreduce([3., -4.], 'sum'), [3., -4.])
     if 'perturb' not in opts:      # the diagnostics are those of Cartesian zones
         assert np.isfinite(FastSmpi._computeEnstrophy(job.t, job.metrics)).all()
+    job.ctx.close()
+
+
+def test_self_send_from_the_flat_connectivity():
+    """The same, the joins handed over as tc/Parameter_int / Parameter_real (fs_joins_set: no block is local)."""
+    _, first_l, last_l = _run(10, (2, 1, 2), 'NSLaminar', False, 3, {})
+    job, first_m, last_m = _run(10, (2, 1, 2), 'NSLaminar', True, 3, {}, flat=True)
+    for a, b in zip(first_l + last_l, first_m + last_m):
+        assert np.array_equal(a, b)
     job.ctx.close()
 
 

@@ -35,7 +35,7 @@ def _oracle_job(nn, blocks, scheme, model):
     ((2, 2, 1), (12, 12, 7), 'ausmpred', 'NSLaminar'),
     ((2, 2, 2), (132, 8, 8), 'senseur', 'Euler'),          # blocks wider than one 64-cell tile
 ])
-@pytest.mark.parametrize("layer", ["c", "Python"])
+@pytest.mark.parametrize("layer", ["c", "Python", "flat"])
 def test_local_joins_bit_exact(blocks, nn, scheme, model, layer):
     s = _oracle_job(nn, blocks, scheme, model)
     t = cases.tgv(nn, scheme, model=model, blocks=blocks, extra_numz=SINGLE)
@@ -43,6 +43,10 @@ def test_local_joins_bit_exact(blocks, nn, scheme, model, layer):
     nv = tuple(nn[d] // blocks[d] for d in range(3))
     tc = C.node2Center(t)
     connect.add_joins_to_tc(tc, connect.periodic_block_joins(blocks, nv), [z[0] for z in zones])
+    if layer == "flat":      # the same joins through the flattened connectivity arrays and fs_joins_set
+        index = {z[0]: n for n, z in enumerate(zones)}
+        connect.add_flat_to_tc(tc, *connect.flatten_joins(FastS.joins_from_tc(t, tc), index, None))
+        layer = "c"
     (t, tc, metrics) = FastS.warmup(t, tc)
     zones = Internal.getZones(t)
     for z, oz in zip(zones, s.zones):
@@ -136,3 +140,33 @@ def test_two_contexts_exchange_through_the_split_calls(blocks, nn, split):
         ctxs[0].compute(4, 1, 3, 1)      # joins to another context need the split calls
     for c in ctxs:
         c.close()
+
+
+def test_flat_connectivity_is_validated():
+    """fs_joins_set refuses what a match join cannot be, and arrays that end early, with a message."""
+    nn, blocks = (8, 8, 16), (1, 1, 2)
+    t = cases.tgv(nn, 'senseur', blocks=blocks, extra_numz=SINGLE)
+    zones = Internal.getZones(t)
+    tc = C.node2Center(t)
+    connect.add_joins_to_tc(tc, connect.periodic_block_joins(blocks, (8, 8, 8)), [z[0] for z in zones])
+    index = {z[0]: n for n, z in enumerate(zones)}
+    pint, preal = connect.flatten_joins(FastS.joins_from_tc(t, tc), index, None)
+    zs, metrics, dtloc = FastS._warmup_host(t, None)
+
+    def fresh():
+        ctx, _ = FastS._new_context(zs, metrics, dtloc, 0)
+        return ctx
+
+    ctx = fresh(); ctx.joins_set(pint, preal, 0); ctx.upload(); ctx.close()
+    bad = preal.copy(); bad[3] = 0.5                      # an interpolation weight: not a match join
+    with pytest.raises(_capi.FastsHipError, match="unit coefficients"):
+        fresh().joins_set(pint, bad, 0)
+    with pytest.raises(_capi.FastsHipError, match="outside|truncated"):
+        fresh().joins_set(pint[:pint.size // 2], preal, 0)
+    ech = int(pint[4]); nrac = int(pint[ech + 1])
+    ibc = pint.copy(); ibc[ech + 4 + 3 * nrac] = 2        # ibcType >= 0: immersed boundary rac
+    with pytest.raises(_capi.FastsHipError, match="immersed"):
+        fresh().joins_set(ibc, preal, 0)
+    far = pint.copy(); far[ech + 4 + 5 * nrac] = 7        # donor zone that does not exist
+    with pytest.raises(_capi.FastsHipError, match="donor zone"):
+        fresh().joins_set(far, preal, 0)

@@ -216,3 +216,39 @@ def test_split_faces_carry_no_bc():
     pt = int(p[FastC.PT_BC])
     dirs = sorted(int(p[int(p[pt + 1 + n]) + 1]) for n in range(int(p[pt])))
     assert dirs == [1, 2, 5, 6]
+
+
+def test_flat_connectivity_layout_reads_back():
+    """connect.flatten_joins lays the joins out so that the reference's reads
+    (Fast/FastC/FastC/Com/setInterpTransfersFast.cpp:114-118,220,474-478,646-653,748-758) find them again."""
+    import numpy as np
+    from fast_amd import connect
+    blocks, nv = (1, 2, 2), (4, 3, 5)
+    names = ['cart%d' % b for b in range(4)]
+    owner = {names[b]: b // 2 for b in range(4)}
+    joins = [(names[br], names[bd], r, d) for br, bd, r, d in connect.periodic_block_joins(blocks, nv) if owner[names[bd]] == 1]
+    pint, preal = connect.flatten_joins(joins, {'cart2': 0, 'cart3': 1}, owner, 1, {n: int(n[4:]) % 2 for n in names})
+    assert pint[0] == 0 and pint[2] == 0 and pint[3] == 0
+    shift_graph = pint[2] + pint[3 + pint[2]] + 3
+    seen = []
+    for ip2p in range(1, pint[1] + 1):
+        ech = pint[ip2p + shift_graph]
+        dest, nrac, nrac_inst, timelevel = pint[ech:ech + 4]
+        assert nrac_inst == 0 and timelevel == 0
+        for irac in range(nrac):
+            sr = ech + 4 + 2 * timelevel + irac
+            assert pint[sr + nrac * 3] < 0
+            nod, nor = pint[sr + nrac * 5], pint[sr + nrac * 11 + 1]
+            n = pint[sr + nrac * 10 + 1]
+            don = pint[pint[sr + nrac * 6]:][:n]; rcv = pint[pint[sr + nrac * 12 + 1]:][:n]
+            pos = pint[sr + nrac * 7]; ntype = pint[pos]
+            types = pint[pos + 1 + ntype:][:n]
+            assert ntype == 1 and pint[pos + 1] == n and (types == 1).all()
+            assert (preal[pint[sr + nrac * 8]:][:pint[sr + nrac]] == 1.).all()
+            assert pint[sr + nrac * 13 + 1] == 5 and pint[sr + nrac * 14 + 1] == 0
+            seen.append((int(dest), int(nor), int(nod), rcv.copy(), don.copy()))
+    assert [s[0] for s in seen] == sorted([s[0] for s in seen], key=lambda d: (d != 1, d))     # this rank's block first
+    want = [(owner[rn], int(rn[4:]) % 2, int(dn[4:]) % 2, r, d) for rn, dn, r, d in joins]
+    assert len(seen) == len(want)
+    for s in seen:
+        assert any(s[:3] == w[:3] and np.array_equal(s[3], w[3]) and np.array_equal(s[4], w[4]) for w in want)
