@@ -180,6 +180,12 @@ def main():
     el = time.perf_counter() - t0
     el = float(FastSmpi.allreduce([el], 'max')[0])
     k_ms, k_n = ctx.stage_kernel_ms(reset=False)
+    triad = None
+    if rank == 0:
+        try:
+            triad = ctx.stream_triad(1 << 27, 20)
+        except Exception:
+            triad = None
 
     # sanity: the field must still be finite
     ctx.download(1)
@@ -217,7 +223,9 @@ def main():
                                        "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit if a.implicit else "explicit RK3"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n},
+                         "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n,
+                         # what a plain streaming kernel reaches on this device, measured in this run (3 x 1 GiB triad)
+                         "stream_triad": triad, "frac_of_stream_triad": ach / triad if triad else None},
         }
         if not a.no_cpu and world == 1:
             try:

@@ -19,7 +19,7 @@ SYMBOLS = [
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_tgv_sums_static", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
     "fs_comm_unique_id", "fs_comm_init", "fs_zone_set_global_id", "fs_send_add_remote", "fs_comm_setup", "fs_halo_exchange",
-    "fs_comm_allreduce", "fs_joins_set",
+    "fs_comm_allreduce", "fs_joins_set", "fs_stream_triad",
 ]
 
 COMM_ID_BYTES = 128
@@ -253,6 +253,13 @@ class Context:
 
     def sync(self):
         self._chk(lib().fs_sync(self._h), "fs_sync")
+
+    def stream_triad(self, n_doubles=1 << 27, reps=20):
+        """GB/s of a = b + s*c over three arrays of n_doubles doubles on this context's device."""
+        g = ctypes.c_double(0.)
+        self._chk(lib().fs_stream_triad(self._h, ctypes.c_longlong(int(n_doubles)), ctypes.c_int(int(reps)), ctypes.byref(g)),
+                  "fs_stream_triad")
+        return g.value
 
     def stage_kernel_ms(self, reset=False):
         avg = ctypes.c_double(0.); n = ctypes.c_int(0)

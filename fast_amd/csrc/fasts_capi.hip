@@ -1132,6 +1132,38 @@ extern "C" int fs_sync(fs_ctx *ctx)
   return FS_OK;
 }
 
+// Streaming rate of the device this context runs on: triad a = b + s*c over three arrays of n doubles, timed with HIP
+// events over `reps` launches after one warm-up launch; *gbs = 24 n reps / time.  Allocates and frees its arrays.
+extern "C" int fs_stream_triad(fs_ctx *ctx, long long n_doubles, int reps, double *gbs)
+{
+  if (!ctx) return FS_ERR_ARG;
+  if (!gbs || n_doubles < 1024 || n_doubles % 2 || reps < 1) return fail(ctx, FS_ERR_ARG, "fs_stream_triad: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double *a = nullptr, *b = nullptr, *c = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = FS_OK;
+  const size_t nb = sizeof(double) * (size_t)n_doubles;
+  if (hipMalloc(&a, nb) != hipSuccess || hipMalloc(&b, nb) != hipSuccess || hipMalloc(&c, nb) != hipSuccess ||
+      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    rc = fail(ctx, FS_ERR_HIP, "fs_stream_triad: allocation failed");
+  if (!rc) {
+    (void)hipMemsetAsync(b, 0, nb, ctx->stream); (void)hipMemsetAsync(c, 0, nb, ctx->stream);
+    fsk_triad(n_doubles, a, b, c, 0.5, ctx->stream);
+    (void)hipEventRecord(e0, ctx->stream);
+    for (int r = 0; r < reps; r++) fsk_triad(n_doubles, a, b, c, 0.5, ctx->stream);
+    (void)hipEventRecord(e1, ctx->stream);
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f)
+      rc = fail(ctx, FS_ERR_HIP, "fs_stream_triad: timing failed");
+    else
+      *gbs = 24. * (double)n_doubles * reps / (ms * 1e-3) / 1e9;
+  }
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  return rc;
+}
+
 extern "C" int fs_stage_kernel_ms(fs_ctx *ctx, int reset, double *avg_ms, int *n_launch)
 {
   if (!ctx) return FS_ERR_ARG;

@@ -74,6 +74,8 @@ void fsk_cfl(const FsZone &z, double gam1, double gam2, const double *rop, const
              hipStream_t s);
 // kinetic energy / enstrophy sums of a Cartesian zone added to out[3] = {enstrophy, kinetic energy, volume};
 // part = 2 doubles per (j,k) row of scratch
+// a[i] = b[i] + s * c[i] over n doubles, 16 bytes per lane: the streaming ceiling a memory-bound kernel is held against
+void fsk_triad(long long n, double *a, const double *b, const double *c, double s, hipStream_t st);
 void fsk_tgv_sums(const FsZone &z, const double *rop, double *part, double *out, hipStream_t s);
 // implicit scheme (fasts_lusgs.hip)
 void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, double gamma, double prandtl, double rgp,

@@ -709,3 +709,34 @@ void fsk_tgv_sums(const FsZone &z, const double *rop, double *part, double *out,
   hipLaunchKernelGGL(k_tgv_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv,
                      (double)((long long)z.iv * z.jv * z.kv) * z.vol0, part, out);
 }
+
+// ---- streaming ceiling ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_triad(long long n2, double2 *__restrict__ a, const double2 *__restrict__ b,
+                                               const double2 *__restrict__ c, double s)
+{
+  // four 16-byte loads of each input in flight per lane, many short workgroups: the shape that streamed fastest on
+  // MI355X among those tried (profiles/triad_sweep.hip)
+  constexpr int U = 4;
+  const long long stride = (long long)gridDim.x * blockDim.x * U;
+  for (long long i0 = (long long)blockIdx.x * blockDim.x * U + threadIdx.x; i0 < n2; i0 += stride) {
+    double2 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long long i = i0 + u * 256;
+      if (i < n2) { x[u] = b[i]; y[u] = c[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long long i = i0 + u * 256;
+      if (i < n2) a[i] = make_double2(x[u].x + s * y[u].x, x[u].y + s * y[u].y);
+    }
+  }
+}
+
+void fsk_triad(long long n, double *a, const double *b, const double *c, double s, hipStream_t st)
+{
+  const long long n2 = n / 2;
+  long long g = (n2 + 1023) / 1024;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(k_triad, dim3((unsigned)g), dim3(256), 0, st, n2, (double2 *)a, (const double2 *)b, (const double2 *)c, s);
+}

@@ -249,6 +249,11 @@ int fs_tgv_sums_static(fs_ctx *ctx, int level, double *dev_sums);
 /* Block until everything enqueued on the context's stream has finished. */
 int fs_sync(fs_ctx *ctx);
 
+/* Measurement aid without a counterpart in the reference: streaming rate (GB/s) of the context's device on a triad
+ * a = b + s*c over three arrays of n_doubles (even) doubles, HIP events over `reps` launches.  The ceiling the
+ * memory-bound stage kernel is held against next to the 8 TB/s of the data sheet.  Allocates and frees 24 n bytes. */
+int fs_stream_triad(fs_ctx *ctx, long long n_doubles, int reps, double *gbs);
+
 /* Average device time in milliseconds of the stage kernel (RHS + update) launches since the
  * last call with reset != 0; measured with HIP events on the launch stream.  *n_launch
  * receives the number of launches averaged. */
