@@ -86,7 +86,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
     if (zn.ev_lu_fork) (void)hipEventDestroy(zn.ev_lu_fork);
     if (zn.ev_lu_join) (void)hipEventDestroy(zn.ev_lu_join);
@@ -174,8 +174,10 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   const bool implicit = p[ITYPCP] == 1;
   if (!ctx->zones.empty() && implicit != ctx->implicit)
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: explicit and implicit zones cannot share a context");
-  if (implicit && (p[NB_RELAX] != 1 || p[LU_MATCH] != 0 || p[IMPLICITSOLVER] != 0))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme is LU-SGS with nb_relax = 1 and lu_match = 0 (no SSOR relaxation, no overlap, no GMRES)");
+  if (implicit && (p[NB_RELAX] < 1 || p[LU_MATCH] != 0 || p[IMPLICITSOLVER] != 0))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme is LU-SGS / LU-SSOR with lu_match = 0 (no overlap, no GMRES)");
+  if (implicit && p[NB_RELAX] > 1 && (p[NEQ] != 5 || twod))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: SSOR relaxations (nb_relax > 1) are implemented for 5 equations on three-dimensional zones");
   const bool sa = p[IFLOW] == 3 && p[NEQ] == 6;
   if (!sa && (p[NEQ] != 5 || p[IFLOW] > 2)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: governing equations must be Euler, NSLaminar or NSTurbulent (Spalart-Allmaras)");
   if (sa && (p[47] > 1 || p[SA_DIST] != 1))
@@ -423,7 +425,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
       return fail(ctx, FS_ERR_HIP, std::string("fs_zone_add: metric upload: ") + hipGetErrorString(e));
     }
     z.mt[0] = zn.mtr_dev; z.mt[1] = zn.mtr_dev + 3 * z.ndm; z.mt[2] = zn.mtr_dev + 6 * z.ndm;
@@ -527,6 +529,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
       if (ctx->implicit) {
         HIPCHK(ctx, hipMalloc(&zn.scratch, nb));
         HIPCHK(ctx, hipMemsetAsync(zn.scratch, 0, nb, ctx->stream));
+        if (zn.pint[NB_RELAX] > 1) {   // increments and accumulator of the SSOR relaxations (Compute/ssor.cpp)
+          HIPCHK(ctx, hipMalloc(&zn.ssor_work, 2 * nb));
+          HIPCHK(ctx, hipMemsetAsync(zn.ssor_work, 0, 2 * nb, ctx->stream));
+        }
       }
       HIPCHK(ctx, hipMalloc(&zn.res_part, sizeof(double) * 12 * (size_t)zn.z.jv * zn.z.kv));
       HIPCHK(ctx, hipMalloc(&zn.res_out, sizeof(double) * (12 * (size_t)zn.z.nssiter + 3)));
@@ -801,7 +807,11 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
         HIPCHK(ctx, hipEventRecord(zn.ev_lu_fork, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ls, zn.ev_lu_fork, 0));
       }
-      const int lrc = fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
+      const int sdm[6] = {1, z.iv, 1, z.jv, 1, z.kv};
+      const int lrc = zn.pint[NB_RELAX] > 1
+                          ? fsk_lussor(z, zn.lu, sdm, zn.pint[NB_RELAX], zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch,
+                                       zn.drodm, zn.ssor_work, zn.coe, ls)
+                          : fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
       if (ctx->lu_nstreams > 0) {
         HIPCHK(ctx, hipEventRecord(zn.ev_lu_join, ls));
         lu_joins.push_back(zn.ev_lu_join);

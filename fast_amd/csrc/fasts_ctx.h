@@ -17,6 +17,7 @@ struct Zone {
   double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]
   // implicit scheme: coe(nd,5) = dt/vol, spectral radii i/j/k, LU diagonal; one spare time level
   double *coe = nullptr, *scratch = nullptr;
+  double *ssor_work = nullptr;   // nb_relax > 1: increments and accumulator of the SSOR relaxations, 2 * neq * nd
   double *dist = nullptr;      // SA model: wall distance of every cell (fs_zone_set_distance)
   const double *dist_host = nullptr;
   // implicit scheme with wall BCs: windows applied to the Newton residual before the LU solve (whole-face

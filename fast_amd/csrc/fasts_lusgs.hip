@@ -343,6 +343,177 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// LU-SSOR, nb_relax >= 2 relaxations (LU/invlu.for:195-340, invlussor1_l.for, invlussor_l.for, invlussor_u.for),
+// 5 equations, three-dimensional zones.  Same hyperplanes and the same lane layout as the sweeps above.  Per cell
+// and sweep the neighbour terms are added in the order i, j, k to the increment (din = right-hand side, kept; dout
+// = increments) and to the accumulator ssor (mjr_drodm_IO_ssor.for, mjr_drodm_ssor.for), then the increment is
+// divided by the diagonal (lu_dinv.for).  FIRSTM: first lower sweep, the increment starts from din.  Between two
+// sweeps k_ssor_reset puts din + ssor into dout and zeroes ssor (mjr_ssor.for; the reference does it one plane
+// behind the sweep, when every successor of a cell has read its increment: after the sweep is the same).
+// LAST: last upper sweep, followed by the Newton update of the cells inside sdm (mjr_newton.for).
+// ------------------------------------------------------------------------------------------------------
+template <bool FULL, bool FIRSTM>
+__global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+                                                        const double *__restrict__ rop, const double *__restrict__ din,
+                                                        double *__restrict__ dout, double *__restrict__ ssor,
+                                                        const double *__restrict__ coe)
+{
+  constexpr int NE = 5;
+  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
+  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int j = r.j0 + h - cn - (k - r.k0);
+  const int i = r.i0 + cn * 8 + m;
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
+  const long long nd = z.nd;
+  const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
+  const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
+  const bool has_prev = active && i > r.i0;
+  const bool has_j = active && j > r.j0, has_k = active && k > r.k0;
+  double A[NE] = {}, S[NE] = {}, P[NE] = {}, BJ[NE] = {}, BK[NE] = {}, ST[4] = {0., 0., 0., 0.};
+  double CR = 0., XAL = 0., DG = 0.;
+  if (active) {
+    XAL = coe[l] * 0.5;
+    double b[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) { A[e] = FIRSTM ? din[l + e * nd] : dout[l + e * nd]; S[e] = FIRSTM ? 0. : ssor[l + e * nd]; }
+    if (has_j) { lu_neighbour<FULL, 1, 1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BJ[e] = b[e] * XAL; }
+    if (has_k) { lu_neighbour<FULL, 2, 1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BK[e] = b[e] * XAL; }
+    DG = 1. / coe[l + 4 * nd];
+    if (has_prev) {
+      ST[0] = rop[l - 1 + nd]; ST[1] = rop[l - 1 + 2 * nd]; ST[2] = rop[l - 1 + 3 * nd]; ST[3] = rop[l - 1 + 4 * nd];
+      CR = coe[l - 1 + nd];
+      if (m == 0) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) P[e] = dout[l - 1 + e * nd];
+      }
+    }
+  }
+  for (int st = 0; st < 8; st++) {
+    double pin[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+      const double up = __shfl_up(P[e], 1, 8);
+      pin[e] = m == 0 ? P[e] : up;
+    }
+    if (m == st && active) {
+      bool any = false;
+      if (has_prev) {
+        double b[NE];
+        lu_term<FULL, 0, 1, NE>(z, c, lt, ST[0], ST[1], ST[2], ST[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+#pragma unroll
+        for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = FIRSTM ? t : S[e] + t; }
+        any = true;
+      }
+      if (has_j) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) { A[e] = A[e] + BJ[e]; S[e] = (FIRSTM && !any) ? BJ[e] : S[e] + BJ[e]; }
+        any = true;
+      }
+      if (has_k) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = (FIRSTM && !any) ? BK[e] : S[e] + BK[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < NE; e++) P[e] = A[e] * DG;
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < NE; e++) { dout[l + e * nd] = P[e]; ssor[l + e * nd] = S[e]; }
+  }
+}
+
+template <bool FULL, bool LAST>
+__global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuRange r, LuRange sdm, int nchunk, int h, int kbase,
+                                                        const double *__restrict__ rop, const double *rop_kn, double *rop_new,
+                                                        double *__restrict__ dout, double *__restrict__ ssor,
+                                                        const double *__restrict__ coe)
+{
+  constexpr int NE = 5;
+  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
+  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int j = r.j0 + h - cn - (k - r.k0);
+  const int i = r.i0 + cn * 8 + m;
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
+  const long long nd = z.nd;
+  const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
+  const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
+  const bool has_next = active && i < r.i1;
+  const bool has_j = active && j < r.j1, has_k = active && k < r.k1;
+  const bool last_of_unit = m == 7 || i == r.i1;
+  double A[NE] = {}, S[NE] = {}, P[NE] = {}, BJ[NE] = {}, BK[NE] = {}, ST[4] = {0., 0., 0., 0.};
+  double CR = 0., XAL = 0., DG = 0.;
+  double q[NE] = {1., 0., 0., 0., 1.};
+  if (active) {
+    XAL = coe[l] * -0.5;
+    double b[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) { A[e] = dout[l + e * nd]; S[e] = ssor[l + e * nd]; q[e] = rop[l + e * nd]; }
+    if (has_j) { lu_neighbour<FULL, 1, -1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BJ[e] = b[e] * XAL; }
+    if (has_k) { lu_neighbour<FULL, 2, -1, NE>(z, c, l, lt, LAST ? rop_kn : rop, dout, coe, b); for (int e = 0; e < NE; e++) BK[e] = b[e] * XAL; }
+    DG = 1. / coe[l + 4 * nd];
+    if (has_next) {
+      ST[0] = rop[l + 1 + nd]; ST[1] = rop[l + 1 + 2 * nd]; ST[2] = rop[l + 1 + 3 * nd]; ST[3] = rop[l + 1 + 4 * nd];
+      CR = coe[l + 1 + nd];
+      if (last_of_unit) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) P[e] = dout[l + 1 + e * nd];
+      }
+    }
+  }
+  for (int st = 7; st >= 0; st--) {
+    double pin[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+      const double dn = __shfl_down(P[e], 1, 8);
+      pin[e] = last_of_unit ? P[e] : dn;
+    }
+    if (m == st && active) {
+      if (has_next) {
+        double b[NE];
+        lu_term<FULL, 0, -1, NE>(z, c, lt, ST[0], ST[1], ST[2], ST[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+#pragma unroll
+        for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = S[e] + t; }
+      }
+      if (has_j) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) { A[e] = A[e] + BJ[e]; S[e] = S[e] + BJ[e]; }
+      }
+      if (has_k) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = S[e] + BK[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < NE; e++) P[e] = A[e] * DG;
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < NE; e++) { dout[l + e * nd] = P[e]; ssor[l + e * nd] = S[e]; }
+    if (LAST && i >= sdm.i0 && i <= sdm.i1 && j >= sdm.j0 && j <= sdm.j1 && k >= sdm.k0 && k <= sdm.k1) {
+      const double ro_old = q[0], u_old = q[1], v_old = q[2], w_old = q[3], t_old = q[4];
+      const double rn = ro_old + P[0];
+      const double r_1 = 1. / rn;
+      const double un = (ro_old * u_old + P[1]) * r_1;
+      const double vn = (ro_old * v_old + P[2]) * r_1;
+      const double wn = (ro_old * w_old + P[3]) * r_1;
+      const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+      rop_new[l] = rn; rop_new[l + nd] = un; rop_new[l + 2 * nd] = vn; rop_new[l + 3 * nd] = wn;
+      rop_new[l + 4 * nd] = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ssor_reset(FsZone z, LuRange r, const double *__restrict__ din,
+                                                    double *__restrict__ dout, double *__restrict__ ssor)
+{
+  const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x, j = r.j0 + blockIdx.y, k = r.k0 + blockIdx.z;
+  if (i > r.i1) return;
+  const long long l = lcell(z, i, j, k);
+  for (int e = 0; e < 5; e++) { dout[l + e * z.nd] = din[l + e * z.nd] + ssor[l + e * z.nd]; ssor[l + e * z.nd] = 0.; }
+}
+
 __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const double *__restrict__ src,
                                                     double *__restrict__ dst)
 {
@@ -412,5 +583,59 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
     dim3 g((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
     hipLaunchKernelGGL(k_copy_range, g, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
   }
+  return 0;
+}
+
+// LU-SSOR with nb_relax >= 2 on the range `range`, Newton update on the cells of `sdm` (the interior of the zone).
+// din = Newton residual (kept); work = 2 * neq * nd doubles (increments, accumulator).  In-place update as in fsk_lusgs.
+int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax, double gamma, const double *rop, double *rop_out,
+               double *scratch, const double *din, double *work, const double *coe, hipStream_t s)
+{
+  if (z.neq != 5 || z.twod || nb_relax < 2) return -1;
+  LuConst c;
+  c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
+  c.cv = z.cv; c.cvinv = 1. / z.cv; c.cvinv2 = 0.5 * c.cvinv;
+  LuRange r = {range[0], range[1], range[2], range[3], range[4], range[5]};
+  LuRange sdm = {sdm_[0], sdm_[1], sdm_[2], sdm_[3], sdm_[4], sdm_[5]};
+  const int ni = r.i1 - r.i0 + 1, nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
+  if (ni < 1 || nj < 1 || nk < 1) return -1;
+  const bool full = z.ityp == 0;
+  const bool inplace = rop_out == rop;
+  if (inplace && !scratch) return -1;
+  double *rop_new = inplace ? scratch : rop_out;
+  const double *rop_kn = inplace ? scratch : rop;
+  double *dout = work, *ssor = work + (size_t)z.neq * z.nd;
+  const int nchunk = (ni + 7) / 8;
+  const int nhc = nchunk + nj + nk - 2;
+  const unsigned gx8 = (unsigned)((nchunk + 7) / 8);
+  const dim3 gr((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
+  if (inplace) {
+    // cells of the range outside sdm keep their state: the copy back below covers the whole range
+    hipLaunchKernelGGL(k_copy_range, gr, dim3(256), 0, s, z, r, rop, scratch);
+  }
+  for (int m = 1; m <= nb_relax; m++) {
+    const bool last = m == nb_relax;
+    for (int pass = 0; pass < 2; pass++) {
+      for (int n = 0; n < nhc; n++) {
+        const int h = pass == 0 ? n : nhc - 1 - n;
+        int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
+        int khi = h < nk - 1 ? h : nk - 1;
+        dim3 g(gx8, (unsigned)(khi - klo + 1));
+#define FS_LO(F, M1) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, din, dout, ssor, coe)
+#define FS_UP(F, L) hipLaunchKernelGGL((k_ssor_upper_wave<F, L>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe)
+        if (pass == 0) {
+          if (full) { if (m == 1) FS_LO(true, true); else FS_LO(true, false); }
+          else { if (m == 1) FS_LO(false, true); else FS_LO(false, false); }
+        } else {
+          if (full) { if (last) FS_UP(true, true); else FS_UP(true, false); }
+          else { if (last) FS_UP(false, true); else FS_UP(false, false); }
+        }
+#undef FS_LO
+#undef FS_UP
+      }
+      if (!(last && pass == 1)) hipLaunchKernelGGL(k_ssor_reset, gr, dim3(256), 0, s, z, r, din, dout, ssor);
+    }
+  }
+  if (inplace) hipLaunchKernelGGL(k_copy_range, gr, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
   return 0;
 }

@@ -2297,6 +2297,114 @@ int fo_bczone_rhs(const i32 *p, double *drodm, const double *ti, const double *t
   return 0;
 }
 
+/* Newton update of one cell from its increment (LU/mjr_newton.for), 5 equations */
+static inline void mjr_newton5(const double *pr, long nd, long l, const double *rop, const double *dw, double *rop_1)
+{
+  const double cvinv = 1. / pr[CVINF], cvinv2 = 0.5 * cvinv;
+  const double ro_old = rop[l], u_old = rop[l + nd], v_old = rop[l + 2 * nd], w_old = rop[l + 3 * nd];
+  const double t_old = rop[l + 4 * nd];
+  rop_1[l] = rop[l] + dw[l];
+  const double r_1 = 1. / rop_1[l];
+  rop_1[l + nd] = (ro_old * u_old + dw[l + nd]) * r_1;
+  rop_1[l + 2 * nd] = (ro_old * v_old + dw[l + 2 * nd]) * r_1;
+  rop_1[l + 3 * nd] = (ro_old * w_old + dw[l + 3 * nd]) * r_1;
+  const double roe_old = ro_old * (pr[CVINF] * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+  rop_1[l + 4 * nd] = (roe_old + dw[l + 4 * nd]) * r_1 * cvinv -
+                      cvinv2 * (rop_1[l + nd] * rop_1[l + nd] + rop_1[l + 2 * nd] * rop_1[l + 2 * nd] +
+                                rop_1[l + 3 * nd] * rop_1[l + 3 * nd]);
+}
+
+/* LU-SSOR with nb_relax >= 2 relaxations on the range ind of a three-dimensional zone, 5 equations, one thread whose
+ * window is the whole zone (so the window index of the reference's work arrays is the cell index):
+ * Fast/FastS/FastS/Compute/LU/invlu.for:195-340 calling invlussor1_l.for (first lower sweep: the increment starts from
+ * the right-hand side drodm_in), invlussor_l.for (later lower sweeps: it starts from what the upper sweep left) and
+ * invlussor_u.for.  Per cell and sweep: neighbour terms in the order i, j, k, each added to the increment and to the
+ * accumulator `ssor` (mjr_drodm_IO_ssor.for, mjr_drodm_ssor.for), then the division by the diagonal (lu_dinv.for); one
+ * plane behind the sweep the increment is reset to drodm_in + ssor and ssor to zero (mjr_ssor.for), which is what the
+ * next sweep starts from.  The last upper sweep updates the state plane by plane (mjr_newton.for) on the interior sdm.
+ * dout, ssor: work arrays of neq * NDIMDX doubles. */
+int fo_invlussor(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm, const double *drodm_in, double *dout,
+                 double *ssor, const double *rop, double *rop_1, const double *ti, const double *tj, const double *tk,
+                 const double *coe)
+{
+  GEOM(p)
+  if (p[NEQ] != 5 || p[ITYPZONE] == 3 || p[ITYPZONE] == 1) return -1;
+  const int nrelax = p[NB_RELAX];
+  const double *coe5 = coe + 4 * nd;
+  double b[6];
+  luctx c;
+  for (int m = 1; m <= nrelax; m++) {
+    const int last = m == nrelax;
+    /* ---- lower ---- */
+    luctx_init(&c, p, pr, ti, tj, tk, +1);
+    for (int k = ind[4]; k <= ind[5]; k++) {
+      for (int j = ind[2]; j <= ind[3]; j++)
+        for (int i = ind[0]; i <= ind[1]; i++) {
+          const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+          const double xal = coe[l] * c.signe;
+          const int has[3] = {i > ind[0], j > ind[2], k > ind[4]};
+          int first = 1;
+          for (int d = 0; d < 3; d++) {
+            if (!has[d]) continue;
+            lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
+            for (int e = 0; e < 5; e++) {
+              if (m == 1 && first) { dout[l + e * nd] = drodm_in[l + e * nd] + b[e] * xal; ssor[l + e * nd] = b[e] * xal; }
+              else { dout[l + e * nd] = dout[l + e * nd] + b[e] * xal; ssor[l + e * nd] = ssor[l + e * nd] + b[e] * xal; }
+            }
+            first = 0;
+          }
+          const double diag = 1. / coe5[l];
+          if (m == 1 && first) {   /* first cell of the sweep: lu_dinv_IO.for */
+            for (int e = 0; e < 5; e++) { dout[l + e * nd] = drodm_in[l + e * nd] * diag; ssor[l + e * nd] = 0.; }
+          } else
+            for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+          if (k > ind[4]) {
+            const long l1 = l - ninj;
+            for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+          }
+        }
+    }
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l1 = INDDM(i, j, ind[5]);
+        for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+      }
+    /* ---- upper ---- */
+    luctx_init(&c, p, pr, ti, tj, tk, -1);
+    for (int k = ind[5]; k >= ind[4]; k--) {
+      for (int j = ind[3]; j >= ind[2]; j--)
+        for (int i = ind[1]; i >= ind[0]; i--) {
+          const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+          const double xal = coe[l] * c.signe;
+          const int has[3] = {i < ind[1], j < ind[3], k < ind[5]};
+          for (int d = 0; d < 3; d++) {
+            if (!has[d]) continue;
+            lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
+            for (int e = 0; e < 5; e++) { dout[l + e * nd] = dout[l + e * nd] + b[e] * xal; ssor[l + e * nd] = ssor[l + e * nd] + b[e] * xal; }
+          }
+          const double diag = 1. / coe5[l];
+          for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+        }
+      if (last && k >= sdm[4] && k <= sdm[5])
+        for (int j = sdm[2]; j <= sdm[3]; j++)
+          for (int i = sdm[0]; i <= sdm[1]; i++) mjr_newton5(pr, nd, INDDM(i, j, k), rop, dout, rop_1);
+      if (!last && k < ind[5])
+        for (int j = ind[3]; j >= ind[2]; j--)
+          for (int i = ind[1]; i >= ind[0]; i--) {
+            const long l1 = INDDM(i, j, k + 1);
+            for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+          }
+    }
+    if (!last)
+      for (int j = ind[3]; j >= ind[2]; j--)
+        for (int i = ind[1]; i >= ind[0]; i--) {
+          const long l1 = INDDM(i, j, ind[4]);
+          for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+        }
+  }
+  return 0;
+}
+
 /* One Newton sub-iteration of one zone, one cache block, one thread: sequence of
  * Fast/FastS/FastS/Compute/navier_stokes_struct.for:199-275 (viscosity and coefficients at the first
  * sub-iteration, on the whole zone), :295-301 (drodm = 0), :310-345 (fluxes), :406-419 (core3as2) and
@@ -2315,8 +2423,9 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   const int f = p[NIJK + 3], fk = p[NIJK + 4];
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
   const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
-  if (p[NB_RELAX] != 1 || p[LU_MATCH] != 0) return -1;
+  if (p[NB_RELAX] < 1 || p[LU_MATCH] != 0) return -1;
   if (p[NEQ] != 5 && !(p[NEQ] == 6 && p[IFLOW] == 3)) return -1;
+  if (p[NB_RELAX] > 1 && (p[NEQ] != 5 || p[ITYPZONE] == 3)) return -1;
   const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);
@@ -2338,6 +2447,14 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   if (rhs_only) return 0;
   i32 lu[6];
   if (fo_bczone_rhs(p, drodm, ti, tj, tk, lu)) return -1;
+  if (p[NB_RELAX] > 1) {
+    const size_t n = (size_t)p[NEQ] * p[NDIMDX];
+    double *w = (double *)calloc(2 * n, sizeof(double));
+    if (!w) return -1;
+    const int rc = fo_invlussor(p, pr, lu, sdm, drodm, w, w + n, rop_ss, ro_p1, ti, tj, tk, coe);
+    free(w);
+    return rc;
+  }
   fo_invlu(p, pr, lu, drodm, rop_ss, ro_p1, ti, tj, tk, coe);
   return 0;
 }

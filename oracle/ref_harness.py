@@ -451,11 +451,23 @@ class RefSolver:
         return shift
 
     def _invlu(self, nd, zn, nitrun, nstep, ro_ssiter):
-        """Fast/FastS/FastS/Compute/lhs.cpp:135-161 for nb_relax = 1, lu_match = 0."""
+        """Fast/FastS/FastS/Compute/lhs.cpp:135-161 for lu_match = 0.  nb_relax > 1: the increments are built in a work
+        array (iptdrodm_out = ssortmp, lhs.cpp:148) next to the accumulator ssor, both dimensioned on the window of
+        the thread, here the whole zone with its ghost cells (Compute/ssor.cpp, lhs.cpp:184-200)."""
         L = lib()
         p = zn.pint
-        assert p[71] == 1 and p[75] == 0, "nb_relax = 1 and lu_match = 0 only"
+        assert p[75] == 0, "lu_match = 0 only"
         shift = self._bczone_rhs(nd, zn, nstep)
+        if p[71] > 1:
+            ssor_size = int(p[NIJK]) * int(p[NIJK + 1]) * int(p[NIJK + 2])
+            neq = int(p[36])
+            if getattr(zn, 'ssor', None) is None:
+                zn.ssor = np.zeros(ssor_size * neq); zn.ssortmp = np.zeros(ssor_size * neq)
+            L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(shift), _p(zn.ind_dm), _i(1),
+                     _p(zn.ro_p1), _p(ro_ssiter), _p(zn.drodm), _p(zn.ssortmp),
+                     _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),
+                     _p(zn.coe), _p(zn.ssor), _i(ssor_size))
+            return
         dummy = np.zeros(8)
         L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(shift), _p(zn.ind_dm), _i(1),
                  _p(zn.ro_p1), _p(ro_ssiter), _p(zn.drodm), _p(zn.drodm),

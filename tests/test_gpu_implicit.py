@@ -117,3 +117,41 @@ def test_implicit_blocks_with_joins(blocks, nn, scheme, perturb):
         s.step()
         for z, oz in zip(zones, s.zones):
             assert np.array_equal(FastC.level_buffer(z), oz.ro), "step %d zone %s" % (it, z[0])
+
+
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs,nb_relax", [
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', 0., None, 2),
+    ((40, 11, 35), 'senseur', 'Euler', 0., None, 3),                   # several 8-cell units per line
+    ((12, 10, 9), 'senseur', 'NSLaminar', 0.15, None, 2),              # curvilinear
+    ((10, 8, 9), 'roe', 'NSLaminar', 0.15, FAR, 2),
+    ((12, 9, 10), 'ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 2),
+    ((10, 9, 8), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 3),
+])
+def test_ssor_relaxations_bit_exact_vs_oracle(n, scheme, model, perturb, bcs, nb_relax):
+    """LU-SSOR with nb_relax > 1 (LU/invlu.for:195-340): the restatement is bit-exact against invlu_ of the compiled
+    reference (test_oracle_vs_ref.py::test_implicit_lussor_bit_exact); the device sweeps hyperplanes and resets the
+    increments after a sweep instead of one plane behind it."""
+    extra = dict(SINGLE, nb_relax=nb_relax)
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[71]) == nb_relax
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()
+    ro0 = oz.ro.copy()
+    for it in range(1, 5):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4
+
+
+def test_ssor_outside_the_device_path_is_refused():
+    from fast_amd import _capi
+    t = cases.tgv((8, 8, 8), 'senseur', model='NSTurbulent', extra_numz=dict(SINGLE, nb_relax=2), extra_numb={'ss_iteration': 2},
+                  temporal_scheme='implicit', time_step=0.02)
+    with pytest.raises(_capi.FastsHipError, match="nb_relax"):
+        FastS.warmup(t, None)

@@ -172,6 +172,47 @@ def test_implicit_lusgs_bit_exact(scheme, model, perturb, bcs, blocks):
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
 
 
+@pytest.mark.parametrize("scheme,model,perturb,bcs,blocks,nb_relax", [
+    ('ausmpred', 'NSLaminar', 0., None, (1, 1, 1), 2),
+    ('senseur', 'Euler', 0., None, (1, 1, 1), 3),
+    ('senseur', 'NSLaminar', 0.15, None, (1, 1, 1), 2),
+    ('roe', 'NSLaminar', 0.15, FAR, (1, 1, 1), 2),
+    ('ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, (1, 1, 1), 2),
+    ('senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, (1, 1, 1), 3),
+    ('ausmpred', 'NSLaminar', 0., None, (1, 2, 1), 2),
+])
+def test_implicit_lussor_bit_exact(scheme, model, perturb, bcs, blocks, nb_relax):
+    """LU-SSOR with nb_relax > 1 relaxations (LU/invlu.for:195-340, invlussor1_l.for, invlussor_l.for,
+    invlussor_u.for, mjr_ssor.for) against invlu_ of the compiled reference."""
+    nn = (10, 8, 9)
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000, 'nb_relax': nb_relax}
+    t = cases.tgv(nn, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs, blocks=blocks,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb)
+    nv = tuple(nn[d] // blocks[d] for d in range(3))
+    so, sr = _pair(t, blocks if blocks != (1, 1, 1) else None, nv)
+    assert int(so.zones[0].pint[71]) == nb_relax
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        for a, b in zip(so.zones, sr.zones):
+            assert np.array_equal(a.ro, b.ro) and np.array_equal(a.ro_m1, b.ro_m1), "step %d" % it
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-4
+    # the relaxations matter: the same case with nb_relax = 1 gives another field
+    extra['nb_relax'] = 1
+    t1 = cases.tgv(nn, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs, blocks=blocks,
+                   temporal_scheme='implicit', time_step=0.02, perturb=perturb)
+    s1, _ = _pair(t1, blocks if blocks != (1, 1, 1) else None, nv)
+    s1.fill_ghostcells()
+    for a in s1.zones:
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro
+    for it in range(1, 5):
+        s1.step()
+    assert not np.array_equal(s1.zones[0].ro, so.zones[0].ro)
+
+
 @pytest.mark.parametrize("nn,scheme,model,perturb,bcs,nblk", [
     ((10, 8, 8), 'ausmpred', 'NSLaminar', 0., None, 1),
     ((12, 23, 21), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'imax': 'BCFarfield'}, 4),   # 1 x 2 x 2 sub-blocks
