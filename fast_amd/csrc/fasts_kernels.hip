@@ -20,10 +20,13 @@ FS_DEV long long fs_inddm(const FsZone &z, int i, int j, int k)
 __global__ void __launch_bounds__(256) k_invist(FsZone z, int depth, const double *__restrict__ rop,
                                                 double *__restrict__ xmut)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x + 1 - depth;  // 1-depth .. iv+depth
-  const int j = blockIdx.y + 1 - depth;
-  const int k = blockIdx.z + 1 - (depth < z.ifick ? depth : z.ifick);   // no ghost layer along k on a 2-D zone
-  if (i > z.iv + depth) return;
+  // the (i,j) cells of a plane are numbered row after row, so that every workgroup but the last of a plane is full
+  const int wi = z.iv + 2 * depth;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= wi * (z.jv + 2 * depth)) return;
+  const int i = idx % wi + 1 - depth;  // 1-depth .. iv+depth
+  const int j = idx / wi + 1 - depth;
+  const int k = blockIdx.y + 1 - (depth < z.ifick ? depth : z.ifick);   // no ghost layer along k on a 2-D zone
   long long l = fs_inddm(z, i, j, k);
   xmut[l] = fs_sutherland(z, rop[4 * z.nd + l]);
 }
@@ -639,7 +642,7 @@ static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b
 
 void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s)
 {
-  dim3 g(cdiv(z.iv + 2 * depth, 256), z.jv + 2 * depth, z.kv + 2 * (depth < z.ifick ? depth : z.ifick));
+  dim3 g(cdiv((long long)(z.iv + 2 * depth) * (z.jv + 2 * depth), 256), z.kv + 2 * (depth < z.ifick ? depth : z.ifick));
   hipLaunchKernelGGL(k_invist, g, dim3(256), 0, s, z, depth, rop, xmut);
 }
 

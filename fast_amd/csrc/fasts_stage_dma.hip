@@ -520,10 +520,22 @@ FsTiling fsk_stage_dma_tiling(const FsZone &z)
   // the face i = iv+1 is evaluated by lane iv - i0 of the last tile, or by its i-edge wave
   t.nti = (z.iv + TI - 1) / TI;
   t.ntj = (z.jv + TJ - 1) / TJ;
-  t.kchunk = 32;
+  // one workgroup per CU is resident (LDS): the k chunks are cut so that the tiles of the zone give about one
+  // workgroup per CU, the fewest plane-ring fills (256^3: 128 tiles x 2 chunks of 128 planes, 0.710 ms per stage
+  // against 0.738 with chunks of 32)
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    ncu = n;
+  }
+  int nchunks = ncu / (t.nti * t.ntj);
+  if (nchunks < 1) nchunks = 1;
+  t.kchunk = (z.kv + nchunks - 1) / nchunks;
+  if (t.kchunk < 16) t.kchunk = 16;
   if (const char *ev = getenv("FASTS_HIP_KCHUNK")) t.kchunk = atoi(ev) > 0 ? atoi(ev) : t.kchunk;   // tuning aid
   if (z.kv < t.kchunk) t.kchunk = z.kv;
-  t.pace = 4;
+  t.pace = 1;
   if (const char *ev = getenv("FASTS_HIP_PACE")) t.pace = atoi(ev);   // tuning aid
   t.ntk = (z.kv + t.kchunk - 1) / t.kchunk;
   return t;

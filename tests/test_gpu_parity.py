@@ -81,8 +81,8 @@ def test_unsupported_options_are_refused():
     t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCOutflow'})
     with pytest.raises(_capi.FastsHipError, match="tag 10"):
         FastS.warmup(t, None)
-    t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'nb_relax': 2})
-    with pytest.raises(_capi.FastsHipError, match="nb_relax"):
+    t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'lu_match': 1})
+    with pytest.raises(_capi.FastsHipError, match="lu_match"):
         FastS.warmup(t, None)
 
 
