@@ -93,9 +93,13 @@ struct LuConst { double gam1, gamm1, gam2, cp, cvinv, cvinv2, cv; };
 // radius crad = coe(m, 2+D); lt = metric index of cell l.
 // NE = 6: Spalart-Allmaras, the 6th equation is a decoupled scalar, b6 = (qn + signe*rho_d) dW6
 // (LU/lu_{i,j,k}_3dcart_SA.for).
+// Matrix of the neighbour term, M[5*r + c] = b(r+1)(c+1) of the reference's fragments (entries the fragment of the
+// direction does not have are left unset and never read); M[25] = qn + signe*rho_d, the factor of the 6th equation.
+// It depends on the neighbour's state and radius only, not on its increment: the i recurrence of the sweeps computes
+// it once per cell, outside the serial chain.
 template <bool FULL, int D, int SGN, int NE = 5>
-FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, double v, double w, double t,
-                    double d1, double d2, double d3, double d4, double d5, double crad, double *b, double d6 = 0.)
+FS_DEV void lu_mat(const FsZone &z, const LuConst &c, long long lt, double u, double v, double w, double t, double crad,
+                   double *M)
 {
   const double signe = SGN > 0 ? 0.5 : -0.5;
   const double gamm1 = c.gamm1, gam2 = c.gam2, gam1 = c.gam1, cp = c.cp;
@@ -112,67 +116,88 @@ FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, d
     const double tcy = 0.5 * (tt[lt2 + ndm] + tt[lt1 + ndm]);
     const double tcz = 0.5 * (tt[lt2 + 2 * ndm] + tt[lt1 + 2 * ndm]);
     const double qn = tcx * u + tcy * v + tcz * w;
-    const double b11 = cr, b12 = tcx, b13 = tcy, b14 = tcz;
-    const double b21 = (tcx * ph2 - u * qn), b22 = (qn - tcx * gam2 * u) + cr;
-    const double b23 = (tcy * u - tcx * gamm1 * v), b24 = (tcz * u - tcx * gamm1 * w), b25 = tcx * gamm1;
-    const double b31 = (tcy * ph2 - v * qn), b32 = (tcx * v - tcy * gamm1 * u);
-    const double b33 = (qn - tcy * gam2 * v) + cr, b34 = (tcz * v - tcy * gamm1 * w), b35 = tcy * gamm1;
-    const double b41 = (tcz * ph2 - w * qn), b42 = (tcx * w - tcz * gamm1 * u);
-    const double b43 = (tcy * w - tcz * gamm1 * v), b44 = (qn - tcz * gam2 * w) + cr, b45 = tcz * gamm1;
-    const double b51 = qn * (ph2 - h), b52 = (tcx * h - gamm1 * u * qn), b53 = (tcy * h - gamm1 * v * qn);
-    const double b54 = (tcz * h - gamm1 * w * qn), b55 = (gam1 * qn) + cr;
-    b[0] = b11 * d1 + b12 * d2 + b13 * d3 + b14 * d4;
-    b[1] = b21 * d1 + b22 * d2 + b23 * d3 + b24 * d4 + b25 * d5;
-    b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
-    b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
-    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
-    if (NE == 6) b[5] = (qn + cr) * d6;
+    M[0] = cr; M[1] = tcx; M[2] = tcy; M[3] = tcz;
+    M[5] = (tcx * ph2 - u * qn); M[6] = (qn - tcx * gam2 * u) + cr;
+    M[7] = (tcy * u - tcx * gamm1 * v); M[8] = (tcz * u - tcx * gamm1 * w); M[9] = tcx * gamm1;
+    M[10] = (tcy * ph2 - v * qn); M[11] = (tcx * v - tcy * gamm1 * u);
+    M[12] = (qn - tcy * gam2 * v) + cr; M[13] = (tcz * v - tcy * gamm1 * w); M[14] = tcy * gamm1;
+    M[15] = (tcz * ph2 - w * qn); M[16] = (tcx * w - tcz * gamm1 * u);
+    M[17] = (tcy * w - tcz * gamm1 * v); M[18] = (qn - tcz * gam2 * w) + cr; M[19] = tcz * gamm1;
+    M[20] = qn * (ph2 - h); M[21] = (tcx * h - gamm1 * u * qn); M[22] = (tcy * h - gamm1 * v * qn);
+    M[23] = (tcz * h - gamm1 * w * qn); M[24] = (gam1 * qn) + cr;
+    if (NE == 6) M[25] = qn + cr;
     return;
   }
   const double tc = D == 0 ? z.tcx : (D == 1 ? z.tcy : z.tcz);
   if (D == 0) {
     const double qn = tc * u;
-    const double b11 = cr, b12 = tc, b21 = (tc * ph2 - u * qn), b22 = (qn - tc * gam2 * u) + cr;
-    const double b23 = (-tc * gamm1 * v), b24 = (-tc * gamm1 * w), b25 = tc * gamm1;
-    const double b31 = (-v * qn), b32 = (tc * v), b33 = (qn) + cr;
-    const double b41 = (-w * qn), b42 = (tc * w), b44 = (qn) + cr;
-    const double b51 = qn * (ph2 - h), b52 = (tc * h - gamm1 * u * qn), b53 = (-gamm1 * v * qn);
-    const double b54 = (-gamm1 * w * qn), b55 = (gam1 * qn) + cr;
-    b[0] = b11 * d1 + b12 * d2;
-    b[1] = b21 * d1 + b22 * d2 + b23 * d3 + b24 * d4 + b25 * d5;
-    b[2] = b31 * d1 + b32 * d2 + b33 * d3;
-    b[3] = b41 * d1 + b42 * d2 + b44 * d4;
-    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
-    if (NE == 6) b[5] = (qn + cr) * d6;
+    M[0] = cr; M[1] = tc; M[5] = (tc * ph2 - u * qn); M[6] = (qn - tc * gam2 * u) + cr;
+    M[7] = (-tc * gamm1 * v); M[8] = (-tc * gamm1 * w); M[9] = tc * gamm1;
+    M[10] = (-v * qn); M[11] = (tc * v); M[12] = (qn) + cr;
+    M[15] = (-w * qn); M[16] = (tc * w); M[18] = (qn) + cr;
+    M[20] = qn * (ph2 - h); M[21] = (tc * h - gamm1 * u * qn); M[22] = (-gamm1 * v * qn);
+    M[23] = (-gamm1 * w * qn); M[24] = (gam1 * qn) + cr;
+    if (NE == 6) M[25] = qn + cr;
   } else if (D == 1) {
     const double qn = tc * v;
-    const double b11 = cr, b13 = tc, b21 = (-u * qn), b22 = qn + cr, b23 = tc * u;
-    const double b31 = (tc * ph2 - v * qn), b32 = (-tc * gamm1 * u), b33 = (qn - tc * gam2 * v) + cr;
-    const double b34 = (-tc * gamm1 * w), b35 = tc * gamm1;
-    const double b41 = (-w * qn), b43 = (tc * w), b44 = (qn) + cr;
-    const double b51 = qn * (ph2 - h), b52 = (-gamm1 * u * qn), b53 = (tc * h - gamm1 * v * qn);
-    const double b54 = (-gamm1 * w * qn), b55 = (gam1 * qn) + cr;
-    b[0] = b11 * d1 + b13 * d3;
-    b[1] = b21 * d1 + b22 * d2 + b23 * d3;
-    b[2] = b31 * d1 + b32 * d2 + b33 * d3 + b34 * d4 + b35 * d5;
-    b[3] = b41 * d1 + b43 * d3 + b44 * d4;
-    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
-    if (NE == 6) b[5] = (qn + cr) * d6;
+    M[0] = cr; M[2] = tc; M[5] = (-u * qn); M[6] = qn + cr; M[7] = tc * u;
+    M[10] = (tc * ph2 - v * qn); M[11] = (-tc * gamm1 * u); M[12] = (qn - tc * gam2 * v) + cr;
+    M[13] = (-tc * gamm1 * w); M[14] = tc * gamm1;
+    M[15] = (-w * qn); M[17] = (tc * w); M[18] = (qn) + cr;
+    M[20] = qn * (ph2 - h); M[21] = (-gamm1 * u * qn); M[22] = (tc * h - gamm1 * v * qn);
+    M[23] = (-gamm1 * w * qn); M[24] = (gam1 * qn) + cr;
+    if (NE == 6) M[25] = qn + cr;
   } else {
     const double qn = tc * w;
-    const double b11 = cr, b14 = tc, b21 = -u * qn, b22 = qn + cr, b24 = tc * u;
-    const double b31 = -v * qn, b33 = qn + cr, b34 = tc * v;
-    const double b41 = tc * ph2 - w * qn, b42 = -tc * gamm1 * u, b43 = -tc * gamm1 * v;
-    const double b44 = (qn - tc * gam2 * w) + cr, b45 = tc * gamm1;
-    const double b51 = qn * (ph2 - h), b52 = -gamm1 * u * qn, b53 = -gamm1 * v * qn;
-    const double b54 = tc * h - gamm1 * w * qn, b55 = gam1 * qn + cr;
-    b[0] = b11 * d1 + b14 * d4;
-    b[1] = b21 * d1 + b22 * d2 + b24 * d4;
-    b[2] = b31 * d1 + b33 * d3 + b34 * d4;
-    b[3] = b41 * d1 + b42 * d2 + b43 * d3 + b44 * d4 + b45 * d5;
-    b[4] = b51 * d1 + b52 * d2 + b53 * d3 + b54 * d4 + b55 * d5;
-    if (NE == 6) b[5] = (qn + cr) * d6;
+    M[0] = cr; M[3] = tc; M[5] = -u * qn; M[6] = qn + cr; M[8] = tc * u;
+    M[10] = -v * qn; M[12] = qn + cr; M[13] = tc * v;
+    M[15] = tc * ph2 - w * qn; M[16] = -tc * gamm1 * u; M[17] = -tc * gamm1 * v;
+    M[18] = (qn - tc * gam2 * w) + cr; M[19] = tc * gamm1;
+    M[20] = qn * (ph2 - h); M[21] = -gamm1 * u * qn; M[22] = -gamm1 * v * qn;
+    M[23] = tc * h - gamm1 * w * qn; M[24] = gam1 * qn + cr;
+    if (NE == 6) M[25] = qn + cr;
   }
+}
+
+// b = M dW, the sums of the fragment of the direction (LU/lu_{i,j,k}_3dcart.for, lu_{i,j,k}_3dfull.for)
+template <bool FULL, int D, int NE = 5>
+FS_DEV void lu_mul(const double *M, double d1, double d2, double d3, double d4, double d5, double *b, double d6 = 0.)
+{
+  if (FULL) {
+    b[0] = M[0] * d1 + M[1] * d2 + M[2] * d3 + M[3] * d4;
+    b[1] = M[5] * d1 + M[6] * d2 + M[7] * d3 + M[8] * d4 + M[9] * d5;
+    b[2] = M[10] * d1 + M[11] * d2 + M[12] * d3 + M[13] * d4 + M[14] * d5;
+    b[3] = M[15] * d1 + M[16] * d2 + M[17] * d3 + M[18] * d4 + M[19] * d5;
+    b[4] = M[20] * d1 + M[21] * d2 + M[22] * d3 + M[23] * d4 + M[24] * d5;
+  } else if (D == 0) {
+    b[0] = M[0] * d1 + M[1] * d2;
+    b[1] = M[5] * d1 + M[6] * d2 + M[7] * d3 + M[8] * d4 + M[9] * d5;
+    b[2] = M[10] * d1 + M[11] * d2 + M[12] * d3;
+    b[3] = M[15] * d1 + M[16] * d2 + M[18] * d4;
+    b[4] = M[20] * d1 + M[21] * d2 + M[22] * d3 + M[23] * d4 + M[24] * d5;
+  } else if (D == 1) {
+    b[0] = M[0] * d1 + M[2] * d3;
+    b[1] = M[5] * d1 + M[6] * d2 + M[7] * d3;
+    b[2] = M[10] * d1 + M[11] * d2 + M[12] * d3 + M[13] * d4 + M[14] * d5;
+    b[3] = M[15] * d1 + M[17] * d3 + M[18] * d4;
+    b[4] = M[20] * d1 + M[21] * d2 + M[22] * d3 + M[23] * d4 + M[24] * d5;
+  } else {
+    b[0] = M[0] * d1 + M[3] * d4;
+    b[1] = M[5] * d1 + M[6] * d2 + M[8] * d4;
+    b[2] = M[10] * d1 + M[12] * d3 + M[13] * d4;
+    b[3] = M[15] * d1 + M[16] * d2 + M[17] * d3 + M[18] * d4 + M[19] * d5;
+    b[4] = M[20] * d1 + M[21] * d2 + M[22] * d3 + M[23] * d4 + M[24] * d5;
+  }
+  if (NE == 6) b[5] = M[25] * d6;
+}
+
+template <bool FULL, int D, int SGN, int NE = 5>
+FS_DEV void lu_term(const FsZone &z, const LuConst &c, long long lt, double u, double v, double w, double t,
+                    double d1, double d2, double d3, double d4, double d5, double crad, double *b, double d6 = 0.)
+{
+  double M[26];
+  lu_mat<FULL, D, SGN, NE>(z, c, lt, u, v, w, t, crad, M);
+  lu_mul<FULL, D, NE>(M, d1, d2, d3, d4, d5, b, d6);
 }
 
 // rs = state array the neighbour is read from, dw = increments, coe = coefficient array
@@ -211,6 +236,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
   const bool has_prev = active && i > r.i0;
   double A[NE] = {}, P[NE] = {}, S[4] = {0., 0., 0., 0.};
   double CR = 0., XAL = 0., DG = 0., C6 = 1.;   // C6 = diagonal of the 6th equation, coe(:,6)
+  double MI[26] = {};
   if (active) {
     XAL = coe[l] * 0.5;
     double b[NE];
@@ -229,6 +255,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
     if (has_prev) {
       S[0] = rop[l - 1 + nd]; S[1] = rop[l - 1 + 2 * nd]; S[2] = rop[l - 1 + 3 * nd]; S[3] = rop[l - 1 + 4 * nd];
       CR = coe[l - 1 + nd];
+      lu_mat<FULL, 0, 1, NE>(z, c, lt, S[0], S[1], S[2], S[3], CR, MI);   // matrix of the i predecessor, once
       if (m == 0) {   // the cell before the unit belongs to an earlier hyperplane: final
 #pragma unroll
         for (int e = 0; e < NE; e++) P[e] = dw[l - 1 + e * nd];
@@ -246,7 +273,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
     if (m == st && active) {
       if (has_prev) {
         double b[NE];
-        lu_term<FULL, 0, 1, NE>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b, NE == 6 ? pin[NE - 1] : 0.);
+        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
 #pragma unroll
         for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
       }
@@ -280,6 +307,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
   const bool last_of_unit = m == 7 || i == r.i1;     // its i+1 neighbour lies outside the unit
   double A[NE] = {}, P[NE] = {}, S[4] = {0., 0., 0., 0.};
   double CR = 0., XAL = 0., DG = 0., C6 = 1.;   // C6 = diagonal of the 6th equation, coe(:,6)
+  double MI[26] = {};
   double q[NE] = {1., 0., 0., 0., 1.};
   if (active) {
     XAL = coe[l] * -0.5;
@@ -294,6 +322,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
     if (has_next) {
       S[0] = rop[l + 1 + nd]; S[1] = rop[l + 1 + 2 * nd]; S[2] = rop[l + 1 + 3 * nd]; S[3] = rop[l + 1 + 4 * nd];
       CR = coe[l + 1 + nd];
+      lu_mat<FULL, 0, -1, NE>(z, c, lt, S[0], S[1], S[2], S[3], CR, MI);   // matrix of the i predecessor, once
       if (last_of_unit) {
 #pragma unroll
         for (int e = 0; e < NE; e++) P[e] = dw[l + 1 + e * nd];
@@ -310,7 +339,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
     if (m == st && active) {
       if (has_next) {
         double b[NE];
-        lu_term<FULL, 0, -1, NE>(z, c, lt, S[0], S[1], S[2], S[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b, NE == 6 ? pin[NE - 1] : 0.);
+        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
 #pragma unroll
         for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
       }
@@ -372,6 +401,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
   const bool has_j = active && j > r.j0, has_k = active && k > r.k0;
   double A[NE] = {}, S[NE] = {}, P[NE] = {}, BJ[NE] = {}, BK[NE] = {}, ST[4] = {0., 0., 0., 0.};
   double CR = 0., XAL = 0., DG = 0.;
+  double MI[26] = {};
   if (active) {
     XAL = coe[l] * 0.5;
     double b[NE];
@@ -383,6 +413,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
     if (has_prev) {
       ST[0] = rop[l - 1 + nd]; ST[1] = rop[l - 1 + 2 * nd]; ST[2] = rop[l - 1 + 3 * nd]; ST[3] = rop[l - 1 + 4 * nd];
       CR = coe[l - 1 + nd];
+      lu_mat<FULL, 0, 1, NE>(z, c, lt, ST[0], ST[1], ST[2], ST[3], CR, MI);   // matrix of the i predecessor, once
       if (m == 0) {
 #pragma unroll
         for (int e = 0; e < NE; e++) P[e] = dout[l - 1 + e * nd];
@@ -400,7 +431,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
       bool any = false;
       if (has_prev) {
         double b[NE];
-        lu_term<FULL, 0, 1, NE>(z, c, lt, ST[0], ST[1], ST[2], ST[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b);
 #pragma unroll
         for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = FIRSTM ? t : S[e] + t; }
         any = true;
@@ -444,6 +475,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
   const bool last_of_unit = m == 7 || i == r.i1;
   double A[NE] = {}, S[NE] = {}, P[NE] = {}, BJ[NE] = {}, BK[NE] = {}, ST[4] = {0., 0., 0., 0.};
   double CR = 0., XAL = 0., DG = 0.;
+  double MI[26] = {};
   double q[NE] = {1., 0., 0., 0., 1.};
   if (active) {
     XAL = coe[l] * -0.5;
@@ -456,6 +488,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
     if (has_next) {
       ST[0] = rop[l + 1 + nd]; ST[1] = rop[l + 1 + 2 * nd]; ST[2] = rop[l + 1 + 3 * nd]; ST[3] = rop[l + 1 + 4 * nd];
       CR = coe[l + 1 + nd];
+      lu_mat<FULL, 0, -1, NE>(z, c, lt, ST[0], ST[1], ST[2], ST[3], CR, MI);   // matrix of the i predecessor, once
       if (last_of_unit) {
 #pragma unroll
         for (int e = 0; e < NE; e++) P[e] = dout[l + 1 + e * nd];
@@ -472,7 +505,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
     if (m == st && active) {
       if (has_next) {
         double b[NE];
-        lu_term<FULL, 0, -1, NE>(z, c, lt, ST[0], ST[1], ST[2], ST[3], pin[0], pin[1], pin[2], pin[3], pin[4], CR, b);
+        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b);
 #pragma unroll
         for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = S[e] + t; }
       }
