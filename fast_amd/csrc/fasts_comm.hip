@@ -8,6 +8,8 @@
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cstdio>
 #include <cstring>
 #include <map>
 
@@ -46,6 +48,15 @@ bool rccl_open()
   g_rccl.h = h;
   return true;
 }
+
+// RCCL prints a version banner on the standard output of rank 0 when it initialises.  Callers of this library own
+// their standard output (a benchmark prints one line of JSON there), so the banner is sent to the standard error for
+// the duration of the two initialising calls.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
+  ~StdoutToStderr() { if (saved >= 0) { fflush(stdout); (void)dup2(saved, 1); close(saved); } }
+};
 
 struct Peer {
   int rank = 0;
@@ -99,7 +110,10 @@ extern "C" int fs_comm_unique_id(void *id, int nbytes)
   if (!id || nbytes < NCCL_UNIQUE_ID_BYTES) return FS_ERR_ARG;
   if (!rccl_open()) return FS_ERR_HIP;
   ncclUniqueId u;
-  if (g_rccl.GetUniqueId(&u) != ncclSuccess) return FS_ERR_HIP;
+  {
+    StdoutToStderr quiet;
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) return FS_ERR_HIP;
+  }
   memcpy(id, &u, NCCL_UNIQUE_ID_BYTES);
   return FS_OK;
 }
@@ -117,7 +131,10 @@ extern "C" int fs_comm_init(fs_ctx *ctx, int rank, int world, const void *id, in
   ctx->comm = c;
   ncclUniqueId u;
   memcpy(&u, id, NCCL_UNIQUE_ID_BYTES);
-  NCCLCHK(ctx, g_rccl.CommInitRank(&c->comm, world, u, rank));
+  {
+    StdoutToStderr quiet;
+    NCCLCHK(ctx, g_rccl.CommInitRank(&c->comm, world, u, rank));
+  }
   HIPCHK(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));

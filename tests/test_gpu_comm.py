@@ -54,6 +54,21 @@ def test_self_send_from_the_flat_connectivity():
     job.ctx.close()
 
 
+def test_transport_without_a_tensor_framework_in_the_process():
+    """The library's own dlopen of librccl beside the system HIP runtime (this test process has torch loaded, which
+    ships copies of both under the same sonames: a fresh process has not)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(here, 'rccl_loopback_notorch.py')], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and 'RCCL_NOTORCH_RESULT 1' in r.stdout, r.stdout + r.stderr
+    # the caller owns the standard output (bench.py prints one line of JSON there): RCCL's banner must not reach it
+    assert r.stdout.strip().splitlines() == ['RCCL_NOTORCH_RESULT 1'], r.stdout
+
+
 def test_compute_without_setup_is_refused():
     """Remote joins registered but no communicator: fs_compute fails with a message, it does not skip the messages."""
     from fast_amd import cases
