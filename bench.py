@@ -198,7 +198,7 @@ def main():
         # own by profiles/run_profiles.sh; counters cannot be read inside a timed run)
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'traffic_%s_%d%s.json' % (a.scheme, a.n, '_curvilinear' if a.perturb else ''))
-        if os.path.exists(tf):
+        if os.path.exists(tf) and not a.naca:
             with open(tf) as fh:
                 traffic = json.load(fh).get('traffic_bytes_per_launch')
         # algorithmic bytes per launch; per-cell metrics (9 surface-vector components + volume) are read once per stage
