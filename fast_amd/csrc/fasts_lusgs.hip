@@ -219,6 +219,23 @@ FS_DEV void lu_neighbour(const FsZone &z, const LuConst &c, long long l, long lo
 // every array); the i recurrence then runs in 8 steps, the increment of cell m-1 reaching cell m through
 // a shuffle inside each group of 8 lanes.
 // ------------------------------------------------------------------------------------------------------
+#ifdef FS_LU_STAMP
+// development aid: time stamps of wave (0,0) of every lower-sweep launch (profiles/lu_stamps.py)
+__device__ long long fs_lu_stamp_buf[1024 * 8];
+#define LUSTAMP(slot, wait)                                                                               \
+  {                                                                                                       \
+    if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && h < 1024)                               \
+      fs_lu_stamp_buf[h * 8 + (slot)] = (slot) == 0 || (slot) == 7 ? (long long)wall_clock64() : (long long)clock64(); \
+  }
+extern "C" int fs_lu_stamp_fetch(long long *host)
+{
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fs_lu_stamp_buf), sizeof(long long) * 1024 * 8);
+}
+#else
+#define LUSTAMP(slot, wait)
+#endif
+
 template <bool FULL, int NE>
 __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
                                                       const double *__restrict__ rop, double *__restrict__ dw,
@@ -237,6 +254,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
   double A[NE] = {}, P[NE] = {}, S[4] = {0., 0., 0., 0.};
   double CR = 0., XAL = 0., DG = 0., C6 = 1.;   // C6 = diagonal of the 6th equation, coe(:,6)
   double MI[26] = {};
+  LUSTAMP(0, false) LUSTAMP(1, false)
   if (active) {
     XAL = coe[l] * 0.5;
     double b[NE];
@@ -262,6 +280,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
       }
     }
   }
+  LUSTAMP(2, true)
   // P of lane m holds: before its step, the increment of cell m-1 (lane 0: preloaded); after, its own
   for (int st = 0; st < 8; st++) {
     double pin[NE];
@@ -282,10 +301,12 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
       if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
     }
   }
+  LUSTAMP(3, false)
   if (active) {
 #pragma unroll
     for (int e = 0; e < NE; e++) dw[l + e * nd] = P[e];
   }
+  LUSTAMP(4, true) LUSTAMP(7, false)
 }
 
 template <bool FULL, int NE>
