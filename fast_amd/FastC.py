@@ -715,6 +715,60 @@ def planar_metrics(x, y, z):
     return out
 
 
+def homo_metrics(x, y, z, ific, ifick):
+    """ti(:,1..2), tj(:,1..2), tk(:,1) and vol of a k-homogeneous zone (zone type 1: an extruded mesh), evaluated on
+    the first interior plane of cells only, with the operand order of Fast/FastC/FastC/Metric/cp_tijk.for:196-289 and
+    cp_vol.for:115-146 (the k faces below and above a cell share one surface value).  Arrays are dimensioned on the
+    nodes of one k-plane (index = i + j*ni, NDIMDX_MTR = ni*nj, no stride along k).  Returns the flat buffer
+    [ti(:,1..2) | tj(:,1..2) | tk | vol]."""
+    ni, nj, nk = x.shape
+    n = ni * nj
+    X = [numpy.asarray(a, dtype=numpy.float64)[:, :, ifick:ifick + 2] for a in (x, y, z)]
+
+    def N(a, di, dj, dk, si, sj):
+        return a[si.start + di:si.stop + di, sj.start + dj:sj.stop + dj, dk]
+
+    def cross(p1, p0, p3, q0, c):
+        a, b = (c + 1) % 3, (c + 2) % 3
+        return (p1[a] - p0[a]) * (p3[b] - q0[b]) - (p1[b] - p0[b]) * (p3[a] - q0[a])
+
+    T = [numpy.zeros((2, ni, nj)) for _ in range(2)]
+    si, sj = slice(0, ni), slice(0, nj - 1)
+    l0 = [N(a, 0, 0, 0, si, sj) for a in X]; l1 = [N(a, 0, 1, 0, si, sj) for a in X]
+    l2 = [N(a, 0, 0, 1, si, sj) for a in X]; l3 = [N(a, 0, 1, 1, si, sj) for a in X]
+    for c in range(2):
+        T[0][c][si, sj] = .5 * (cross(l1, l0, l3, l0, c) + cross(l2, l3, l0, l2, c))
+    si, sj = slice(0, ni - 1), slice(0, nj)
+    l0 = [N(a, 0, 0, 0, si, sj) for a in X]; l2 = [N(a, 0, 0, 1, si, sj) for a in X]
+    l4 = [N(a, 1, 0, 0, si, sj) for a in X]; l6 = [N(a, 1, 0, 1, si, sj) for a in X]
+    for c in range(2):
+        T[1][c][si, sj] = .5 * (cross(l0, l4, l2, l0, c) + cross(l6, l2, l4, l6, c))
+    si, sj = slice(0, ni - 1), slice(0, nj - 1)
+    P = {m: [N(a, (m >> 2) & 1, m & 1, (m >> 1) & 1, si, sj) for a in X] for m in range(8)}
+    px = {m: P[m][0] for m in range(8)}; py = {m: P[m][1] for m in range(8)}; pz = {m: P[m][2] for m in range(8)}
+    tkz10 = (px[4] - px[0]) * (py[5] - py[4]) - (py[4] - py[0]) * (px[5] - px[4])
+    tkz11 = (px[1] - px[5]) * (py[0] - py[1]) - (py[1] - py[5]) * (px[0] - px[1])
+    tk = numpy.zeros((ni, nj))
+    tk[si, sj] = .5 * (tkz10 + tkz11)
+    acc = []
+    for c in range(2):
+        q = {m: P[m][c] for m in range(8)}
+        acc.append(.25 * ((q[4] + q[5] + q[7] + q[6]) * T[0][c][1:ni, 0:nj - 1]
+                          - (q[0] + q[1] + q[3] + q[2]) * T[0][c][si, sj]
+                          + (q[1] + q[3] + q[5] + q[7]) * T[1][c][0:ni - 1, 1:nj]
+                          - (q[0] + q[2] + q[4] + q[6]) * T[1][c][si, sj]))
+    az = .25 * ((pz[2] + pz[3] + pz[6] + pz[7]) * tk[si, sj] - (pz[0] + pz[1] + pz[4] + pz[5]) * tk[si, sj])
+    vol = numpy.zeros((ni, nj))
+    vol[si, sj] = numpy.maximum((acc[0] + acc[1] + az) / 3., 1.e-30)
+    out = numpy.zeros(6 * n)
+    for d in range(2):
+        for c in range(2):
+            out[(2 * d + c) * n:(2 * d + c + 1) * n] = T[d][c].reshape(-1, order='F')
+    out[4 * n:5 * n] = tk.reshape(-1, order='F')
+    out[5 * n:] = vol.reshape(-1, order='F')
+    return out
+
+
 def allocate_metric_zone(z, nssiter):
     """Fill the size/type entries of Parameter_int and return the per-zone ``metrics`` list
     ``[mtr, mtr0, vent, mtr_df, rdm, ind_dm, it_lu_ssdom, degen]``
@@ -802,8 +856,7 @@ def allocate_metric_zone(z, nssiter):
     elif typ == 3:
         mtr[:] = planar_metrics(x, y, zz)
     else:
-        raise ValueError("fast_amd: zone %s is k-homogeneous (zone type 1); only Cartesian (2), curvilinear (0) "
-                         "and two-dimensional (3) zones are implemented on the device." % z[0])
+        mtr[:] = homo_metrics(x, y, zz, ific, ifick)
     # collapsed ghost cells: flags dimensioned on the nodes like the reference's (metrics[7]), then the metric
     # correction of init_metric.cpp:318 and, for the Spalart-Allmaras model, that of the wall distance (:324-329)
     deg = degenerate_cells(x, y, zz)

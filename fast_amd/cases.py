@@ -36,6 +36,18 @@ def _perturb(z, amp, L=2. * math.pi):
     xs[2][...] = zc + amp * h[2] * numpy.sin(w * x + 1.1) * numpy.cos(w * y) * numpy.cos(w * zc)
 
 
+def _perturb_homo(z, amp, L=2. * math.pi):
+    """Smooth displacement of the nodes inside the planes z = const, the same in every plane: an extruded mesh,
+    classified k-homogeneous (zone type 1: metrics of one plane)."""
+    g = Internal.getNodeFromName1(z, Internal.__GridCoordinates__)
+    xs = [Internal.getNodeFromName1(g, n)[1] for n in ('CoordinateX', 'CoordinateY')]
+    h = [xs[0][1, 0, 0] - xs[0][0, 0, 0], xs[1][0, 1, 0] - xs[1][0, 0, 0]]
+    w = 2. * math.pi / L
+    x, y = xs[0][:, :, 0].copy(), xs[1][:, :, 0].copy()
+    xs[0][...] = (x + amp * h[0] * numpy.sin(w * y + 0.3) * numpy.cos(w * x))[:, :, None]
+    xs[1][...] = (y + amp * h[1] * numpy.sin(w * x + 0.7) * numpy.cos(w * y))[:, :, None]
+
+
 def _collapse(z, faces, ghost=2):
     """Put the ghost nodes of the given faces on the boundary nodes: the flat ghost cells a mesh generator leaves
     behind physical boundaries (the solver then takes their metrics from the mirror cells)."""
@@ -96,12 +108,13 @@ def sa_fields(t, state, walls=(), L=2. * math.pi):
 
 def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1, 1),
         temporal_scheme='explicit', modulo_verif=50, extra_numz=None, only=None, bcs=None,
-        perturb=0., extra_numb=None, collapse=()):
+        perturb=0., extra_numb=None, collapse=(), homo=False):
     """Single- or multi-block TGV tree (+ numerics).  n = interior cells per direction of the
     whole box; blocks = (bi,bj,bk) split; only = block numbers to instantiate (the blocks of one
     rank; block b = ib + jb*bi + kb*bi*bj is named 'cart<b>').  Split directions carry no BC:
     their ghost cells are filled by match joins (fast_amd.connect).  perturb > 0 displaces the nodes
-    smoothly (see _perturb) so that the zones are curvilinear.  Returns t."""
+    smoothly (see _perturb) so that the zones are curvilinear; with homo the displacement is that of an extruded
+    mesh (_perturb_homo, zone type 1).  Returns t."""
     L1 = 2. * math.pi
     nn = (n, n, n) if isinstance(n, int) else tuple(n)
     nb = [nn[d] // blocks[d] for d in range(3)]
@@ -119,7 +132,7 @@ def tgv(n=32, scheme='senseur', model='NSLaminar', time_step=None, blocks=(1, 1,
                 name = 'cart%d' % b
                 z = _box(nb, ln, org, name)
                 if perturb:
-                    _perturb(z, perturb, L1)
+                    (_perturb_homo if homo else _perturb)(z, perturb, L1)
                 if collapse:
                     _collapse(z, collapse)
                 faces = []

@@ -166,10 +166,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (n_int < 137 || n_real < 41) return fail(ctx, FS_ERR_ARG, "fs_zone_add: Parameter_int/real too short");
   if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_zone_add: zones must be registered before fs_upload");
   const int32_t *p = pint;
-  if (p[ITYPZONE] != 2 && p[ITYPZONE] != 0 && p[ITYPZONE] != 3)
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: Cartesian (zone type 2), curvilinear (0) and two-dimensional (3) zones are implemented; "
-                "k-homogeneous zones (1) are not");
-  const bool twod = p[ITYPZONE] == 3;
+  if (p[ITYPZONE] < 0 || p[ITYPZONE] > 3) return fail(ctx, FS_ERR_ARG, "fs_zone_add: zone type must be 0, 1, 2 or 3");
+  const bool twod = p[ITYPZONE] == 3, homo = p[ITYPZONE] == 1;
   if (p[ITYPCP] != 2 && p[ITYPCP] != 1) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: temporal scheme must be explicit or implicit");
   const bool implicit = p[ITYPCP] == 1;
   if (!ctx->zones.empty() && implicit != ctx->implicit)
@@ -200,6 +198,14 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
         p[NIJK_MTR + 2] != (p[NIJK] + 1) * (p[NIJK + 1] + 1) || p[NIJK_MTR + 3] != p[NIJK + 3] || p[NIJK_MTR + 4] != p[NIJK + 4])
       return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric layout of a curvilinear zone must be node-dimensioned with 3 components per direction");
     if ((long long)n_mtr < 10 * nn) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short for a curvilinear zone");
+  }
+  if (homo) {
+    // ti, tj(NDIMDX_MTR, 2), tk(NDIMDX_MTR, 1) and vol on the nodes of one k-plane (nature_geom_dom.for:468-479)
+    const long long nn = (long long)(p[NIJK] + 1) * (p[NIJK + 1] + 1);
+    if (p[NDIMDX_MTR] != nn || p[NEQ_IJ] != 2 || p[NEQ_K] != 1 || p[NIJK_MTR] != 1 || p[NIJK_MTR + 1] != p[NIJK] + 1 ||
+        p[NIJK_MTR + 2] != 0 || p[NIJK_MTR + 3] != 2 || p[NIJK_MTR + 4] != 0)
+      return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric layout of a k-homogeneous zone must be that of one node plane, 2 + 2 + 1 components");
+    if ((long long)n_mtr < 6 * nn) return fail(ctx, FS_ERR_ARG, "fs_zone_add: metric array too short for a k-homogeneous zone");
   }
   if (twod) {
     // ti, tj(NDIMDX_MTR, 2) and vol on the nodes of one k-plane, no tk (nature_geom_dom.for:186-198)
@@ -243,7 +249,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   z.coe = r[DTC] / mtr[3];  // tstb3_global.for:72-78
   z.vol0 = mtr[3];
   // a two-dimensional zone runs through the curvilinear kernels: same formulas with zero z metrics and no k faces
-  z.ityp = twod ? 0 : p[ITYPZONE]; z.twod = twod ? 1 : 0; z.ndm = 0; z.mincj = z.minck = 0;
+  // a k-homogeneous zone too: general formulas, zero-padded metrics of one plane, no metric stride along k
+  z.ityp = (twod || homo) ? 0 : p[ITYPZONE]; z.twod = twod ? 1 : 0; z.homo = homo ? 1 : 0; z.ndm = 0; z.mincj = z.minck = 0;
   z.mt[0] = z.mt[1] = z.mt[2] = z.vol = nullptr;
   if (z.ityp == 0) {
     z.ndm = p[NDIMDX_MTR]; z.mincj = p[NIJK_MTR + 1]; z.minck = p[NIJK_MTR + 2];
@@ -420,6 +427,14 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       memcpy(&full[0], mtr, sizeof(double) * 2 * n);
       memcpy(&full[3 * n], mtr + 2 * n, sizeof(double) * 2 * n);
       memcpy(&full[9 * n], mtr + 4 * n, sizeof(double) * n);
+      e = hipMemcpy(zn.mtr_dev, full.data(), nb, hipMemcpyHostToDevice);
+    } else if (homo) {   // expand [ti(2) | tj(2) | tk(1) | vol]: zero z components of ti, tj, zero x, y components of tk
+      std::vector<double> full(10 * (size_t)z.ndm, 0.);
+      const size_t n = (size_t)z.ndm;
+      memcpy(&full[0], mtr, sizeof(double) * 2 * n);
+      memcpy(&full[3 * n], mtr + 2 * n, sizeof(double) * 2 * n);
+      memcpy(&full[8 * n], mtr + 4 * n, sizeof(double) * n);
+      memcpy(&full[9 * n], mtr + 5 * n, sizeof(double) * n);
       e = hipMemcpy(zn.mtr_dev, full.data(), nb, hipMemcpyHostToDevice);
     } else
       e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);

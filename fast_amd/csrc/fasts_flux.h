@@ -42,6 +42,10 @@ struct FsZone {
   int ityp;
   int twod;                // two-dimensional zone (one cell along k, no k faces); handled as a curvilinear zone
                            // whose surface vectors have a zero z component and whose tk is zero
+  int homo;                // k-homogeneous zone (zone type 1, an extruded mesh): handled as a curvilinear zone whose
+                           // metrics have no stride along k, ti / tj a zero z component and tk only a z component;
+                           // the z derivatives of the viscous flux and of the SA source take the factored form of
+                           // the reference's 3dhomo fragments
   long long ndm, mincj, minck;
   const double *mt[3];
   const double *vol;
@@ -302,7 +306,9 @@ FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, doubl
 // SA = true (Spalart-Allmaras): conductivity with the turbulent Prandtl number (mut_prandtltb_interface.for) and
 // the diffusion of nu_tilde added to flu[5] (SA/fluvisq_SA_3dfull_i.for, SA/assemble_tauij_3dfull.for,
 // SA/mut_interface.for); q(5, ...) = nu_tilde, q(0, 0, 0, dn) = density, q(4, 0, 0, dn) = temperature.
-template <bool SA = false, class Q, class TT>
+// HOMO (k-homogeneous zone; DIR = direction of the face): the z derivative as fluvisq_3dhomo_{i,j,k}.for write it, the difference of
+// the two sums along k times the one k-face surface, where the general fragment multiplies first.
+template <bool SA = false, int DIR = 0, bool HOMO = false, class Q, class TT>
 FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, double vol_r, double vol_l, double mul,
                                  double mur, double tcx, double tcy, double tcz, double *flu)
 {
@@ -329,6 +335,7 @@ FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, doubl
 #pragma unroll
     for (int m = 0; m < 3; m++)
       g[e - 1][m] = (f2 * tn1[m] - f1 * tn[m]) + (f4 * ta1[m] - f3 * ta[m]) + (f6 * tb1[m] - f5 * tb[m]);
+    if (HOMO) g[e - 1][2] = DIR == 0 ? (f6 - f5) * tb[2] : (DIR == 1 ? (f4 - f3) * ta[2] : (f2 - f1) * tn[2]);
     sum_lr[e - 1] = qr + ql;
   }
   double div = (g[0][0] + g[1][1] + g[2][2]) * z.cvisq;
@@ -361,7 +368,8 @@ FS_DEV void fs_flux_viscous_full(const FsZone &z, const Q &q, const TT &T, doubl
   if (SA) {
     double xm = xmulam + q(5, 0, 0, -1) * q(0, 0, 0, -1) + q(5, 0, 0, 0) * q(0, 0, 0, 0);
     xm = xm * volinv * (1. / (2. / 3.));
-    flu[5] = flu[5] - xm * (g[4][0] * tcx + g[4][1] * tcy + g[4][2] * tcz);
+    if (HOMO && DIR == 2) flu[5] = flu[5] - xm * g[4][2] * tcz;   // SA/fluvisq_SA_3dhomo_k.for: this order
+    else flu[5] = flu[5] - xm * (g[4][0] * tcx + g[4][1] * tcy + g[4][2] * tcz);
   }
 }
 

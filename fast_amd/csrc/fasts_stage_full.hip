@@ -29,7 +29,7 @@ template <int DIR> FS_DEV long long minc_of(const FsZone &z) { return DIR == 0 ?
 // FIRST: the sensor of the face is evaluated from the stencil and stored (0/1 byte); later stages read it.
 // TWOD: two-dimensional zone; the k stride of the field is taken as 0 (the cross terms along k then read the
 // cell itself and meet zero metrics: they vanish exactly, as in the reference's 2d fragments fluvisq_2d_{i,j}.for).
-template <int KFLU, int IFLOW, int DIR, bool FIRST, bool TWOD>
+template <int KFLU, int IFLOW, int DIR, bool FIRST, bool TWOD, bool HOMO = false>
 FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
                       unsigned char *__restrict__ wig, long long l, long long lt, const double *qm2,
                       const double *qm1, const double *q0, const double *qp1, double *flu)
@@ -85,7 +85,7 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
       const long long off = o == 0 ? 0 : (o == 1 ? -md : (o == 2 ? md : (o == 3 ? mc : mc - md)));
       return t[lt + off + m * ndm];
     };
-    fs_flux_viscous_full<IFLOW == 3>(z, q, T, z.vol[lt], z.vol[lt - md], xmut[l - inc], xmut[l], tcx, tcy, tcz, flu);
+    fs_flux_viscous_full<IFLOW == 3, DIR, HOMO>(z, q, T, z.vol[lt], z.vol[lt - md], xmut[l - inc], xmut[l], tcx, tcy, tcz, flu);
   }
 }
 
@@ -93,7 +93,7 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
 // + cb2 term) (SA/spsource_SA.for:100-130, SA/sourceSA_grad_3d.for, sourceSA_grad_2d.for, sourceSA_prod_dest.for).
 // qc = state of the cell; tsb / amu (may be null): production - destruction and the clipped rho*nu_tilde
 // (SA/sourceSA_LU.for).
-template <bool TWOD>
+template <bool TWOD, bool HOMO = false>
 FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ dlng, long long l,
                              long long lt, const double *qc, double *tsb = nullptr, double *amu = nullptr)
 {
@@ -128,6 +128,7 @@ FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, co
     const double u4 = (c + q[l4]), u5 = (c + q[l5]), u6 = (c + q[l6]);
 #pragma unroll
     for (int m = 0; m < 3; m++) g[v][m] = (TWOD && (m == 2 || v == 2)) ? 0. : grad(u1, u2, u3, u4, u5, u6, m);
+    if (HOMO) g[v][2] = (u5 - u6) * t0[2][2];   // SA/sourceSA_grad_3dhomo.for
   }
   const double rotx = g[2][1] - g[1][2], roty = g[0][2] - g[2][0], rotz = g[1][0] - g[0][1];
   const double rot = (TWOD ? fabs(rotz) : sqrt(rotx * rotx + roty * roty + rotz * rotz)) * xvol;
@@ -142,10 +143,13 @@ FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, co
   double u1 = (nc + n2), u2 = (nc + n3), u3 = (nc + n1), u4 = (nc + n4), u5 = (nc + n5), u6 = (nc + n6);
   double dudx = grad(u1, u2, u3, u4, u5, u6, 0), dudy = grad(u1, u2, u3, u4, u5, u6, 1);
   double dudz = TWOD ? 0. : grad(u1, u2, u3, u4, u5, u6, 2);
+  if (HOMO) dudz = (u5 - u6) * t0[2][2];
+  const double dudz0 = dudz;
   u1 = nc * rc + n2 * R[l2]; u2 = nc * rc + n3 * R[l3]; u3 = nc * rc + n1 * R[l1];
   u4 = nc * rc + n4 * R[l4]; u5 = nc * rc + n5 * R[l5]; u6 = nc * rc + n6 * R[l6];
   dudx = dudx * grad(u1, u2, u3, u4, u5, u6, 0); dudy = dudy * grad(u1, u2, u3, u4, u5, u6, 1);
   dudz = TWOD ? 0. : dudz * grad(u1, u2, u3, u4, u5, u6, 2);
+  if (HOMO) dudz = dudz0 * (u5 - u6) * t0[2][2];
   const double anvisc = TWOD ? c1 * (dudx + dudy) * xvol * xvol : c1 * (dudx + dudy + dudz) * xvol * xvol;
   const double amulam = fs_mulam_sa(z, qc[4]);
   const double anulam = rc / amulam;
@@ -174,7 +178,7 @@ FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, co
 
 // BDF = false: Runge-Kutta stage.  BDF = true: Newton residual of the implicit scheme (rop_out unused).
 // TWOD: one plane, no k faces: the cell is finished in the same step (+Fj- +Fi- -Fi+ -Fj+).
-template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD>
+template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO = false>
 __global__ void __launch_bounds__(256)
 k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
@@ -257,7 +261,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
         }
     };
     if (own && !TWOD) {
-      face_full<KFLU, IFLOW, 2, FIRST, TWOD>(z, rop, xmut, wig, l, lt, qa, qb, qc, qd, fk);
+      face_full<KFLU, IFLOW, 2, FIRST, TWOD, HOMO>(z, rop, xmut, wig, l, lt, qa, qb, qc, qd, fk);
       if (k > k0) {   // the cell below is complete
         double d[NQ];
 #pragma unroll
@@ -273,7 +277,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
         for (int e = 0; e < NQ; e++) {
           m2[e] = rop[e * nd + l - 2 * z.incj]; m1[e] = rop[e * nd + l - z.incj]; p1[e] = rop[e * nd + l + z.incj];
         }
-        face_full<KFLU, IFLOW, 1, FIRST, TWOD>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
+        face_full<KFLU, IFLOW, 1, FIRST, TWOD, HOMO>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
       }
       const int buf = (k - k0) & 1;
 #pragma unroll
@@ -284,7 +288,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
         for (int e = 0; e < NQ; e++) {
           m2[e] = rop[e * nd + l - 2]; m1[e] = rop[e * nd + l - 1]; p1[e] = rop[e * nd + l + 1];
         }
-        face_full<KFLU, IFLOW, 0, FIRST, TWOD>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fim);
+        face_full<KFLU, IFLOW, 0, FIRST, TWOD, HOMO>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fim);
       }
       double fip[NQ];
 #pragma unroll
@@ -292,7 +296,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
       __syncthreads();
       if (own) {
         double src = 0.;
-        if (NQ == 6) src = sa_source_full<TWOD>(z, rop, dlng, l, lt, qc);
+        if (NQ == 6) src = sa_source_full<TWOD, HOMO>(z, rop, dlng, l, lt, qc);
 #pragma unroll
         for (int e = 0; e < NQ; e++) {
           double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
@@ -310,7 +314,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
 
 // coe(:,6) of the implicit Spalart-Allmaras scheme on a curvilinear / two-dimensional zone (SA/sourceSA_LU.for),
 // interior plus one ghost layer (none along k on a two-dimensional zone)
-template <bool TWOD>
+template <bool TWOD, bool HOMO = false>
 __global__ void __launch_bounds__(256) k_sa_coe6_full(FsZone z, const double *__restrict__ rop,
                                                       const double *__restrict__ dlng, double *__restrict__ coe)
 {
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(256) k_sa_coe6_full(FsZone z, const double *__
 #pragma unroll
   for (int e = 0; e < 6; e++) qc[e] = rop[e * nd + l];
   double tsb, amu;
-  sa_source_full<TWOD>(z, rop, dlng, l, lt, qc, &tsb, &amu);
+  sa_source_full<TWOD, HOMO>(z, rop, dlng, l, lt, qc, &tsb, &amu);
   const double tsourcenu = z.vol[lt] * tsb / amu;
   coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
 }
@@ -336,6 +340,7 @@ void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, do
   const int gk = z.twod ? 0 : 1;
   dim3 g((z.iv + 2 + 255) / 256, z.jv + 2, z.kv + 2 * gk);
   if (z.twod) hipLaunchKernelGGL(k_sa_coe6_full<true>, g, dim3(256), 0, s, z, rop, dist, coe);
+  else if (z.homo) hipLaunchKernelGGL((k_sa_coe6_full<false, true>), g, dim3(256), 0, s, z, rop, dist, coe);
   else hipLaunchKernelGGL(k_sa_coe6_full<false>, g, dim3(256), 0, s, z, rop, dist, coe);
 }
 
@@ -359,6 +364,9 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
     if (z.twod)                                                                                               \
       hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop,  \
                          rop_out, drodm, xmut, wig, b, dist);                                                 \
+    else if (z.homo && F >= 2)   /* the Euler fluxes of a k-homogeneous zone are the general ones */         \
+      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false, (F >= 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, \
+                         rop, rop_out, drodm, xmut, wig, b, dist);                                            \
     else                                                                                                      \
       hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, \
                          rop_out, drodm, xmut, wig, b, dist);                                                 \

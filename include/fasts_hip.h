@@ -86,7 +86,8 @@ int fs_set_first_it(fs_ctx *ctx, int first_it);
  * cp_tijk.for:60-123, cp_vol.for:55-93); the array is copied to the device during this call.
  * Two-dimensional zone (ITYPZONE 3: one cell along k, NIJK(5) = 0): ti,tj(NDIMDX_MTR,2) and vol(NDIMDX_MTR)
  * on the nodes of one k-plane, no tk (nature_geom_dom.for:186-198, cp_tijk.for:376-402, cp_vol.for:177-212).
- * Zone type 1 (k-homogeneous) returns FS_ERR_UNSUPPORTED.
+ * k-homogeneous zone (ITYPZONE 1, an extruded mesh): ti,tj(NDIMDX_MTR,2), tk(NDIMDX_MTR,1) and vol(NDIMDX_MTR) on the
+ * nodes of one k-plane, no stride along k (nature_geom_dom.for:468-479, cp_tijk.for:196-289, cp_vol.for:115-146).
  * The BC table appended to param_int from PT_BC and the BC data appended to param_real
  * (Fast/FastC/FastC/PyTree.py:2958-3014) are read here: window data (pressure of a BCOutpres, wall temperature
  * of a BCWallViscousIsothermal, state arrays of a BCInflowSupersonic or BCInj1, the uniform state a far field or

@@ -28,6 +28,11 @@
 #define NIJK 0
 #define IJKV 20
 #define ITYPZONE 25
+/* zone types 0 (curvilinear) and 1 (k-homogeneous, an extruded mesh): metric arrays with three components per
+ * direction; the caller pads those of a type-1 zone with zeros and gives them a zero stride along k.  The reference's
+ * *_3dhomo_* fragments are the general ones without the terms the missing components multiply (the same bits),
+ * except for the z derivatives of the viscous flux and of the Spalart-Allmaras source: see `homo` below. */
+#define FULL3D(t) ((t) == 0 || (t) == 1)
 #define IFLOW 27
 #define ITYPCP 29
 #define KFLUDOM 33
@@ -166,6 +171,7 @@ typedef struct {
   long nd, inc[3];
   /* curvilinear zones (zone type 0): metric arrays ti,tj,tk(NDIMDX_MTR,3), vol(NDIMDX_MTR) */
   int ityp;
+  int homo;   /* zone type 1 */
   const double *t[3], *vol;
   long ndm, minc[3];
 } fluxctx;
@@ -590,6 +596,8 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
       double f6 = has_b ? q[ir] + q[il] + q[il + ib] + q[ir + ib] : 0.;
       for (int m = 0; m < 3; m++)
         g[e - 1][m] = (f2 * tn1[m] - f1 * tn[m]) + (f4 * ta1[m] - f3 * ta[m]) + (f6 * tb1[m] - f5 * tb[m]);
+      if (c->homo)   /* fluvisq_3dhomo_{i,j,k}.for: the one k-face surface factored out of the z derivative */
+        g[e - 1][2] = dir == 0 ? (f6 - f5) * tb[2] : (dir == 1 ? (f4 - f3) * ta[2] : (f2 - f1) * tn[2]);
     }
     const double *U = rop + nd, *V = rop + 2 * nd, *W = rop + 3 * nd;
     double div = (g[0][0] + g[1][1] + g[2][2]) * c->cvisq;
@@ -624,7 +632,8 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
       const double *R = rop, *N = rop + 5 * nd;
       double xm = xmulam + N[il] * R[il] + N[ir] * R[ir];
       xm = xm * volinv * c->sigma_1;
-      flu6 = flu6 - xm * (g[4][0] * tcx + g[4][1] * tcy + g[4][2] * tcz);
+      if (c->homo && dir == 2) flu6 = flu6 - xm * g[4][2] * tcz;   /* SA/fluvisq_SA_3dhomo_k.for: this order */
+      else flu6 = flu6 - xm * (g[4][0] * tcx + g[4][1] * tcy + g[4][2] * tcz);
     }
   }
   flu[0] = flu1; flu[1] = flu2; flu[2] = flu3; flu[3] = flu4; flu[4] = flu5;
@@ -635,6 +644,7 @@ static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const doubl
                          const double *tj, const double *tk, const double *vol)
 {
   c->ityp = p[ITYPZONE];
+  c->homo = p[ITYPZONE] == 1;
   c->t[0] = ti; c->t[1] = tj; c->t[2] = tk; c->vol = vol;
   c->ndm = p[NDIMDX_MTR];
   c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
@@ -692,7 +702,7 @@ static void flux_own(const i32 *p, const double *pr, const i32 *ind, const doubl
   const int neq = p[NEQ];
 #define FACE(l, i, j, k, dir)                                                                     \
   do {                                                                                            \
-    if (c.ityp == 0 || c.ityp == 3) face_flux_full(&c, rop, wig, xmut, (l), INDMTR(p, i, j, k), (dir), f); \
+    if (FULL3D(c.ityp) || c.ityp == 3) face_flux_full(&c, rop, wig, xmut, (l), INDMTR(p, i, j, k), (dir), f); \
     else face_flux(&c, rop, wig, xmut, (l), (dir), f);                                            \
   } while (0)
   const int twod = c.ityp == 3;
@@ -821,7 +831,7 @@ void fo_spsource_SA(const i32 *p, const double *pr, int nitcfg, const i32 *ind, 
   const double c1 = SA_CB2 / SA_SIGMA;
   const double cw1 = (SA_CB1 / SA_CKARM / SA_CKARM) + (1. + SA_CB2) / SA_SIGMA;
   const long incj = ni, inck = ninj;
-  const int cart = p[ITYPZONE] == 2, twod = p[ITYPZONE] == 3;
+  const int cart = p[ITYPZONE] == 2, twod = p[ITYPZONE] == 3, homo = p[ITYPZONE] == 1;
   const double tix = ti[0], tjy = tj[0], tkz = cart ? tk[0] : 0.;
   double xvol = 0.5 / vol[0];
   const long ndm = p[NDIMDX_MTR];
@@ -858,6 +868,7 @@ void fo_spsource_SA(const i32 *p, const double *pr, int nitcfg, const i32 *ind, 
           if (cart) { g[v][0] = (u3 - u1) * tix; g[v][1] = (u2 - u4) * tjy; g[v][2] = (u5 - u6) * tkz; }
           else if (twod && v == 2) { g[v][0] = g[v][1] = g[v][2] = 0.; }
           else for (int m = 0; m < 3; m++) g[v][m] = (twod && m == 2) ? 0. : GRAD(u1, u2, u3, u4, u5, u6, m);
+          if (homo) g[v][2] = (u5 - u6) * t0[2][2];   /* SA/sourceSA_grad_3dhomo.for */
         }
         const double rotx = g[2][1] - g[1][2], roty = g[0][2] - g[2][0], rotz = g[1][0] - g[0][1];
         const double rot = (twod ? fabs(rotz) : sqrt(rotx * rotx + roty * roty + rotz * rotz)) * xvol;
@@ -872,12 +883,15 @@ void fo_spsource_SA(const i32 *p, const double *pr, int nitcfg, const i32 *ind, 
         double dudx, dudy, dudz;
         if (cart) { dudx = (u3 - u1) * tix; dudy = (u2 - u4) * tjy; dudz = (u5 - u6) * tkz; }
         else { dudx = GRAD(u1, u2, u3, u4, u5, u6, 0); dudy = GRAD(u1, u2, u3, u4, u5, u6, 1); dudz = twod ? 0. : GRAD(u1, u2, u3, u4, u5, u6, 2); }
+        if (homo) dudz = (u5 - u6) * t0[2][2];
+        const double dudz0 = dudz;
         u1 = N[l] * R[l] + N[l2] * R[l2]; u2 = N[l] * R[l] + N[l3] * R[l3]; u3 = N[l] * R[l] + N[l1] * R[l1];
         u4 = N[l] * R[l] + N[l4] * R[l4]; u5 = N[l] * R[l] + N[l5] * R[l5]; u6 = N[l] * R[l] + N[l6] * R[l6];
         if (cart) { dudx = dudx * (u3 - u1) * tix; dudy = dudy * (u2 - u4) * tjy; dudz = dudz * (u5 - u6) * tkz; }
         else {
           dudx = dudx * GRAD(u1, u2, u3, u4, u5, u6, 0); dudy = dudy * GRAD(u1, u2, u3, u4, u5, u6, 1);
           dudz = twod ? 0. : dudz * GRAD(u1, u2, u3, u4, u5, u6, 2);
+          if (homo) dudz = dudz0 * (u5 - u6) * t0[2][2];
         }
         const double anvisc = twod ? c1 * (dudx + dudy) * xvol * xvol : c1 * (dudx + dudy + dudz) * xvol * xvol;
         const double T = rop[l + 4 * nd];
@@ -1053,7 +1067,7 @@ void fo_bc_wall_viscous(const i32 *p, int idir, const i32 *cl, double *rop)
 static void fo_bc_metric(const i32 *p, int idir, int i, int j, int k, const double *ti, const double *tj,
                          const double *tk, double *tc)
 {
-  if (p[ITYPZONE] == 0 || p[ITYPZONE] == 3) {
+  if (FULL3D(p[ITYPZONE]) || p[ITYPZONE] == 3) {
     const double *t = idir <= 2 ? ti : (idir <= 4 ? tj : tk);
     int q[3] = {i, j, k};
     if (idir % 2 == 0) q[(idir - 1) / 2] += 1;
@@ -1544,7 +1558,7 @@ void fo_bfl3(const i32 *p, const double *pr, const double *rop, double *drodm, c
         for (int j = cl[2]; j <= cl[3]; j++)
           for (int i = cl[0]; i <= cl[1]; i++) {
             const long l = INDDM(i, j, k), l0 = l - shift;
-            if (c.ityp == 0 || c.ityp == 3) face_flux_full(&c, rop, wig, xmut, l, INDMTR(p, i, j, k), d, f);
+            if (FULL3D(c.ityp) || c.ityp == 3) face_flux_full(&c, rop, wig, xmut, l, INDMTR(p, i, j, k), d, f);
             else face_flux(&c, rop, wig, xmut, l, d, f);
             for (int e = 0; e < 5; e++) drodm[l0 + e * nd] = drodm[l0 + e * nd] + f[e] * sens;
           }
@@ -1864,7 +1878,7 @@ void fo_tstb3_implicit(const i32 *p, const double *pr, int first_it, const i32 *
   const long ndm = p[NDIMDX_MTR];
   const long minc[3] = {p[NIJK_MTR], p[NIJK_MTR + 1], p[NIJK_MTR + 2]};
   const int twod = p[ITYPZONE] == 3;   /* tstb3_impli.for:315-380: the general formulas without z / w / k terms */
-  const int full = p[ITYPZONE] == 0 || twod;
+  const int full = FULL3D(p[ITYPZONE]) || twod;
   const double *T[3] = {ti, tj, tk};
   double tcc[3] = {ti[0], tj[0], twod ? 0. : tk[0]}, tc2c[3];
   for (int d = 0; d < 3; d++) tc2c[d] = sqrt(tcc[d] * tcc[d]);
@@ -2072,7 +2086,7 @@ static void luctx_init(luctx *c, const i32 *p, const double *pr, const double *t
   c->ndm = p[NDIMDX_MTR];
   c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
   c->twod = p[ITYPZONE] == 3;
-  c->full = p[ITYPZONE] == 0 || c->twod;
+  c->full = FULL3D(p[ITYPZONE]) || c->twod;
   c->neq = p[NEQ];
   c->t[0] = ti; c->t[1] = tj; c->t[2] = tk;
   c->tcc[0] = ti[0]; c->tcc[1] = tj[0]; c->tcc[2] = c->twod ? 0. : tk[0];
@@ -2205,7 +2219,7 @@ void fo_cpcfl3(const i32 *p, const double *pr, const double *rop, const double *
         const long l = INDDM(i, j, k);
         double surf = surf_c, volc = vol[0];
         double w = rop[l + 3 * nd];
-        if (typ == 0) {
+        if (FULL3D(typ)) {
           const long lt = INDMTR(p, i, j, k);
           double ddi = sqrt(ti[lt + inci] * ti[lt + inci] + ti[lt + inci + ndm] * ti[lt + inci + ndm] +
                             ti[lt + inci + 2 * ndm] * ti[lt + inci + 2 * ndm]);
@@ -2328,7 +2342,7 @@ int fo_invlussor(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm,
                  const double *coe)
 {
   GEOM(p)
-  if (p[NEQ] != 5 || p[ITYPZONE] == 3 || p[ITYPZONE] == 1) return -1;
+  if (p[NEQ] != 5 || p[ITYPZONE] == 3) return -1;
   const int nrelax = p[NB_RELAX];
   const double *coe5 = coe + 4 * nd;
   double b[6];

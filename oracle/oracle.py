@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfasts_oracle.so")
 _lib = None
 
-NIJK = 0; IJKV = 20; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NDIMDX = 41; NDIMDX_MTR = 43
+NIJK = 0; IJKV = 20; ITYPZONE = 25; NEQ = 36; NEQ_IJ = 37; NEQ_K = 38; NDIMDX = 41; NDIMDX_MTR = 43
 NSSITER = 58; DTC = 0; ITYPCP = 29; NEQ_COE = 39; IFLOW = 27; SIZE_SSDOM = 30
 
 
@@ -79,6 +79,19 @@ class OracleZone:
         self.ro = np.ascontiguousarray(ro, dtype=np.float64).reshape(-1).copy()
         self.ro_m1 = self.ro.copy(); self.ro_p1 = self.ro.copy()
         self.mtr = np.ascontiguousarray(mtr, dtype=np.float64).copy()
+        if int(p[ITYPZONE]) == 1:
+            # k-homogeneous zone (extruded mesh): ti, tj(:,1..2), tk(:,1) and vol of one plane, no stride along k.
+            # The reference runs its *_3dhomo_* fragments, which are the general ones without the terms that the
+            # missing components would multiply; here the vectors are padded with zeros and the zone goes through the
+            # general restatement with the same zero stride (adding a product by zero changes no bit of a sum), the z
+            # derivatives of the viscous flux and of the SA source excepted, which the C code takes in the factored
+            # form of those fragments.  tests/test_oracle_vs_ref.py holds this bit-exact against the compiled fragments.
+            nm = int(p[NDIMDX_MTR])
+            full = np.zeros(10 * nm)
+            full[0:2 * nm] = self.mtr[0:2 * nm]; full[3 * nm:5 * nm] = self.mtr[2 * nm:4 * nm]
+            full[8 * nm:9 * nm] = self.mtr[4 * nm:5 * nm]; full[9 * nm:] = self.mtr[5 * nm:6 * nm]
+            self.mtr = full
+            p[NEQ_IJ] = 3; p[NEQ_K] = 3
         nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
         self.ti = self.mtr[0:nm * nij]; self.tj = self.mtr[nm * nij:2 * nm * nij]
         self.tk = self.mtr[2 * nm * nij:2 * nm * nij + nm * nk]

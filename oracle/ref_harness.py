@@ -100,7 +100,6 @@ def ref_metrics(param_int, param_real, x, y, z):
     (loop range (1,1,1,1,1,1), Fast/FastC/FastC/Metric/indice_omp1.h:24-28)."""
     L = lib()
     p = np.ascontiguousarray(param_int, dtype=np.int32)
-    assert p[ITYPZONE] in (0, 2, 3), "ref_metrics: Cartesian, curvilinear and two-dimensional zones only"
     nm = int(p[NDIMDX_MTR]); nij = int(p[NEQ_IJ]); nk = int(p[NEQ_K])
     mtr = np.zeros(nm * (2 * nij + nk + 1))
     ti = mtr[0:nm * nij]; tj = mtr[nm * nij:2 * nm * nij]
@@ -113,6 +112,8 @@ def ref_metrics(param_int, param_real, x, y, z):
         f, fk = int(p[NIJK + 3]), int(p[NIJK + 4])
         ind = np.array([1 - f, int(p[IJKV]) + f, 1 - f, int(p[IJKV + 1]) + f, 1 - fk, int(p[IJKV + 2]) + fk],
                        dtype=np.int32)
+        if p[ITYPZONE] == 1:   # k-homogeneous zone: the metrics of the plane k = 1 (indice_omp1.h:19-23)
+            ind[4] = ind[5] = 1
     L.cp_tijk_(_p(p), _p(xf), _p(yf), _p(zf), _p(ti), _p(tj), _p(tk), _p(ti), _p(tj), _p(tk), _p(ind))
     L.cp_vol_(_p(p), _p(xf), _p(yf), _p(zf), _p(ti), _p(tj), _p(tk), _p(ti), _p(tj), _p(tk), _p(vol), _p(ind))
     return mtr

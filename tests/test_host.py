@@ -99,7 +99,7 @@ def test_switch_pointers_rotation():
     assert [FastC.level_buffer(z, s).ctypes.data for s in ('', '_M1', '_P1')] == a
 
 
-def test_zone_classification_curvilinear_accepted_k_homogeneous_refused():
+def test_zone_classification_curvilinear_and_k_homogeneous():
     t = cases.tgv(6, 'senseur')
     z = _zone(t)
     g = Internal.getNodeFromName1(z, 'GridCoordinates')
@@ -114,8 +114,11 @@ def test_zone_classification_curvilinear_accepted_k_homogeneous_refused():
     g = Internal.getNodeFromName1(z, 'GridCoordinates')
     x = Internal.getNodeFromName1(g, 'CoordinateX')[1]
     x[3, 3, :] += 0.01        # the same displacement on every k plane: k-homogeneous (type 1)
-    with pytest.raises((ValueError, NotImplementedError)):
-        prepare(t)
+    m = prepare(t)
+    pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
+    # metrics of one node plane: ti, tj with two components, tk with one, no stride along k
+    assert pint[25] == 1 and list(pint[5:10]) == [1, 11, 0, 2, 0] and pint[43] == 11 ** 2
+    assert pint[37] == 2 and pint[38] == 1 and m[0][0].size == 6 * 11 ** 2
 
 
 def test_golden_inputs_reproduced_by_host_model():

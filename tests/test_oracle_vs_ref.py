@@ -509,17 +509,53 @@ def test_split_box_equals_single_block_to_rounding():
     assert np.abs(a - b).max() < 1e-12
 
 
-@pytest.mark.parametrize("n,perturb", [((8, 8, 8), 0.), ((5, 9, 7), 0.), ((7, 9, 6), 0.2)])
-def test_host_metrics_equal_reference(n, perturb):
+IMPL = dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})
+
+
+@pytest.mark.parametrize("n,scheme,model,bcs,opts", [
+    ((9, 8, 7), 'senseur', 'NSLaminar', None, {}),
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', {'jmin': 'BCWall', 'jmax': 'BCWall'}, {}),
+    ((9, 8, 7), 'roe', 'NSLaminar', None, {}),      # a case where multiplying before subtracting changes a last bit
+    ((9, 8, 7), 'roe', 'NSLaminar', {'jmin': 'BCWall', 'kmax': 'BCWall'}, {}),
+    ((9, 8, 7), 'roe', 'Euler', {'imin': 'BCWallInviscid', 'jmax': 'BCFarfield'}, {}),
+    ((9, 8, 7), 'senseur', 'Euler', None, {}),
+    ((9, 8, 7), 'senseur', 'NSTurbulent', {'jmin': 'BCWall'}, {}),
+    ((10, 9, 8), 'roe', 'NSTurbulent', None, {}),
+    ((9, 8, 7), 'ausmpred', 'NSLaminar', {'jmin': 'BCWall', 'kmin': 'BCFarfield'}, IMPL),
+    ((9, 8, 7), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, IMPL),
+    ((10, 9, 8), 'roe', 'NSLaminar', {'jmin': 'BCWall'}, dict(IMPL, extra_numz={'nb_relax': 2})),
+])
+def test_homogeneous_zone_bit_exact(n, scheme, model, bcs, opts):
+    """k-homogeneous zones (zone type 1): the restatement runs the general formulas on zero-padded metrics of one
+    plane, with the z derivatives of the viscous flux and of the SA source factored as fluvisq_3dhomo_{i,j,k}.for and
+    SA/sourceSA_grad_3dhomo.for write them; the compiled reference runs its own *_3dhomo_* fragments (fluxes,
+    tstb3_impli.for:175-255, lu_{i,j,k}_3dhomogene.for, cpcfl3.for:142-187)."""
+    opts = dict(opts)
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    extra.update(opts.pop('extra_numz', {}))
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=0.2, homo=True, **opts)
+    so, sr = _pair(t)
+    assert int(so.zones[0].pint[25]) == 1
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    for it in range(1, 6):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+    assert np.isfinite(so.zones[0].ro).all()
+
+
+@pytest.mark.parametrize("n,perturb,homo", [((8, 8, 8), 0., False), ((5, 9, 7), 0., False), ((7, 9, 6), 0.2, False),
+                                            ((7, 9, 6), 0.2, True), ((11, 5, 8), 0.3, True)])
+def test_host_metrics_equal_reference(n, perturb, homo):
     """ti,tj,tk,vol built on the host equal the reference's cp_tijk / cp_vol bit for bit, and the
-    zone classification equals nature_geom_dom."""
-    t = cases.tgv(n, 'senseur', perturb=perturb)
+    zone classification equals nature_geom_dom (Cartesian, curvilinear and k-homogeneous zones)."""
+    t = cases.tgv(n, 'senseur', perturb=perturb, homo=homo)
     metrics = prepare(t)
     z = Internal.getZones(t)[0]
     pint, preal, xyz = zone_arrays(z)
     assert np.array_equal(metrics[0][0], R.ref_metrics(pint, preal, xyz[0], xyz[1], xyz[2]))
     typ, nijk_mtr, ndimdx_mtr, neq_ij, neq_k = R.ref_nature_geom_dom(xyz[0], xyz[1], xyz[2], 2, 2)
-    assert typ == int(pint[25]) == (0 if perturb else 2)
+    assert typ == int(pint[25]) == ((1 if homo else 0) if perturb else 2)
     assert nijk_mtr == [int(v) for v in pint[5:10]]
     assert ndimdx_mtr == int(pint[43]) and neq_ij == int(pint[37]) and neq_k == int(pint[38])
 
