@@ -236,6 +236,24 @@ extern "C" int fs_lu_stamp_fetch(long long *host)
 #define LUSTAMP(slot, wait)
 #endif
 
+// Value of the previous / next lane by a DPP row shift (a VALU move, no trip through the LDS crossbar as
+// __shfl_up / __shfl_down take).  Rows are 16 lanes, units 8: the first (last) lane of a unit receives the value of a
+// lane of the neighbouring unit or zero, and never uses it.
+FS_DEV double lane_prev(double x)
+{
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false);   // row_shr:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+FS_DEV double lane_next(double x)
+{
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, false);   // row_shl:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 template <bool FULL, int NE>
 __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
                                                       const double *__restrict__ rop, double *__restrict__ dw,
@@ -286,7 +304,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
-      const double up = __shfl_up(P[e], 1, 8);
+      const double up = lane_prev(P[e]);
       pin[e] = m == 0 ? P[e] : up;
     }
     if (m == st && active) {
@@ -354,7 +372,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
-      const double dn = __shfl_down(P[e], 1, 8);
+      const double dn = lane_next(P[e]);
       pin[e] = last_of_unit ? P[e] : dn;
     }
     if (m == st && active) {
@@ -445,7 +463,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
-      const double up = __shfl_up(P[e], 1, 8);
+      const double up = lane_prev(P[e]);
       pin[e] = m == 0 ? P[e] : up;
     }
     if (m == st && active) {
@@ -520,7 +538,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
-      const double dn = __shfl_down(P[e], 1, 8);
+      const double dn = lane_next(P[e]);
       pin[e] = last_of_unit ? P[e] : dn;
     }
     if (m == st && active) {
