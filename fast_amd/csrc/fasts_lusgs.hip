@@ -2,7 +2,8 @@
 // Built with -ffp-contract=off; expressions keep the operand order of the reference fragments
 //   coefficients   Fast/FastS/FastS/Compute/tstb3_global.for:64-78, tstb3c.for:62-76,86-176,262-311
 //   neighbour term LU/lu_{i,j,k}_3dcart.for, LU/lu_{i,j,k}_3dfull.for
-//   sweeps         LU/invlu_l.for, LU/invlu_u.for (nb_relax = 1, lu_match = 0), LU/lu_d.for, lu_dinv.for
+//   sweeps         LU/invlu_l.for, LU/invlu_u.for (nb_relax = 1, lu_match = 0), LU/lu_d.for, lu_dinv.for;
+//                  LU/invlu_overlap_l.for, invlu_overlap_u.for (lu_match = 1) with the LU-SSOR kernels below
 //   update         LU/mjr_newton.for
 //
 // The reference sweeps a zone in lexicographic order (k, j, then a serial i loop).  A cell only depends
@@ -494,7 +495,9 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
   }
 }
 
-template <bool FULL, bool LAST>
+// LUD: the upper sweep of LU-SGS with lu_match = 1 (LU/invlu_overlap_u.for): the increment of the lower sweep is
+// multiplied by the diagonal first (lu_d.for), the terms follow in the order i, j, k, no accumulator.
+template <bool FULL, bool LAST, bool LUD = false>
 __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuRange r, LuRange sdm, int nchunk, int h, int kbase,
                                                         const double *__restrict__ rop, const double *rop_kn, double *rop_new,
                                                         double *__restrict__ dout, double *__restrict__ ssor,
@@ -520,7 +523,12 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
     XAL = coe[l] * -0.5;
     double b[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) { A[e] = dout[l + e * nd]; S[e] = ssor[l + e * nd]; q[e] = rop[l + e * nd]; }
+    for (int e = 0; e < NE; e++) { A[e] = dout[l + e * nd]; S[e] = LUD ? 0. : ssor[l + e * nd]; q[e] = rop[l + e * nd]; }
+    if (LUD) {
+      const double c5 = coe[l + 4 * nd];
+#pragma unroll
+      for (int e = 0; e < NE; e++) A[e] = A[e] * c5;
+    }
     if (has_j) { lu_neighbour<FULL, 1, -1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BJ[e] = b[e] * XAL; }
     if (has_k) { lu_neighbour<FULL, 2, -1, NE>(z, c, l, lt, LAST ? rop_kn : rop, dout, coe, b); for (int e = 0; e < NE; e++) BK[e] = b[e] * XAL; }
     DG = 1. / coe[l + 4 * nd];
@@ -562,7 +570,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
   }
   if (active) {
 #pragma unroll
-    for (int e = 0; e < NE; e++) { dout[l + e * nd] = P[e]; ssor[l + e * nd] = S[e]; }
+    for (int e = 0; e < NE; e++) { dout[l + e * nd] = P[e]; if (!LUD) ssor[l + e * nd] = S[e]; }
     if (LAST && i >= sdm.i0 && i <= sdm.i1 && j >= sdm.j0 && j <= sdm.j1 && k >= sdm.k0 && k <= sdm.k1) {
       const double ro_old = q[0], u_old = q[1], v_old = q[2], w_old = q[3], t_old = q[4];
       const double rn = ro_old + P[0];
@@ -660,10 +668,13 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
 
 // LU-SSOR with nb_relax >= 2 on the range `range`, Newton update on the cells of `sdm` (the interior of the zone).
 // din = Newton residual (kept); work = 2 * neq * nd doubles (increments, accumulator).  In-place update as in fsk_lusgs.
-int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax, double gamma, const double *rop, double *rop_out,
-               double *scratch, const double *din, double *work, const double *coe, hipStream_t s)
+// overlap (nb_relax = 1): LU-SGS as the reference runs it with lu_match = 1 (LU/invlu.for:98-109, invlu_overlap_l.for,
+// invlu_overlap_u.for): one lower and one upper sweep with the neighbour terms in the order i, j, k, the increments
+// in the work array, the Newton update on `sdm`.
+int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax, int overlap, double gamma, const double *rop,
+               double *rop_out, double *scratch, const double *din, double *work, const double *coe, hipStream_t s)
 {
-  if (z.neq != 5 || z.twod || nb_relax < 2) return -1;
+  if (z.neq != 5 || z.twod || (overlap ? nb_relax != 1 : nb_relax < 2)) return -1;
   LuConst c;
   c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
   c.cv = z.cv; c.cvinv = 1. / z.cv; c.cvinv2 = 0.5 * c.cvinv;
@@ -695,7 +706,11 @@ int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax,
         dim3 g(gx8, (unsigned)(khi - klo + 1));
 #define FS_LO(F, M1) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, din, dout, ssor, coe)
 #define FS_UP(F, L) hipLaunchKernelGGL((k_ssor_upper_wave<F, L>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe)
-        if (pass == 0) {
+#define FS_UPD(F) hipLaunchKernelGGL((k_ssor_upper_wave<F, true, true>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe)
+        if (overlap) {
+          if (pass == 0) { if (full) FS_LO(true, true); else FS_LO(false, true); }
+          else { if (full) FS_UPD(true); else FS_UPD(false); }
+        } else if (pass == 0) {
           if (full) { if (m == 1) FS_LO(true, true); else FS_LO(true, false); }
           else { if (m == 1) FS_LO(false, true); else FS_LO(false, false); }
         } else {
@@ -704,8 +719,9 @@ int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax,
         }
 #undef FS_LO
 #undef FS_UP
+#undef FS_UPD
       }
-      if (!(last && pass == 1)) hipLaunchKernelGGL(k_ssor_reset, gr, dim3(256), 0, s, z, r, din, dout, ssor);
+      if (!overlap && !(last && pass == 1)) hipLaunchKernelGGL(k_ssor_reset, gr, dim3(256), 0, s, z, r, din, dout, ssor);
     }
   }
   if (inplace) hipLaunchKernelGGL(k_copy_range, gr, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);

@@ -2419,6 +2419,67 @@ int fo_invlussor(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm,
   return 0;
 }
 
+/* LU-SGS as the reference runs it with lu_match = 1 and one thread per zone (LU/invlu.for:98-109): invlu_overlap_l.for
+ * (the neighbour terms in the order i, j, k, increments built in a work array from the kept residual: mjr_drodm_IO.for,
+ * mjr_drodm.for, lu_dinv.for, lu_dinv_IO.for for the first cell) and invlu_overlap_u.for (plane by plane: multiplication
+ * by the diagonal lu_d.for, sweep, division, then the Newton update mjr_newton.for on the interior sdm).  With several
+ * threads the reference also lets the ranges of neighbouring thread blocks overlap (BC/BCzone.cpp:129-149): the result
+ * then depends on the number of threads; this is the single-thread result. */
+int fo_invlu_overlap(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm, const double *drodm_in, double *dout,
+                     const double *rop, double *rop_1, const double *ti, const double *tj, const double *tk,
+                     const double *coe)
+{
+  GEOM(p)
+  if (p[NEQ] != 5 || p[ITYPZONE] == 3) return -1;
+  const double *coe5 = coe + 4 * nd;
+  double b[6];
+  luctx c;
+  luctx_init(&c, p, pr, ti, tj, tk, +1);
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+        const double xal = coe[l] * c.signe;
+        const int has[3] = {i > ind[0], j > ind[2], k > ind[4]};
+        int first = 1;
+        for (int d = 0; d < 3; d++) {
+          if (!has[d]) continue;
+          lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
+          for (int e = 0; e < 5; e++)
+            dout[l + e * nd] = (first ? drodm_in[l + e * nd] : dout[l + e * nd]) + b[e] * xal;
+          first = 0;
+        }
+        const double diag = 1. / coe5[l];
+        for (int e = 0; e < 5; e++) dout[l + e * nd] = (first ? drodm_in[l + e * nd] : dout[l + e * nd]) * diag;
+      }
+  luctx_init(&c, p, pr, ti, tj, tk, -1);
+  for (int k = ind[5]; k >= ind[4]; k--) {
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const long l = INDDM(i, j, k);
+        const double diag = coe5[l];
+        for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+      }
+    for (int j = ind[3]; j >= ind[2]; j--)
+      for (int i = ind[1]; i >= ind[0]; i--) {
+        const long l = INDDM(i, j, k), lt = c.full ? INDMTR(p, i, j, k) : 0;
+        const double xal = coe[l] * c.signe;
+        const int has[3] = {i < ind[1], j < ind[3], k < ind[5]};
+        for (int d = 0; d < 3; d++) {
+          if (!has[d]) continue;
+          lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
+          for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] + b[e] * xal;
+        }
+        const double diag = 1. / coe5[l];
+        for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+      }
+    if (k >= sdm[4] && k <= sdm[5])
+      for (int j = sdm[2]; j <= sdm[3]; j++)
+        for (int i = sdm[0]; i <= sdm[1]; i++) mjr_newton5(pr, nd, INDDM(i, j, k), rop, dout, rop_1);
+  }
+  return 0;
+}
+
 /* One Newton sub-iteration of one zone, one cache block, one thread: sequence of
  * Fast/FastS/FastS/Compute/navier_stokes_struct.for:199-275 (viscosity and coefficients at the first
  * sub-iteration, on the whole zone), :295-301 (drodm = 0), :310-345 (fluxes), :406-419 (core3as2) and
@@ -2437,9 +2498,9 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   const int f = p[NIJK + 3], fk = p[NIJK + 4];
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
   const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
-  if (p[NB_RELAX] < 1 || p[LU_MATCH] != 0) return -1;
+  if (p[NB_RELAX] < 1 || (p[LU_MATCH] != 0 && p[NB_RELAX] > 1)) return -1;
   if (p[NEQ] != 5 && !(p[NEQ] == 6 && p[IFLOW] == 3)) return -1;
-  if (p[NB_RELAX] > 1 && (p[NEQ] != 5 || p[ITYPZONE] == 3)) return -1;
+  if ((p[NB_RELAX] > 1 || p[LU_MATCH] != 0) && (p[NEQ] != 5 || p[ITYPZONE] == 3)) return -1;
   const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);
@@ -2461,11 +2522,12 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   if (rhs_only) return 0;
   i32 lu[6];
   if (fo_bczone_rhs(p, drodm, ti, tj, tk, lu)) return -1;
-  if (p[NB_RELAX] > 1) {
+  if (p[NB_RELAX] > 1 || p[LU_MATCH] != 0) {
     const size_t n = (size_t)p[NEQ] * p[NDIMDX];
     double *w = (double *)calloc(2 * n, sizeof(double));
     if (!w) return -1;
-    const int rc = fo_invlussor(p, pr, lu, sdm, drodm, w, w + n, rop_ss, ro_p1, ti, tj, tk, coe);
+    const int rc = p[LU_MATCH] != 0 ? fo_invlu_overlap(p, pr, lu, sdm, drodm, w, rop_ss, ro_p1, ti, tj, tk, coe)
+                                    : fo_invlussor(p, pr, lu, sdm, drodm, w, w + n, rop_ss, ro_p1, ti, tj, tk, coe);
     free(w);
     return rc;
   }

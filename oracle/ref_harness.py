@@ -452,14 +452,15 @@ class RefSolver:
         return shift
 
     def _invlu(self, nd, zn, nitrun, nstep, ro_ssiter):
-        """Fast/FastS/FastS/Compute/lhs.cpp:135-161 for lu_match = 0.  nb_relax > 1: the increments are built in a work
+        """Fast/FastS/FastS/Compute/lhs.cpp:135-161.  nb_relax > 1 or lu_match = 1: the increments are built in a work
         array (iptdrodm_out = ssortmp, lhs.cpp:148) next to the accumulator ssor, both dimensioned on the window of
         the thread, here the whole zone with its ghost cells (Compute/ssor.cpp, lhs.cpp:184-200)."""
         L = lib()
         p = zn.pint
-        assert p[75] == 0, "lu_match = 0 only"
+        # lu_match = 1: the copy of the residual into the ghost cells of joins (lhs.cpp:1-15) is left out: with one
+        # thread per zone no sweep reads them (BC/BCzone.cpp:122-149)
         shift = self._bczone_rhs(nd, zn, nstep)
-        if p[71] > 1:
+        if p[71] > 1 or p[75] != 0:
             ssor_size = int(p[NIJK]) * int(p[NIJK + 1]) * int(p[NIJK + 2])
             neq = int(p[36])
             if getattr(zn, 'ssor', None) is None:

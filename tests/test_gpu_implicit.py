@@ -149,6 +149,62 @@ def test_ssor_relaxations_bit_exact_vs_oracle(n, scheme, model, perturb, bcs, nb
     assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4
 
 
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs,homo", [
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', 0., None, False),
+    ((40, 11, 35), 'senseur', 'Euler', 0., None, False),                   # several 8-cell units per line
+    ((12, 10, 9), 'senseur', 'NSLaminar', 0.15, None, False),              # curvilinear
+    ((10, 8, 9), 'roe', 'NSLaminar', 0.15, FAR, False),
+    ((12, 9, 10), 'ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, False),
+    ((10, 9, 8), 'senseur', 'NSLaminar', 0.2, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, True),
+])
+def test_lu_match_bit_exact_vs_oracle(n, scheme, model, perturb, bcs, homo):
+    """lu_match = 1: the sweeps of LU/invlu_overlap_l.for / invlu_overlap_u.for (terms in the order i, j, k); the
+    restatement is bit-exact against invlu_ of the compiled reference (test_oracle_vs_ref.py::
+    test_implicit_lu_match_bit_exact)."""
+    extra = dict(SINGLE, lu_match=1)
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb, homo=homo)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[75]) == 1 and int(pint[71]) == 1
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()
+    ro0 = oz.ro.copy()
+    for it in range(1, 5):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4
+
+
+def test_lu_match_blocks_with_joins():
+    blocks, nn = (2, 1, 2), (16, 9, 12)
+    nv = tuple(nn[d] // blocks[d] for d in range(3))
+    joins = connect.periodic_block_joins(blocks, nv)
+    kw = dict(model='NSLaminar', blocks=blocks, extra_numz=dict(SINGLE, lu_match=1), extra_numb={'ss_iteration': 3},
+              temporal_scheme='implicit', time_step=0.02, bcs={'jmin': 'BCWall'})
+    to = cases.tgv(nn, 'senseur', **kw)
+    m = prepare(to)
+    zs = []
+    for z, mm in zip(Internal.getZones(to), m):
+        p, pr, _ = zone_arrays(z)
+        zs.append(O.OracleZone(p, pr, FastC.level_buffer(z), mm[0]))
+    s = O.OracleSolver(zs, [(br, r, bd, d) for br, bd, r, d in joins])
+    s.fill_ghostcells()
+    t = cases.tgv(nn, 'senseur', **kw)
+    tc = C.node2Center(t)
+    connect.add_joins_to_tc(tc, joins, [z[0] for z in Internal.getZones(t)])
+    (t, tc, metrics) = FastS.warmup(t, tc)
+    zones = Internal.getZones(t)
+    for it in range(1, 4):
+        FastS._compute(t, metrics, it, tc)
+        s.step()
+        for z, oz in zip(zones, s.zones):
+            assert np.array_equal(FastC.level_buffer(z), oz.ro), "step %d zone %s" % (it, z[0])
+
+
 def test_ssor_outside_the_device_path_is_refused():
     from fast_amd import _capi
     t = cases.tgv((8, 8, 8), 'senseur', model='NSTurbulent', extra_numz=dict(SINGLE, nb_relax=2), extra_numb={'ss_iteration': 2},

@@ -510,6 +510,62 @@ def test_split_box_equals_single_block_to_rounding():
 
 
 IMPL = dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})
+WALLS = {'jmin': 'BCWall', 'jmax': 'BCFarfield', 'kmin': 'BCWall'}
+
+
+@pytest.mark.parametrize("n,scheme,model,bcs,kw,blocks", [
+    ((9, 8, 7), 'ausmpred', 'NSLaminar', None, {}, None),
+    ((12, 10, 9), 'senseur', 'NSLaminar', WALLS, {}, None),
+    ((10, 9, 8), 'roe', 'Euler', None, {'perturb': 0.15}, None),
+    ((10, 9, 8), 'senseur', 'NSLaminar', WALLS, {'perturb': 0.15}, None),
+    ((10, 9, 8), 'ausmpred', 'NSLaminar', WALLS, {'perturb': 0.2, 'homo': True}, None),
+    ((16, 9, 12), 'senseur', 'NSLaminar', None, {}, (2, 1, 2)),
+    ((16, 9, 12), 'ausmpred', 'NSLaminar', {'jmin': 'BCWall'}, {'perturb': 0.15}, (2, 1, 2)),
+])
+def test_implicit_lu_match_bit_exact(n, scheme, model, bcs, kw, blocks):
+    """lu_match = 1 (LU/invlu.for:98-109: invlu_overlap_l.for, invlu_overlap_u.for) with one thread per zone, against
+    invlu_ of the compiled reference.  The reference also copies the Newton residual into the ghost cells of joins
+    first (lhs.cpp:1-15); neither side does here, and the second half of the test shows why that is the same: the
+    reference's sweeps give the same bits with those ghost cells set to 1e30."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000, 'lu_match': 1}
+    nv = tuple(n[d] // blocks[d] for d in range(3)) if blocks else None
+
+    def run(poison, nit):
+        t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, blocks=blocks or (1, 1, 1), **kw, **IMPL)
+        so, sr = _pair(t, blocks, nv)
+        assert int(so.zones[0].pint[75]) == 1
+        if poison:
+            orig = sr._bczone_rhs
+
+            def poisoned(nd, zn, nstep):
+                p = zn.pint
+                ni, nj, nk, neq, ndx = int(p[0]), int(p[1]), int(p[2]), int(p[36]), int(p[41])
+                d = zn.drodm.reshape(neq, ndx)[:, :ni * nj * nk].reshape(neq, nk, nj, ni)
+                keep = d[:, 2:-2, 2:-2, 2:-2].copy()
+                d[...] = 1.e30
+                d[:, 2:-2, 2:-2, 2:-2] = keep
+                return orig(nd, zn, nstep)
+            sr._bczone_rhs = poisoned
+        so.fill_ghostcells(); sr.fill_ghostcells('ro')
+        for it in range(1, nit + 1):
+            so.step(); sr.step(it)
+            for a, b in zip(so.zones, sr.zones):
+                assert np.array_equal(a.ro, b.ro), "step %d" % it
+        return so.zones[0].ro.copy()
+
+    got = run(False, 5)
+    assert np.isfinite(got).all()
+    if blocks:
+        run(True, 2)
+    # not the sweeps of lu_match = 0: the terms are added in another order
+    extra['lu_match'] = 0
+    t0 = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, blocks=blocks or (1, 1, 1), **kw, **IMPL)
+    s0, _ = _pair(t0, blocks, nv)
+    s0.fill_ghostcells()
+    for it in range(5):
+        s0.step()
+    assert not np.array_equal(s0.zones[0].ro, got)
+    np.testing.assert_allclose(s0.zones[0].ro, got, rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("n,scheme,model,bcs,opts", [
