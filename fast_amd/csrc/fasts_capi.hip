@@ -174,10 +174,6 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: explicit and implicit zones cannot share a context");
   if (implicit && (p[NB_RELAX] < 1 || p[IMPLICITSOLVER] != 0))
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the implicit scheme is LU-SGS / LU-SSOR (no GMRES)");
-  if (implicit && (p[NB_RELAX] > 1 || p[LU_MATCH] != 0) && (p[NEQ] != 5 || twod))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: SSOR relaxations (nb_relax > 1) and lu_match = 1 are implemented for 5 equations on three-dimensional zones");
-  if (implicit && p[NB_RELAX] > 1 && p[LU_MATCH] != 0)
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: SSOR relaxations (nb_relax > 1) together with lu_match = 1 are not implemented");
   const bool sa = p[IFLOW] == 3 && p[NEQ] == 6;
   if (!sa && (p[NEQ] != 5 || p[IFLOW] > 2)) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: governing equations must be Euler, NSLaminar or NSTurbulent (Spalart-Allmaras)");
   if (sa && (p[47] > 1 || p[SA_DIST] != 1))
@@ -825,11 +821,12 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
         HIPCHK(ctx, hipStreamWaitEvent(ls, zn.ev_lu_fork, 0));
       }
       const int sdm[6] = {1, z.iv, 1, z.jv, 1, z.kv};
-      // lu_match = 1: the sweeps of invlu_overlap_{l,u}.for.  The reference also copies the Newton residual into the
+      // lu_match = 1: the sweeps of invlu_overlap_{l,u}.for (with nb_relax > 1, 5 equations: the LU-SSOR sweeps whatever
+      // lu_match is, LU/invlu.for:195-340).  The reference also copies the Newton residual into the
       // ghost cells of match joins first (lhs.cpp:1-15); no sweep reads them (the range grows into ghost cells only
       // over walls, whose BC then overwrites them, and between the thread blocks of a zone): nothing to do here
       const int lrc = (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
-                          ? fsk_lussor(z, zn.lu, sdm, zn.pint[NB_RELAX], zn.pint[LU_MATCH] != 0, zn.preal[GAMMA], zn.dev[in],
+                          ? fsk_lussor(z, zn.lu, sdm, zn.pint[NB_RELAX], zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
                                        zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
                           : fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
       if (ctx->lu_nstreams > 0) {

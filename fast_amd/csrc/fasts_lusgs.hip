@@ -422,13 +422,12 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
 // behind the sweep, when every successor of a cell has read its increment: after the sweep is the same).
 // LAST: last upper sweep, followed by the Newton update of the cells inside sdm (mjr_newton.for).
 // ------------------------------------------------------------------------------------------------------
-template <bool FULL, bool FIRSTM>
+template <bool FULL, bool FIRSTM, int NE = 5>
 __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
                                                         const double *__restrict__ rop, const double *__restrict__ din,
                                                         double *__restrict__ dout, double *__restrict__ ssor,
                                                         const double *__restrict__ coe)
 {
-  constexpr int NE = 5;
   const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
   const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
   const int j = r.j0 + h - cn - (k - r.k0);
@@ -440,7 +439,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
   const bool has_prev = active && i > r.i0;
   const bool has_j = active && j > r.j0, has_k = active && k > r.k0;
   double A[NE] = {}, S[NE] = {}, P[NE] = {}, BJ[NE] = {}, BK[NE] = {}, ST[4] = {0., 0., 0., 0.};
-  double CR = 0., XAL = 0., DG = 0.;
+  double CR = 0., XAL = 0., DG = 0., C6 = 1.;   // C6 = diagonal of the 6th equation, coe(:,6)
   double MI[26] = {};
   if (active) {
     XAL = coe[l] * 0.5;
@@ -450,6 +449,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
     if (has_j) { lu_neighbour<FULL, 1, 1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BJ[e] = b[e] * XAL; }
     if (has_k) { lu_neighbour<FULL, 2, 1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BK[e] = b[e] * XAL; }
     DG = 1. / coe[l + 4 * nd];
+    if (NE == 6) C6 = coe[l + 5 * nd];
     if (has_prev) {
       ST[0] = rop[l - 1 + nd]; ST[1] = rop[l - 1 + 2 * nd]; ST[2] = rop[l - 1 + 3 * nd]; ST[3] = rop[l - 1 + 4 * nd];
       CR = coe[l - 1 + nd];
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
       bool any = false;
       if (has_prev) {
         double b[NE];
-        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b);
+        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
 #pragma unroll
         for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = FIRSTM ? t : S[e] + t; }
         any = true;
@@ -486,7 +486,8 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
         for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = (FIRSTM && !any) ? BK[e] : S[e] + BK[e]; }
       }
 #pragma unroll
-      for (int e = 0; e < NE; e++) P[e] = A[e] * DG;
+      for (int e = 0; e < 5; e++) P[e] = A[e] * DG;
+      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;   // LU/lu_dinv_SA.for
     }
   }
   if (active) {
@@ -497,13 +498,12 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
 
 // LUD: the upper sweep of LU-SGS with lu_match = 1 (LU/invlu_overlap_u.for): the increment of the lower sweep is
 // multiplied by the diagonal first (lu_d.for), the terms follow in the order i, j, k, no accumulator.
-template <bool FULL, bool LAST, bool LUD = false>
+template <bool FULL, bool LAST, bool LUD = false, int NE = 5>
 __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuRange r, LuRange sdm, int nchunk, int h, int kbase,
                                                         const double *__restrict__ rop, const double *rop_kn, double *rop_new,
                                                         double *__restrict__ dout, double *__restrict__ ssor,
                                                         const double *__restrict__ coe)
 {
-  constexpr int NE = 5;
   const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
   const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
   const int j = r.j0 + h - cn - (k - r.k0);
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
   const bool has_j = active && j < r.j1, has_k = active && k < r.k1;
   const bool last_of_unit = m == 7 || i == r.i1;
   double A[NE] = {}, S[NE] = {}, P[NE] = {}, BJ[NE] = {}, BK[NE] = {}, ST[4] = {0., 0., 0., 0.};
-  double CR = 0., XAL = 0., DG = 0.;
+  double CR = 0., XAL = 0., DG = 0., C6 = 1.;
   double MI[26] = {};
   double q[NE] = {1., 0., 0., 0., 1.};
   if (active) {
@@ -524,10 +524,12 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
     double b[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) { A[e] = dout[l + e * nd]; S[e] = LUD ? 0. : ssor[l + e * nd]; q[e] = rop[l + e * nd]; }
+    if (NE == 6) C6 = coe[l + 5 * nd];
     if (LUD) {
       const double c5 = coe[l + 4 * nd];
 #pragma unroll
-      for (int e = 0; e < NE; e++) A[e] = A[e] * c5;
+      for (int e = 0; e < 5; e++) A[e] = A[e] * c5;
+      if (NE == 6) A[NE - 1] = A[NE - 1] * C6;   // LU/lu_d_SA.for
     }
     if (has_j) { lu_neighbour<FULL, 1, -1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BJ[e] = b[e] * XAL; }
     if (has_k) { lu_neighbour<FULL, 2, -1, NE>(z, c, l, lt, LAST ? rop_kn : rop, dout, coe, b); for (int e = 0; e < NE; e++) BK[e] = b[e] * XAL; }
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
     if (m == st && active) {
       if (has_next) {
         double b[NE];
-        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b);
+        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
 #pragma unroll
         for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = S[e] + t; }
       }
@@ -565,7 +567,8 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
         for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = S[e] + BK[e]; }
       }
 #pragma unroll
-      for (int e = 0; e < NE; e++) P[e] = A[e] * DG;
+      for (int e = 0; e < 5; e++) P[e] = A[e] * DG;
+      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
     }
   }
   if (active) {
@@ -580,7 +583,15 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
       const double wn = (ro_old * w_old + P[3]) * r_1;
       const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
       rop_new[l] = rn; rop_new[l + nd] = un; rop_new[l + 2 * nd] = vn; rop_new[l + 3 * nd] = wn;
-      rop_new[l + 4 * nd] = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+      const double tn = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+      rop_new[l + 4 * nd] = tn;
+      if (NE == 6) {   // LU/mjr_newton_SA.for: nu_tilde clipped to [0, ratiom * nu]
+        double anulam = fs_mulam_sa(z, tn);
+        anulam = anulam * r_1 * z.ratiom;
+        double t6 = (ro_old * q[NE - 1] + P[NE - 1]) * r_1;
+        t6 = fs_min(t6, anulam);
+        rop_new[l + 5 * nd] = fs_max(t6, 0.);
+      }
     }
   }
 }
@@ -591,7 +602,7 @@ __global__ void __launch_bounds__(256) k_ssor_reset(FsZone z, LuRange r, const d
   const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x, j = r.j0 + blockIdx.y, k = r.k0 + blockIdx.z;
   if (i > r.i1) return;
   const long long l = lcell(z, i, j, k);
-  for (int e = 0; e < 5; e++) { dout[l + e * z.nd] = din[l + e * z.nd] + ssor[l + e * z.nd]; ssor[l + e * z.nd] = 0.; }
+  for (int e = 0; e < z.neq; e++) { dout[l + e * z.nd] = din[l + e * z.nd] + ssor[l + e * z.nd]; ssor[l + e * z.nd] = 0.; }
 }
 
 __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const double *__restrict__ src,
@@ -674,7 +685,8 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
 int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax, int overlap, double gamma, const double *rop,
                double *rop_out, double *scratch, const double *din, double *work, const double *coe, hipStream_t s)
 {
-  if (z.neq != 5 || z.twod || (overlap ? nb_relax != 1 : nb_relax < 2)) return -1;
+  if ((z.neq != 5 && z.neq != 6) || (overlap ? nb_relax != 1 : nb_relax < 2)) return -1;
+  const bool sa = z.neq == 6;
   LuConst c;
   c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
   c.cv = z.cv; c.cvinv = 1. / z.cv; c.cvinv2 = 0.5 * c.cvinv;
@@ -704,9 +716,18 @@ int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax,
         int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
         int khi = h < nk - 1 ? h : nk - 1;
         dim3 g(gx8, (unsigned)(khi - klo + 1));
-#define FS_LO(F, M1) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, din, dout, ssor, coe)
-#define FS_UP(F, L) hipLaunchKernelGGL((k_ssor_upper_wave<F, L>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe)
-#define FS_UPD(F) hipLaunchKernelGGL((k_ssor_upper_wave<F, true, true>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe)
+#define FS_LO(F, M1)                                                                                                   \
+  do {                                                                                                                 \
+    if (sa) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, din, dout, ssor, coe); \
+    else hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, din, dout, ssor, coe);    \
+  } while (0)
+#define FS_UPX(F, L, D)                                                                                                \
+  do {                                                                                                                 \
+    if (sa) hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, 6>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe); \
+    else hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, 5>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe);    \
+  } while (0)
+#define FS_UP(F, L) FS_UPX(F, L, false)
+#define FS_UPD(F) FS_UPX(F, true, true)
         if (overlap) {
           if (pass == 0) { if (full) FS_LO(true, true); else FS_LO(false, true); }
           else { if (full) FS_UPD(true); else FS_UPD(false); }
@@ -720,6 +741,7 @@ int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax,
 #undef FS_LO
 #undef FS_UP
 #undef FS_UPD
+#undef FS_UPX
       }
       if (!overlap && !(last && pass == 1)) hipLaunchKernelGGL(k_ssor_reset, gr, dim3(256), 0, s, z, r, din, dout, ssor);
     }

@@ -2328,6 +2328,22 @@ static inline void mjr_newton5(const double *pr, long nd, long l, const double *
                                 rop_1[l + 3 * nd] * rop_1[l + 3 * nd]);
 }
 
+/* LU/mjr_newton_SA.for: the same, then nu_tilde clipped to [0, ratiom * nu] */
+static inline void mjr_newton_n(const double *pr, int neq, long nd, long l, const double *rop, const double *dw, double *rop_1)
+{
+  const double ro_old = rop[l], nu_old = neq == 6 ? rop[l + 5 * nd] : 0.;
+  mjr_newton5(pr, nd, l, rop, dw, rop_1);
+  if (neq == 6) {
+    const double cmus1 = pr[CS], temp01 = 1. / pr[TEMP0], coesut = pr[XMUL0] * (1. + cmus1 * temp01);
+    const double r_1 = 1. / rop_1[l];
+    double anulam = coesut * sqrt(rop_1[l + 4 * nd] * temp01) / (1. + cmus1 / rop_1[l + 4 * nd]);
+    anulam = anulam * r_1 * pr[18];
+    double t6 = (ro_old * nu_old + dw[l + 5 * nd]) * r_1;
+    t6 = dmin(t6, anulam);
+    rop_1[l + 5 * nd] = dmax(t6, 0.);
+  }
+}
+
 /* LU-SSOR with nb_relax >= 2 relaxations on the range ind of a three-dimensional zone, 5 equations, one thread whose
  * window is the whole zone (so the window index of the reference's work arrays is the cell index):
  * Fast/FastS/FastS/Compute/LU/invlu.for:195-340 calling invlussor1_l.for (first lower sweep: the increment starts from
@@ -2342,9 +2358,10 @@ int fo_invlussor(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm,
                  const double *coe)
 {
   GEOM(p)
-  if (p[NEQ] != 5 || p[ITYPZONE] == 3) return -1;
+  const int neq = p[NEQ];
+  if (neq != 5 && !(neq == 6 && p[IFLOW] == 3)) return -1;
   const int nrelax = p[NB_RELAX];
-  const double *coe5 = coe + 4 * nd;
+  const double *coe5 = coe + 4 * nd, *coe6 = coe + 5 * nd;   /* 6th equation: its own diagonal (lu_dinv_SA.for) */
   double b[6];
   luctx c;
   for (int m = 1; m <= nrelax; m++) {
@@ -2361,7 +2378,7 @@ int fo_invlussor(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm,
           for (int d = 0; d < 3; d++) {
             if (!has[d]) continue;
             lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
-            for (int e = 0; e < 5; e++) {
+            for (int e = 0; e < neq; e++) {
               if (m == 1 && first) { dout[l + e * nd] = drodm_in[l + e * nd] + b[e] * xal; ssor[l + e * nd] = b[e] * xal; }
               else { dout[l + e * nd] = dout[l + e * nd] + b[e] * xal; ssor[l + e * nd] = ssor[l + e * nd] + b[e] * xal; }
             }
@@ -2369,19 +2386,19 @@ int fo_invlussor(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm,
           }
           const double diag = 1. / coe5[l];
           if (m == 1 && first) {   /* first cell of the sweep: lu_dinv_IO.for */
-            for (int e = 0; e < 5; e++) { dout[l + e * nd] = drodm_in[l + e * nd] * diag; ssor[l + e * nd] = 0.; }
+            for (int e = 0; e < neq; e++) { dout[l + e * nd] = e < 5 ? drodm_in[l + e * nd] * diag : drodm_in[l + e * nd] / coe6[l]; ssor[l + e * nd] = 0.; }
           } else
-            for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+            for (int e = 0; e < neq; e++) dout[l + e * nd] = e < 5 ? dout[l + e * nd] * diag : dout[l + e * nd] / coe6[l];
           if (k > ind[4]) {
             const long l1 = l - ninj;
-            for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+            for (int e = 0; e < neq; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
           }
         }
     }
     for (int j = ind[2]; j <= ind[3]; j++)
       for (int i = ind[0]; i <= ind[1]; i++) {
         const long l1 = INDDM(i, j, ind[5]);
-        for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+        for (int e = 0; e < neq; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
       }
     /* ---- upper ---- */
     luctx_init(&c, p, pr, ti, tj, tk, -1);
@@ -2394,26 +2411,26 @@ int fo_invlussor(const i32 *p, const double *pr, const i32 *ind, const i32 *sdm,
           for (int d = 0; d < 3; d++) {
             if (!has[d]) continue;
             lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
-            for (int e = 0; e < 5; e++) { dout[l + e * nd] = dout[l + e * nd] + b[e] * xal; ssor[l + e * nd] = ssor[l + e * nd] + b[e] * xal; }
+            for (int e = 0; e < neq; e++) { dout[l + e * nd] = dout[l + e * nd] + b[e] * xal; ssor[l + e * nd] = ssor[l + e * nd] + b[e] * xal; }
           }
           const double diag = 1. / coe5[l];
-          for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+          for (int e = 0; e < neq; e++) dout[l + e * nd] = e < 5 ? dout[l + e * nd] * diag : dout[l + e * nd] / coe6[l];
         }
       if (last && k >= sdm[4] && k <= sdm[5])
         for (int j = sdm[2]; j <= sdm[3]; j++)
-          for (int i = sdm[0]; i <= sdm[1]; i++) mjr_newton5(pr, nd, INDDM(i, j, k), rop, dout, rop_1);
+          for (int i = sdm[0]; i <= sdm[1]; i++) mjr_newton_n(pr, neq, nd, INDDM(i, j, k), rop, dout, rop_1);
       if (!last && k < ind[5])
         for (int j = ind[3]; j >= ind[2]; j--)
           for (int i = ind[1]; i >= ind[0]; i--) {
             const long l1 = INDDM(i, j, k + 1);
-            for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+            for (int e = 0; e < neq; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
           }
     }
     if (!last)
       for (int j = ind[3]; j >= ind[2]; j--)
         for (int i = ind[1]; i >= ind[0]; i--) {
           const long l1 = INDDM(i, j, ind[4]);
-          for (int e = 0; e < 5; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
+          for (int e = 0; e < neq; e++) { dout[l1 + e * nd] = drodm_in[l1 + e * nd] + ssor[l1 + e * nd]; ssor[l1 + e * nd] = 0.; }
         }
   }
   return 0;
@@ -2430,8 +2447,9 @@ int fo_invlu_overlap(const i32 *p, const double *pr, const i32 *ind, const i32 *
                      const double *coe)
 {
   GEOM(p)
-  if (p[NEQ] != 5 || p[ITYPZONE] == 3) return -1;
-  const double *coe5 = coe + 4 * nd;
+  const int neq = p[NEQ];
+  if (neq != 5 && !(neq == 6 && p[IFLOW] == 3)) return -1;
+  const double *coe5 = coe + 4 * nd, *coe6 = coe + 5 * nd;
   double b[6];
   luctx c;
   luctx_init(&c, p, pr, ti, tj, tk, +1);
@@ -2445,12 +2463,15 @@ int fo_invlu_overlap(const i32 *p, const double *pr, const i32 *ind, const i32 *
         for (int d = 0; d < 3; d++) {
           if (!has[d]) continue;
           lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
-          for (int e = 0; e < 5; e++)
+          for (int e = 0; e < neq; e++)
             dout[l + e * nd] = (first ? drodm_in[l + e * nd] : dout[l + e * nd]) + b[e] * xal;
           first = 0;
         }
         const double diag = 1. / coe5[l];
-        for (int e = 0; e < 5; e++) dout[l + e * nd] = (first ? drodm_in[l + e * nd] : dout[l + e * nd]) * diag;
+        for (int e = 0; e < neq; e++) {
+          const double v = first ? drodm_in[l + e * nd] : dout[l + e * nd];
+          dout[l + e * nd] = e < 5 ? v * diag : v / coe6[l];
+        }
       }
   luctx_init(&c, p, pr, ti, tj, tk, -1);
   for (int k = ind[5]; k >= ind[4]; k--) {
@@ -2458,7 +2479,7 @@ int fo_invlu_overlap(const i32 *p, const double *pr, const i32 *ind, const i32 *
       for (int i = ind[0]; i <= ind[1]; i++) {
         const long l = INDDM(i, j, k);
         const double diag = coe5[l];
-        for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+        for (int e = 0; e < neq; e++) dout[l + e * nd] = dout[l + e * nd] * (e < 5 ? diag : coe6[l]);
       }
     for (int j = ind[3]; j >= ind[2]; j--)
       for (int i = ind[1]; i >= ind[0]; i--) {
@@ -2468,14 +2489,14 @@ int fo_invlu_overlap(const i32 *p, const double *pr, const i32 *ind, const i32 *
         for (int d = 0; d < 3; d++) {
           if (!has[d]) continue;
           lu_neighbour(&c, d, l, lt, rop, dout, coe, b);
-          for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] + b[e] * xal;
+          for (int e = 0; e < neq; e++) dout[l + e * nd] = dout[l + e * nd] + b[e] * xal;
         }
         const double diag = 1. / coe5[l];
-        for (int e = 0; e < 5; e++) dout[l + e * nd] = dout[l + e * nd] * diag;
+        for (int e = 0; e < neq; e++) dout[l + e * nd] = e < 5 ? dout[l + e * nd] * diag : dout[l + e * nd] / coe6[l];
       }
     if (k >= sdm[4] && k <= sdm[5])
       for (int j = sdm[2]; j <= sdm[3]; j++)
-        for (int i = sdm[0]; i <= sdm[1]; i++) mjr_newton5(pr, nd, INDDM(i, j, k), rop, dout, rop_1);
+        for (int i = sdm[0]; i <= sdm[1]; i++) mjr_newton_n(pr, neq, nd, INDDM(i, j, k), rop, dout, rop_1);
   }
   return 0;
 }
@@ -2498,9 +2519,8 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   const int f = p[NIJK + 3], fk = p[NIJK + 4];
   const i32 sdm[6] = {1, iv, 1, jv, 1, kv};
   const i32 all[6] = {1 - f, iv + f, 1 - f, jv + f, 1 - fk, kv + fk};
-  if (p[NB_RELAX] < 1 || (p[LU_MATCH] != 0 && p[NB_RELAX] > 1)) return -1;
+  if (p[NB_RELAX] < 1) return -1;
   if (p[NEQ] != 5 && !(p[NEQ] == 6 && p[IFLOW] == 3)) return -1;
-  if ((p[NB_RELAX] > 1 || p[LU_MATCH] != 0) && (p[NEQ] != 5 || p[ITYPZONE] == 3)) return -1;
   const double *rop_ss = nitcfg == 1 ? ro : ro_p1;
   if (nitcfg == 1) {
     if (p[IFLOW] == 2) fo_invist(p, pr, all, rop_ss, xmut);
@@ -2526,7 +2546,7 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
     const size_t n = (size_t)p[NEQ] * p[NDIMDX];
     double *w = (double *)calloc(2 * n, sizeof(double));
     if (!w) return -1;
-    const int rc = p[LU_MATCH] != 0 ? fo_invlu_overlap(p, pr, lu, sdm, drodm, w, rop_ss, ro_p1, ti, tj, tk, coe)
+    const int rc = (p[LU_MATCH] != 0 && p[NB_RELAX] == 1) ? fo_invlu_overlap(p, pr, lu, sdm, drodm, w, rop_ss, ro_p1, ti, tj, tk, coe)
                                     : fo_invlussor(p, pr, lu, sdm, drodm, w, w + n, rop_ss, ro_p1, ti, tj, tk, coe);
     free(w);
     return rc;

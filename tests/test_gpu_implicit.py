@@ -121,6 +121,7 @@ def test_implicit_blocks_with_joins(blocks, nn, scheme, perturb):
 
 @pytest.mark.parametrize("n,scheme,model,perturb,bcs,nb_relax", [
     ((12, 10, 9), 'ausmpred', 'NSLaminar', 0., None, 2),
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', 0., None, -2),                  # with lu_match = 1: the same sweeps
     ((40, 11, 35), 'senseur', 'Euler', 0., None, 3),                   # several 8-cell units per line
     ((12, 10, 9), 'senseur', 'NSLaminar', 0.15, None, 2),              # curvilinear
     ((10, 8, 9), 'roe', 'NSLaminar', 0.15, FAR, 2),
@@ -131,7 +132,8 @@ def test_ssor_relaxations_bit_exact_vs_oracle(n, scheme, model, perturb, bcs, nb
     """LU-SSOR with nb_relax > 1 (LU/invlu.for:195-340): the restatement is bit-exact against invlu_ of the compiled
     reference (test_oracle_vs_ref.py::test_implicit_lussor_bit_exact); the device sweeps hyperplanes and resets the
     increments after a sweep instead of one plane behind it."""
-    extra = dict(SINGLE, nb_relax=nb_relax)
+    extra = dict(SINGLE, nb_relax=abs(nb_relax), lu_match=int(nb_relax < 0))
+    nb_relax = abs(nb_relax)
     t = cases.tgv(n, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
                   temporal_scheme='implicit', time_step=0.02, perturb=perturb)
     (t, tc, metrics) = FastS.warmup(t, None)
@@ -205,9 +207,41 @@ def test_lu_match_blocks_with_joins():
             assert np.array_equal(FastC.level_buffer(z), oz.ro), "step %d zone %s" % (it, z[0])
 
 
-def test_ssor_outside_the_device_path_is_refused():
-    from fast_amd import _capi
-    t = cases.tgv((8, 8, 8), 'senseur', model='NSTurbulent', extra_numz=dict(SINGLE, nb_relax=2), extra_numb={'ss_iteration': 2},
-                  temporal_scheme='implicit', time_step=0.02)
-    with pytest.raises(_capi.FastsHipError, match="nb_relax"):
-        FastS.warmup(t, None)
+@pytest.mark.parametrize("dim,n,scheme,model,bcs,perturb,nb_relax,lu_match", [
+    (3, (10, 9, 8), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 2, 0),
+    (3, (10, 9, 8), 'ausmpred', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 2, 1),
+    (3, (10, 9, 8), 'roe', 'NSTurbulent', None, 0.15, 1, 1),
+    (2, (14, 12), 'ausmpred', 'NSLaminar', None, 0.15, 2, 0),
+    (2, (14, 12), 'senseur', 'NSLaminar', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 1, 1),
+    (2, (40, 11), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 2, 1),   # the reference's own use
+    (2, (40, 11), 'roe', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 1, 1),
+    (2, (14, 12), 'ausmpred', 'Euler', None, 0., 3, 1),
+])
+def test_ssor_and_lu_match_six_equations_and_two_dimensional(dim, n, scheme, model, bcs, perturb, nb_relax, lu_match):
+    """LU-SSOR relaxations and lu_match = 1 with the Spalart-Allmaras model (LU/invlussor*_SA.for, invlu_overlap_*_SA.for:
+    a decoupled 6th equation with its own diagonal) and on two-dimensional zones.  Restatement bit-exact against the
+    compiled reference on these cases; device bit for bit (5 equations) / 1e-12 (SA: device pow)."""
+    from common import wall_distance
+    extra = dict(SINGLE, nb_relax=nb_relax, lu_match=lu_match)
+    kw = dict(model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs, temporal_scheme='implicit',
+              time_step=0.02, perturb=perturb)
+    t = cases.tgv(n, scheme, **kw) if dim == 3 else cases.tgv2d(n, scheme, **kw)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    neq = int(pint[36])
+    assert int(pint[71]) == nb_relax and int(pint[75]) == lu_match
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z) if neq == 6 else None)
+    oz.fill_ghostcells()
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, 5):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        if neq == 6:
+            e = rel_err(got, oz.ro, int(pint[41]), neq=6)
+            assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+        else:
+            assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4

@@ -81,11 +81,8 @@ def test_unsupported_options_are_refused():
     t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCOutflow'})
     with pytest.raises(_capi.FastsHipError, match="tag 10"):
         FastS.warmup(t, None)
-    t = cases.tgv(8, 'senseur', model='NSTurbulent', temporal_scheme='implicit', extra_numz={'lu_match': 1})
-    with pytest.raises(_capi.FastsHipError, match="lu_match"):      # 5 equations only
-        FastS.warmup(t, None)
-    t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'lu_match': 1, 'nb_relax': 2})
-    with pytest.raises(_capi.FastsHipError, match="lu_match"):
+    t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'implicit_solver': 'gmres'})
+    with pytest.raises(_capi.FastsHipError, match="GMRES"):
         FastS.warmup(t, None)
 
 

@@ -521,6 +521,7 @@ WALLS = {'jmin': 'BCWall', 'jmax': 'BCFarfield', 'kmin': 'BCWall'}
     ((10, 9, 8), 'ausmpred', 'NSLaminar', WALLS, {'perturb': 0.2, 'homo': True}, None),
     ((16, 9, 12), 'senseur', 'NSLaminar', None, {}, (2, 1, 2)),
     ((16, 9, 12), 'ausmpred', 'NSLaminar', {'jmin': 'BCWall'}, {'perturb': 0.15}, (2, 1, 2)),
+    ((10, 9, 8), 'senseur', 'NSLaminar', WALLS, {'perturb': 0.15, 'nb_relax': 2}, None),     # with LU-SSOR relaxations
 ])
 def test_implicit_lu_match_bit_exact(n, scheme, model, bcs, kw, blocks):
     """lu_match = 1 (LU/invlu.for:98-109: invlu_overlap_l.for, invlu_overlap_u.for) with one thread per zone, against
@@ -528,6 +529,10 @@ def test_implicit_lu_match_bit_exact(n, scheme, model, bcs, kw, blocks):
     first (lhs.cpp:1-15); neither side does here, and the second half of the test shows why that is the same: the
     reference's sweeps give the same bits with those ghost cells set to 1e30."""
     extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000, 'lu_match': 1}
+    kw = dict(kw)
+    ssor = 'nb_relax' in kw
+    if ssor:
+        extra['nb_relax'] = kw.pop('nb_relax')
     nv = tuple(n[d] // blocks[d] for d in range(3)) if blocks else None
 
     def run(poison, nit):
@@ -564,8 +569,38 @@ def test_implicit_lu_match_bit_exact(n, scheme, model, bcs, kw, blocks):
     s0.fill_ghostcells()
     for it in range(5):
         s0.step()
-    assert not np.array_equal(s0.zones[0].ro, got)
-    np.testing.assert_allclose(s0.zones[0].ro, got, rtol=0, atol=1e-9)
+    if ssor:      # the relaxations of LU-SSOR are the same sweeps whatever lu_match is (LU/invlu.for:195-340)
+        assert np.array_equal(s0.zones[0].ro, got)
+    else:
+        assert not np.array_equal(s0.zones[0].ro, got)
+        np.testing.assert_allclose(s0.zones[0].ro, got, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("dim,n,scheme,model,bcs,perturb,nb_relax,lu_match", [
+    (3, (10, 9, 8), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 2, 0),
+    (3, (10, 9, 8), 'ausmpred', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 2, 1),
+    (3, (10, 9, 8), 'roe', 'NSTurbulent', None, 0.15, 1, 1),
+    (3, (10, 9, 8), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 1, 1),
+    (2, (14, 12), 'ausmpred', 'NSLaminar', None, 0.15, 2, 0),
+    (2, (14, 12), 'senseur', 'NSLaminar', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 1, 1),
+    (2, (40, 11), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 2, 1),
+    (2, (40, 11), 'roe', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 1, 1),
+    (2, (14, 12), 'ausmpred', 'Euler', None, 0., 3, 1),
+])
+def test_ssor_and_lu_match_six_equations_and_two_dimensional(dim, n, scheme, model, bcs, perturb, nb_relax, lu_match):
+    """LU-SSOR relaxations and lu_match = 1 with 6 equations (LU/invlussor1_l_SA.for, invlussor_l_SA.for,
+    invlussor_u_SA.for, invlu_overlap_l_SA.for, invlu_overlap_u_SA.for) and on two-dimensional zones (their 2d branches),
+    against invlu_ of the compiled reference."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000,
+             'lu_match': lu_match, 'nb_relax': nb_relax}
+    kw = dict(model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **IMPL)
+    t = cases.tgv(n, scheme, **kw) if dim == 3 else cases.tgv2d(n, scheme, **kw)
+    so, sr = _pair(t)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for it in range(1, 6):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+    assert np.isfinite(so.zones[0].ro).all()
 
 
 @pytest.mark.parametrize("n,scheme,model,bcs,opts", [
