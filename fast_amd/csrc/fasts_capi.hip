@@ -739,18 +739,22 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     const FsBdf *kbdf = deferred ? nullptr : pbdf;
     const int kfirst = deferred && ctx->implicit ? 1 : (nstep == 1);
     double *kout = deferred && ctx->implicit ? zn.scratch : zn.dev[out];
+    // the balance of the last Runge-Kutta stage is dead: the next step starts from zero (init_rhs.for), the norms
+    // are those of the first stage; kept when a later kernel of this stage reads it (wall-flux correction, local
+    // time step) and for a one-stage scheme, whose only stage is also the first
+    const int keep = ctx->implicit || deferred || dtloc || nstep < z.nssiter || nstep == 1;
     if (z.iflow == 3 && z.ityp != 0)
       krc = fsk_stage_sa(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut, zn.dist,
-                         (unsigned char *)zn.wig, kbdf, ctx->stream);
+                         (unsigned char *)zn.wig, kbdf, keep, ctx->stream);
     else if (z.ityp == 0)
       krc = fsk_stage_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
-                           (unsigned char *)zn.wig, kbdf, zn.dist, ctx->stream);
+                           (unsigned char *)zn.wig, kbdf, zn.dist, keep, ctx->stream);
     else {
       const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
       const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
       if (!split || nlist > 0)
         krc = fsk_stage_dma(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
-                            (unsigned char *)zn.wig, blist, nlist, kbdf, ctx->stream);
+                            (unsigned char *)zn.wig, blist, nlist, kbdf, keep, ctx->stream);
     }
     if (krc)
       return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": no kernel for this scheme / model");

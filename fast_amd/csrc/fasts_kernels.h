@@ -39,19 +39,21 @@ struct FsTiling { int nti, ntj, ntk, kchunk, ti, tj, pace; };
 FsTiling fsk_stage_dma_tiling(const FsZone &z);
 // bdf != NULL: the kernel writes the Newton residual of the implicit scheme to drodm instead of the
 // Runge-Kutta update (rop_out unused, coefH / coefW ignored)
+// keep_balance = 0 (Runge-Kutta form only): the balance is not written to drodm; for the last stage of a step, whose
+// balance no later stage, norm or correction reads
 int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                   double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, const FsBdf *bdf,
-                  hipStream_t s);
+                  int keep_balance, hipStream_t s);
 // stage kernel of curvilinear zones (zone type 0, fasts_stage_full.hip); sensors stored as bytes
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                    double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, const double *dist,
-                   hipStream_t s);
+                   int keep_balance, hipStream_t s);
 void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
 // Spalart-Allmaras on Cartesian zones (fasts_stage_sa.hip): total viscosity on the whole zone, stage kernel
 void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s);
 int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                  double *drodm, const double *xmut, const double *dist, unsigned char *wig, const FsBdf *bdf,
-                 hipStream_t s);
+                 int keep_balance, hipStream_t s);
 // coe(:,6), diagonal of the nu_tilde equation, interior + one ghost layer; needs coe(:,1) and coe(:,5)
 void fsk_sa_coe6(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
 // kinds: bit 0 = the table holds periodic / extrapolation windows (copy kernel), bit 1 = walls / far field.

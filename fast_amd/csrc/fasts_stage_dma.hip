@@ -136,7 +136,7 @@ FS_DEV double face_ij(const FsZone &z, const Smem &sm, int k, int rs, int c, dou
 // BDF = true: Newton residual of the implicit scheme (drodm = dt/vol * balance + BDF terms, rop_out unused).
 template <int KFLU, int IFLOW, bool FIRST, bool WIDE, bool BDF>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int ntile_j, int nblk, int pace,
+k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int ntile_j, int nblk, int pace, int keep,
             const double *__restrict__ rop, double *__restrict__ rop_out, double *__restrict__ drodm,
             const double *__restrict__ xmut, unsigned char *__restrict__ wig, const int *__restrict__ blist,
             FsBdf bdf)
@@ -352,8 +352,10 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
 #pragma unroll
           for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, r[e]);
         } else {
+          if (keep) {   // the balance of the last Runge-Kutta stage of a step is read by nothing
 #pragma unroll
-          for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, d[e]);
+            for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, d[e]);
+          }
           double o[5];
           fs_rk_update(z, coefW, qb, d, o);
 #pragma unroll
@@ -481,7 +483,7 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
 template <int KFLU, int IFLOW>
 void launch(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
             double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, const FsBdf *bdf,
-            hipStream_t s)
+            int keep, hipStream_t s)
 {
   const FsTiling t = fsk_stage_dma_tiling(z);
   const int nblk = blist ? nlist : t.nti * t.ntj * t.ntk;
@@ -493,7 +495,7 @@ void launch(const FsZone &z, double coefH, double coefW, int first, const double
   if (bdf) b = *bdf;
 #define FS_LAUNCH(FIRST_, WIDE_, BDF_)                                                                       \
   hipLaunchKernelGGL((k_stage_dma<KFLU, IFLOW, FIRST_, WIDE_, BDF_>), dim3(nblk), dim3(NTHREADS), 0, s, z, coefH, coefW, \
-                     t.kchunk, t.nti, t.ntj, nblk, t.pace, rop, rop_out, drodm, xmut, wig, blist, b)
+                     t.kchunk, t.nti, t.ntj, nblk, t.pace, keep, rop, rop_out, drodm, xmut, wig, blist, b)
   if (bdf) {
     if (first) { if (wide) FS_LAUNCH(true, true, true); else FS_LAUNCH(true, false, true); }
     else       { if (wide) FS_LAUNCH(false, true, true); else FS_LAUNCH(false, false, true); }
@@ -543,13 +545,13 @@ FsTiling fsk_stage_dma_tiling(const FsZone &z)
 
 int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                   double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, const FsBdf *bdf,
-                  hipStream_t s)
+                  int keep_balance, hipStream_t s)
 {
   // one k-plane must stay below 4 GiB / 8 so that in-plane byte offsets fit 32 bits
   if ((long long)z.ni * z.nj >= (1ll << 28)) return -2;
 #define FS_CASE(K, F)                                                                       \
   if (z.kflu == K && z.iflow == F) {                                                        \
-    launch<K, F>(z, coefH, coefW, first, rop, rop_out, drodm, xmut, wig, blist, nlist, bdf, s);  \
+    launch<K, F>(z, coefH, coefW, first, rop, rop_out, drodm, xmut, wig, blist, nlist, bdf, keep_balance, s);  \
     return 0;                                                                               \
   }
   FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)

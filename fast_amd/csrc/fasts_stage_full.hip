@@ -180,7 +180,7 @@ FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, co
 // TWOD: one plane, no k faces: the cell is finished in the same step (+Fj- +Fi- -Fi+ -Fj+).
 template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO = false>
 __global__ void __launch_bounds__(256)
-k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
+k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
              unsigned char *__restrict__ wig, FsBdf bdf, const double *__restrict__ dlng)
 {
@@ -243,8 +243,10 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, const double *__r
 #pragma unroll
           for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = o[e];
         } else {
+          if (keep) {   // the balance of the last Runge-Kutta stage of a step is read by nothing
 #pragma unroll
-          for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = d[e];
+            for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = d[e];
+          }
           fs_rk_update_c(z, coefW, coe, qcell, d, o);
           if (TWOD) o[3] = 0.;   // core3ark3.for:156-183
           if (NQ == 6) {   // nu_tilde clipped to [0, ratiom * nu_laminar] (core3ark3.for:196-236)
@@ -346,7 +348,7 @@ void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, do
 
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                    double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, const double *dist,
-                   hipStream_t s)
+                   int keep_balance, hipStream_t s)
 {
   if (z.ityp != 0 || !z.vol || !z.mt[0] || !z.mt[1] || !z.mt[2]) return -1;
   if (z.iflow == 3 && (z.neq != 6 || !dist)) return -1;
@@ -362,13 +364,13 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
 #define FS_GO(K, F, FIRST_, BDF_)                                                                             \
   do {                                                                                                        \
     if (z.twod)                                                                                               \
-      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop,  \
+      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop,  \
                          rop_out, drodm, xmut, wig, b, dist);                                                 \
     else if (z.homo && F >= 2)   /* the Euler fluxes of a k-homogeneous zone are the general ones */         \
-      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false, (F >= 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, \
+      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false, (F >= 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, \
                          rop, rop_out, drodm, xmut, wig, b, dist);                                            \
     else                                                                                                      \
-      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, \
+      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop, \
                          rop_out, drodm, xmut, wig, b, dist);                                                 \
   } while (0)
 #define FS_CASE(K, F)                                                                                         \

@@ -154,7 +154,7 @@ FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const d
 // (core3as2.for:49-231; rop_out unused).
 template <int KFLU, bool FIRST, bool BDF>
 __global__ void __launch_bounds__(256)
-k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, const double *__restrict__ rop,
+k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const double *__restrict__ rop,
            double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
            const double *__restrict__ dlng, unsigned char *__restrict__ wig, FsBdf bdf)
 {
@@ -211,8 +211,10 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, const double *__res
 #pragma unroll
           for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = o[e];
         } else {
+        if (keep) {   // the balance of the last Runge-Kutta stage of a step is read by nothing
 #pragma unroll
-        for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = d[e];
+          for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = d[e];
+        }
         fs_rk_update(z, coefW, qb, d, o);
 #pragma unroll
         for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
@@ -321,7 +323,7 @@ void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t
 
 int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                  double *drodm, const double *xmut, const double *dist, unsigned char *wig, const FsBdf *bdf,
-                 hipStream_t s)
+                 int keep_balance, hipStream_t s)
 {
   if (z.ityp != 2 || z.neq != 6 || z.iflow != 3 || !dist) return -1;
   int kchunk = 32;
@@ -330,7 +332,7 @@ int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const d
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
 #define FS_GO(K, FIRST_, BDF_)                                                                                  \
-  hipLaunchKernelGGL((k_stage_sa<K, FIRST_, BDF_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, rop, rop_out, drodm, \
+  hipLaunchKernelGGL((k_stage_sa<K, FIRST_, BDF_>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop, rop_out, drodm, \
                      xmut, dist, wig, b)
 #define FS_CASE(K)                                                                                              \
   if (z.kflu == K) {                                                                                            \
