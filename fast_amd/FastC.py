@@ -248,6 +248,10 @@ def _buildOwnData(t, Padding=None):
             extract_res = int(_get(dz, 'extract_res', 0))
             sgsmodel = _get(dz, 'sgsmodel', 'Miles')
             implicit_solver = _get(dz, 'implicit_solver', 'lussor')
+            sfd = int(_get(dz, 'sfd', 0))
+            sfd_chi = float(_get(dz, 'sfd_chi', 0.))
+            sfd_delta = float(_get(dz, 'sfd_delta', 1.e15))
+            sfd_init_iter = int(_get(dz, 'sfd_init_iter', 1))
             nit_inflow = int(_get(dz, 'inj1_newton_nit', 10))
             epsi_inflow = float(_get(dz, 'inj1_newton_tol', 1.e-5))
 
@@ -297,7 +301,7 @@ def _buildOwnData(t, Padding=None):
             pint[52] = rk; pint[53] = 1; pint[54] = exploc; pint[55] = 0; pint[56] = 1; pint[57] = 0
             pint[58] = nssiter
             pint[59] = cacheblckI; pint[60] = cacheblckJ; pint[61] = cacheblckK
-            pint[62] = 0; pint[63] = 1; pint[64] = islope; pint[65] = nit_inflow
+            pint[62] = sfd; pint[63] = sfd_init_iter; pint[64] = islope; pint[65] = nit_inflow
             pint[66] = shiftvar; pint[67] = extract_res; pint[68] = 0
             pint[69] = 0; pint[70] = 0
             pint[71] = nbr_relax; pint[72] = 1; pint[73] = 20
@@ -327,7 +331,7 @@ def _buildOwnData(t, Padding=None):
             preal[14] = epsi_newton; preal[15] = cfl
             preal[16] = azgris; preal[17] = addes; preal[18] = ratiom
             preal[22] = temps
-            preal[34] = psiroe; preal[35] = 0.; preal[36] = 1.e15
+            preal[34] = psiroe; preal[35] = sfd_chi; preal[36] = sfd_delta
             preal[37] = epsi_inflow; preal[38] = prandtltb; preal[39] = epsi_linear
             preal[40] = 1.
             preal[42] = 1. / math.sqrt(3.); preal[43] = 0.5; preal[51] = 0.985; preal[52] = 1.
@@ -1028,18 +1032,23 @@ def _createPrimVars(t):
                     raise ValueError("createPrimVars: field %s missing in zone %s." % (v, z[0]))
             pint = Internal.getNodeFromName2(z, 'Parameter_int')[1]
             ndimdx = int(pint[NDIMDX])
-            for suffix in ('', '_M1', '_P1'):
+            # selective frequency damping: the filtered state, zero unless the tree carries one
+            # (Fast/FastC/FastC/PyTree.py:357-361,678-687)
+            levels = ('', '_M1', '_P1') + (('_f',) if int(pint[62]) == 1 else ())
+            for suffix in levels:
                 buf = numpy.empty(len(vars_) * ndimdx, dtype=numpy.float64)
                 for c, v in enumerate(vars_):
                     src = Internal.getNodeFromName1(sol, v + suffix)
+                    zero = False
                     if src is None:
                         if suffix == '_M1':
                             first_it = 0
                         src = Internal.getNodeFromName1(sol, v)
+                        zero = suffix == '_f'
                         node = Internal.createChild(sol, v + suffix, 'DataArray_t', None)
                     else:
                         node = src
-                    a = src[1]
+                    a = src[1] * 0. if zero else src[1]
                     sh = a.shape
                     view = buf[c * ndimdx:c * ndimdx + a.size]
                     view[:] = a.reshape(-1, order='F')

@@ -116,6 +116,8 @@ def _new_context(zones, metrics, dtloc, device):
             if dist is None:
                 raise ValueError("warmup: zone %s uses the Spalart-Allmaras model and has no TurbulentDistance field" % z[0])
             ctx.zone_set_distance(nd, dist[1])
+        if int(pint[62]) == 1:     # selective frequency damping: the compacted *_f fields
+            ctx.zone_set_filtered(nd, FastC.level_buffer(z, '_f'))
         names[z[0]] = nd
     return ctx, names
 
@@ -205,8 +207,9 @@ def _computeEnstrophy(t, metrics):
     return (s[0] / s[2], s[1] / s[2])
 
 
-def sync_to_host(t=None, levels=_capi.FS_LEVEL_N | _capi.FS_LEVEL_M1 | _capi.FS_LEVEL_P1):
-    """Refresh the host arrays of the pyTree from the device."""
+def sync_to_host(t=None, levels=_capi.FS_LEVEL_N | _capi.FS_LEVEL_M1 | _capi.FS_LEVEL_P1 | _capi.FS_LEVEL_FILTERED):
+    """Refresh the host arrays of the pyTree from the device (time levels and, with selective frequency damping,
+    the filtered state)."""
     _ctx().download(levels)
 
 

@@ -11,10 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FASTS_HIP_LIB", os.path.join(HERE, "csrc", "libfasts_hip.so"))
 
 FS_LEVEL_N, FS_LEVEL_M1, FS_LEVEL_P1 = 1, 2, 4
+FS_LEVEL_FILTERED = 8      # fs_download only: the filtered state of selective frequency damping
 
 SYMBOLS = [
     "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif", "fs_set_first_it",
-    "fs_zone_add", "fs_zone_set_distance", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
+    "fs_zone_add", "fs_zone_set_distance", "fs_zone_set_filtered", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_tgv_sums_static", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
@@ -108,6 +109,15 @@ class Context:
         self._keep.append(d)
         self._chk(lib().fs_zone_set_distance(self._h, ctypes.c_int(int(zone)), _pd(d), ctypes.c_int(d.size)),
                   "fs_zone_set_distance")
+
+    def zone_set_filtered(self, zone, rof):
+        """rof: the contiguous NEQ * NDIMDX buffer of the filtered state (kept by the caller; refreshed by
+        download(FS_LEVEL_FILTERED))."""
+        if rof.dtype != numpy.float64 or not rof.flags['C_CONTIGUOUS']:
+            raise ValueError("zone_set_filtered: contiguous float64 buffer required")
+        self._keep.append(rof)
+        self._chk(lib().fs_zone_set_filtered(self._h, ctypes.c_int(int(zone)), _pd(rof), ctypes.c_longlong(rof.size)),
+                  "fs_zone_set_filtered")
 
     def set_first_it(self, first_it):
         self._chk(lib().fs_set_first_it(self._h, ctypes.c_int(int(first_it))), "fs_set_first_it")

@@ -14,7 +14,7 @@ namespace {
 // Parameter_int / Parameter_real slots (Fast/FastS/FastS/param_solver.h:77-306)
 enum { NIJK = 0, NIJK_MTR = 5, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
        NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
-       SLOPE = 64, PT_BC = 70, SA_LOW_RE = 130, SA_ROT_CORR = 131, SA_DIST = 132, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
+       SLOPE = 64, PT_BC = 70, SA_LOW_RE = 130, SA_ROT_CORR = 131, SA_DIST = 132, SFD = 62, SFD_INIT_IT = 63, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
 enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
        RONUTILDEINF = 8, CFL = 15, SA_RATIOM_R = 18, PRANDT_TUR = 38, VXINF = 19, VYINF = 20, VZINF = 21,
        PSIROE = 34 };
@@ -86,7 +86,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
     if (zn.ev_lu_fork) (void)hipEventDestroy(zn.ev_lu_fork);
     if (zn.ev_lu_join) (void)hipEventDestroy(zn.ev_lu_join);
@@ -123,6 +123,18 @@ extern "C" int fs_zone_set_distance(fs_ctx *ctx, int zone, const double *dist, i
   Zone &zn = ctx->zones[zone];
   if ((long long)n != (long long)zn.z.ni * zn.z.nj * zn.z.nk) return fail(ctx, FS_ERR_ARG, "fs_zone_set_distance: one value per cell, ghost cells included");
   zn.dist_host = dist;
+  return FS_OK;
+}
+
+extern "C" int fs_zone_set_filtered(fs_ctx *ctx, int zone, double *rof, long long n)
+{
+  if (!ctx || !rof) return ctx ? fail(ctx, FS_ERR_ARG, "fs_zone_set_filtered: null argument") : FS_ERR_ARG;
+  if (zone < 0 || zone >= (int)ctx->zones.size()) return fail(ctx, FS_ERR_ARG, "fs_zone_set_filtered: zone index out of range");
+  if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_zone_set_filtered: call before fs_upload");
+  Zone &zn = ctx->zones[zone];
+  if (zn.pint[SFD] != 1) return fail(ctx, FS_ERR_STATE, "fs_zone_set_filtered: the zone does not use selective frequency damping");
+  if (n != (long long)zn.z.neq * zn.z.nd) return fail(ctx, FS_ERR_ARG, "fs_zone_set_filtered: NEQ * NDIMDX values expected");
+  zn.rof_host = rof;
   return FS_OK;
 }
 
@@ -180,6 +192,9 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented as plain SA (no DES variant), "
                 "with a TurbulentDistance field");
   if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
+  if (p[SFD] != 0 && p[SFD] != 1) return fail(ctx, FS_ERR_ARG, "fs_zone_add: SFD must be 0 or 1");
+  if (p[SFD] == 1 && !implicit)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: selective frequency damping is implemented with the implicit scheme");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
   if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
   if (p[DTLOC] != 0 && p[DTLOC] != 1)
@@ -438,7 +453,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
       return fail(ctx, FS_ERR_HIP, std::string("fs_zone_add: metric upload: ") + hipGetErrorString(e));
     }
     z.mt[0] = zn.mtr_dev; z.mt[1] = zn.mtr_dev + 3 * z.ndm; z.mt[2] = zn.mtr_dev + 6 * z.ndm;
@@ -513,6 +528,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
     for (auto &zn : ctx->zones)
       if (zn.z.neq == 6 && !zn.dist_host)
         return fail(ctx, FS_ERR_STATE, "fs_upload: a Spalart-Allmaras zone needs fs_zone_set_distance first");
+  if (!ctx->uploaded)
+    for (auto &zn : ctx->zones)
+      if (zn.pint[SFD] == 1 && !zn.rof_host)
+        return fail(ctx, FS_ERR_STATE, "fs_upload: a zone with selective frequency damping needs fs_zone_set_filtered first");
   for (auto &zn : ctx->zones) {
     const size_t nb = sizeof(double) * (size_t)zn.z.neq * (size_t)zn.z.nd;
     if (!ctx->uploaded) {
@@ -570,6 +589,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
     }
     for (int r = 0; r < 3; r++)
       HIPCHK(ctx, hipMemcpyAsync(zn.dev[r], zn.host[r], nb, hipMemcpyHostToDevice, ctx->stream));
+    if (zn.rof_host) {
+      if (!zn.rof) HIPCHK(ctx, hipMalloc(&zn.rof, nb));
+      HIPCHK(ctx, hipMemcpyAsync(zn.rof, zn.rof_host, nb, hipMemcpyHostToDevice, ctx->stream));
+    }
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (!ctx->diag_out) HIPCHK(ctx, hipMalloc(&ctx->diag_out, sizeof(double) * 3));
@@ -591,6 +614,8 @@ extern "C" int fs_download(fs_ctx *ctx, int mask)
     const size_t nb = sizeof(double) * (size_t)zn.z.neq * (size_t)zn.z.nd;
     for (int r = 0; r < 3; r++)
       if (mask & bits[r]) HIPCHK(ctx, hipMemcpyAsync(zn.host[r], zn.dev[r], nb, hipMemcpyDeviceToHost, ctx->stream));
+    if ((mask & FS_LEVEL_FILTERED) && zn.rof)
+      HIPCHK(ctx, hipMemcpyAsync(zn.rof_host, zn.rof, nb, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FS_OK;
@@ -797,6 +822,13 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
               zn.res_out + 12 * z.nssiter, ctx->stream);
       zn.have_cfl = true;
     }
+    // selective frequency damping, once per time step in its last slot that runs (lhs.cpp:181-185): on a verification
+    // step after the residual of the verification slot (no join or BC follows, gsdr3.cpp:343,417), else after the LU
+    // solve of the last Newton sub-iteration, below
+    const bool sfd = zn.pint[SFD] == 1 && zn.rof;
+    const int sfd_pull = nitrun >= zn.pint[SFD_INIT_IT];
+    if (sfd && slot)
+      fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, zn.coe, ctx->stream);
     if (ctx->implicit && !slot) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:53-68,135-161)
       if (!zn.rhs_face.empty()) {   // wall faces: BCs on the residual, two ordered passes, then edges/corners
         fsk_bc_windows(z, (int)zn.rhs_face.size(), zn.rhs_face_dev, bc_kinds(zn.rhs_face), zn.rhs_max_cells, zn.drodm, ctx->stream);
@@ -833,6 +865,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
                           ? fsk_lussor(z, zn.lu, sdm, zn.pint[NB_RELAX], zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
                                        zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
                           : fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
+      if (sfd && !verif && nstep == z.nssiter - 1)
+        fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, zn.coe, ls);
       if (ctx->lu_nstreams > 0) {
         HIPCHK(ctx, hipEventRecord(zn.ev_lu_join, ls));
         lu_joins.push_back(zn.ev_lu_join);

@@ -19,6 +19,7 @@ struct Zone {
   double *coe = nullptr, *scratch = nullptr;
   double *ssor_work = nullptr;   // nb_relax > 1: increments and accumulator of the SSOR relaxations, 2 * neq * nd
   double *dist = nullptr;      // SA model: wall distance of every cell (fs_zone_set_distance)
+  double *rof = nullptr, *rof_host = nullptr;   // selective frequency damping: filtered state (fs_zone_set_filtered)
   const double *dist_host = nullptr;
   // implicit scheme with wall BCs: windows applied to the Newton residual before the LU solve (whole-face
   // extrapolation first, then the BCs of the wall faces) and the LU range (one ghost layer over wall faces)

@@ -31,6 +31,9 @@ struct FsBcWin {
 // depth = ghost layers covered besides the interior: 1 for the explicit scheme (navier_stokes_struct.for:223,
 // range ind_grad), the whole ghost depth for the implicit one (:219, range ind_coe)
 void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s);
+// selective frequency damping of the interior (Compute/sfd.for): rof relaxes towards rop, then (pull != 0) rop is
+// pulled towards rof; coe1 = dt/vol of every cell (coe(:,1) of the implicit scheme)
+void fsk_sfd(const FsZone &z, double chi, double delta, int pull, double *rop, double *rof, const double *coe1, hipStream_t s);
 // stage kernel of Cartesian zones, planes staged by LDS-DMA (fasts_stage_dma.hip): flux balance + Runge-Kutta update
 // (or Newton residual); at the first stage it also evaluates and stores the sensor.  The zone is cut in nti x ntj x ntk
 // tiles of ti x tj x kchunk cells, numbered bi + nti*(bj + ntj*bk); blist (device, nlist entries)

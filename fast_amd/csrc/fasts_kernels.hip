@@ -640,6 +640,31 @@ __global__ void __launch_bounds__(256) k_tgv_final(long long nrow, double zone_v
 
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+__global__ void __launch_bounds__(256) k_sfd(FsZone z, double chi, double delta, int pull, double *__restrict__ rop,
+                                             double *__restrict__ rof, const double *__restrict__ coe1)
+{
+  const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y, k = 1 + blockIdx.z;
+  if (i > z.iv) return;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  double vol = z.vol0;
+  if (z.ityp == 0)
+    vol = z.vol[(long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck];
+  const double cd = chi * delta;
+  const double xsi = exp(-(chi + 1. / delta) * coe1[l] * vol);
+  for (int e = 0; e < z.neq; e++) {
+    const long long m = l + e * z.nd;
+    const double f = 1. / (1. + cd) * ((1. - xsi) * rop[m] + (cd + xsi) * rof[m]);
+    rof[m] = f;
+    if (pull) rop[m] = 1. / (xsi + cd) * ((1. + cd) * xsi * rop[m] + (cd * (1. - xsi)) * f);
+  }
+}
+
+void fsk_sfd(const FsZone &z, double chi, double delta, int pull, double *rop, double *rof, const double *coe1, hipStream_t s)
+{
+  dim3 g((unsigned)((z.iv + 255) / 256), (unsigned)z.jv, (unsigned)z.kv);
+  hipLaunchKernelGGL(k_sfd, g, dim3(256), 0, s, z, chi, delta, pull, rop, rof, coe1);
+}
+
 void fsk_invist(const FsZone &z, int depth, const double *rop, double *xmut, hipStream_t s)
 {
   dim3 g(cdiv((long long)(z.iv + 2 * depth) * (z.jv + 2 * depth), 256), z.kv + 2 * (depth < z.ifick ? depth : z.ifick));

@@ -45,6 +45,7 @@ typedef struct fs_ctx fs_ctx;
 #define FS_LEVEL_N 1
 #define FS_LEVEL_M1 2
 #define FS_LEVEL_P1 4
+#define FS_LEVEL_FILTERED 8   /* fs_download only: the filtered state of selective frequency damping */
 
 /* Library version, build flags (for the "is the native path loaded" check). */
 const char *fs_version(void);
@@ -101,6 +102,15 @@ int fs_zone_add(fs_ctx *ctx, const int32_t *param_int, int n_int, const double *
  * (the TurbulentDistance field, which the reference keeps in the second slot of its viscosity array,
  * Fast/FastS/FastS/Compute/src_term.for:93-96).  The pointer must stay valid until fs_upload. */
 int fs_zone_set_distance(fs_ctx *ctx, int zone, const double *dist, int n);
+
+/* Selective frequency damping (Parameter_int[SFD] = 1; implicit scheme): host buffer of the filtered state of a zone,
+ * laid out like a time level (NEQ * NDIMDX doubles: Density_f, VelocityX_f ... compacted,
+ * Fast/FastC/FastC/PyTree.py:357-361,678-687), uploaded by fs_upload and read back by fs_download(FS_LEVEL_FILTERED).
+ * Once per time step, in its last sub-iteration that runs, the library applies sfd.for to the interior of the level
+ * just written (Fast/FastS/FastS/Compute/lhs.cpp:181-185, Compute/sfd.for) with SFD_CHI, SFD_DELTA of Parameter_real
+ * and, from time step SFD_INIT_IT on, pulls the state towards the filtered one.  The device exponential is not the
+ * host's: results agree with the reference to 1e-12, not bit for bit.  Call before fs_upload. */
+int fs_zone_set_filtered(fs_ctx *ctx, int zone, double *rof, long long n_doubles);
 
 /* Match-join ghost transfer tables (one entry per join "rac"): receiver zone, donor zone and
  * the two index lists (0-based, ghost-inclusive linear cell indices i + j*ni + k*ni*nj), i.e.

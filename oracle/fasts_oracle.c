@@ -2501,6 +2501,33 @@ int fo_invlu_overlap(const i32 *p, const double *pr, const i32 *ind, const i32 *
   return 0;
 }
 
+/* Selective frequency damping (Fast/FastS/FastS/Compute/sfd.for), once per implicit time step on the interior of the
+ * level the last sub-iteration has written (lhs.cpp:181-185): the filtered state rof relaxes towards the state, then,
+ * from time step SFD_INIT_IT on, the state is pulled towards the filtered state.  coe(:,1) = dt/vol. */
+void fo_sfd(const i32 *p, const double *pr, int nitrun, double *rop, double *rof, const double *coe, const double *vol)
+{
+  GEOM(p)
+  const double delta = pr[36], chi = pr[35], cd = chi * delta;
+  const int cart = p[ITYPZONE] == 2, neq = p[NEQ];
+  for (int ne = 0; ne < neq; ne++)
+    for (int k = 1; k <= p[IJKV + 2]; k++)
+      for (int j = 1; j <= p[IJKV + 1]; j++)
+        for (int i = 1; i <= p[IJKV]; i++) {
+          const long l = INDDM(i, j, k), lvo = cart ? 0 : INDMTR(p, i, j, k);
+          const double xsi = exp(-(chi + 1. / delta) * coe[l] * vol[lvo]);
+          rof[l + ne * nd] = 1. / (1. + cd) * ((1. - xsi) * rop[l + ne * nd] + (cd + xsi) * rof[l + ne * nd]);
+        }
+  if (nitrun < p[63]) return;
+  for (int ne = 0; ne < neq; ne++)
+    for (int k = 1; k <= p[IJKV + 2]; k++)
+      for (int j = 1; j <= p[IJKV + 1]; j++)
+        for (int i = 1; i <= p[IJKV]; i++) {
+          const long l = INDDM(i, j, k), lvo = cart ? 0 : INDMTR(p, i, j, k);
+          const double xsi = exp(-(chi + 1. / delta) * coe[l] * vol[lvo]);
+          rop[l + ne * nd] = 1. / (xsi + cd) * ((1. + cd) * xsi * rop[l + ne * nd] + (cd * (1. - xsi)) * rof[l + ne * nd]);
+        }
+}
+
 /* One Newton sub-iteration of one zone, one cache block, one thread: sequence of
  * Fast/FastS/FastS/Compute/navier_stokes_struct.for:199-275 (viscosity and coefficients at the first
  * sub-iteration, on the whole zone), :295-301 (drodm = 0), :310-345 (fluxes), :406-419 (core3as2) and

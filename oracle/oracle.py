@@ -110,6 +110,8 @@ class OracleZone:
         self.rdm = None; self.it_bloc = 0
         # OpenMP threads of the explicit sub-iteration (k-slabs; same result bit for bit)
         self.threads = 1
+        # selective frequency damping: filtered state (zero at the start) and the number of the time step
+        self.rof = None; self.nitrun = 0
 
     def fill_ghostcells(self):
         if lib().fo_bczone(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ti), _p(self.tj), _p(self.tk)) != 0:
@@ -121,10 +123,22 @@ class OracleZone:
         n = int(self.pint[NSSITER])
         return n - 1 if self.implicit else n
 
+    def sfd(self):
+        """Selective frequency damping of the level just written (once per implicit step)."""
+        if int(self.pint[62]) != 1:
+            return
+        if self.rof is None:
+            self.rof = np.zeros_like(self.ro)
+        lib().fo_sfd(_p(self.pint), _p(self.preal), ctypes.c_int(self.nitrun), _p(self.ro_p1), _p(self.rof), _p(self.coe),
+                     _p(self.vol))
+
     def step(self):
+        self.nitrun += 1
         if self.implicit:
             for nstep in range(1, self.nsub() + 1):
                 self.stage(nstep)
+                if nstep == self.nsub() and not self.verif:
+                    self.sfd()      # before the joins and BCs of the slot (lhs.cpp:181-185)
                 self.bcs(nstep)
             self.verification_slot()
             return self.rotate()
@@ -202,6 +216,7 @@ class OracleZone:
         """Last of the NSSITER slots of an implicit step: run only on verification steps, residual only."""
         if self.implicit and self.verif:
             self.stage(int(self.pint[NSSITER]))
+            self.sfd()              # no join or BC follows in this slot (gsdr3.cpp:343,417)
 
     def stage(self, nstep):
         if self.implicit:
@@ -264,9 +279,13 @@ class OracleSolver:
             z.fill_ghostcells()
 
     def step(self):
+        for z in self.zones:
+            z.nitrun += 1
         for nstep in range(1, self.zones[0].nsub() + 1):
             for z in self.zones:
                 z.stage(nstep)
+                if z.implicit and nstep == z.nsub() and not z.verif:
+                    z.sfd()
             self.transfers([z.roles(nstep)[1] for z in self.zones])
             for z in self.zones:
                 z.bcs(nstep)

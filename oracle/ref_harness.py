@@ -532,6 +532,14 @@ class RefSolver:
             out.append(np.array([enst.value, tke.value, cpt.value]))
         return out
 
+    def _sfd(self, zn, nitrun):
+        """sfd_ on the interior of the level the sub-iteration has written (lhs.cpp:184)."""
+        if int(zn.pint[62]) != 1:
+            return
+        if getattr(zn, 'rof', None) is None:
+            zn.rof = np.zeros_like(zn.ro)
+        lib().sfd_(_p(zn.pint), _p(zn.preal), _i(nitrun), _p(zn.ind_dm), _p(zn.ro_p1), _p(zn.rof), _p(zn.coe), _p(zn.vol))
+
     def step_implicit(self, nitrun):
         """One implicit time step: nssiter-1 Newton sub-iterations (the last slot of nssiter is the
         verification pass, skipped when lssiter_verif = 0: Fast/FastS/FastS/Compute/computePT.cpp:579-585),
@@ -549,11 +557,18 @@ class RefSolver:
                     zn.stage1_rhs = zn.drodm.copy()
                 if self.verif:     # lhs.cpp:90: the residual of the interior, before the LU solve
                     self._cprdu3s1(nd, zn, nitrun, nstep)
+            # selective frequency damping, once per step, in the last slot that runs (lhs.cpp:181-185): after the
+            # LU solve of slot nssiter-1, or, on a verification step, after the residual of slot nssiter
+            sfd_now = nstep == (nssiter if self.verif else nssiter - 1)
             if nstep == nssiter:   # verification slot: lexit_lu = 1 (souszones_list.cpp:83), nothing is advanced
+                for nd, zn in enumerate(self.zones):
+                    self._sfd(zn, nitrun)
                 break
             for nd, zn in enumerate(self.zones):
                 ssiter = zn.ro if nstep == 1 else zn.ro_p1
                 self._invlu(nd, zn, nitrun, nstep, ssiter)
+                if sfd_now:
+                    self._sfd(zn, nitrun)
             cl = [zn.ro_p1 for zn in self.zones]
             self._transfers(cl)
             for nd, zn in enumerate(self.zones):

@@ -245,3 +245,45 @@ def test_ssor_and_lu_match_six_equations_and_two_dimensional(dim, n, scheme, mod
         else:
             assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
     assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4
+
+
+@pytest.mark.parametrize("n,scheme,model,bcs,perturb,init,modulo", [
+    ((12, 10, 9), 'ausmpred', 'NSLaminar', None, 0., 1, 50),
+    ((10, 9, 8), 'senseur', 'NSLaminar', {'jmin': 'BCWall'}, 0.15, 3, 3),
+    ((10, 9, 8), 'roe', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 2, 2),
+    ((40, 11, 9), 'senseur', 'Euler', None, 0., 1, 1),
+])
+def test_selective_frequency_damping(n, scheme, model, bcs, perturb, init, modulo):
+    """sfd.for once per implicit step (lhs.cpp:181-185), before the joins and BCs of the last Newton sub-iteration or, on
+    a verification step, after the verification slot.  The restatement is bit-exact against sfd_ of the compiled
+    reference; the device exponential differs from the host's in the last bits: 1e-12."""
+    from common import wall_distance
+    extra = dict(SINGLE, sfd=1, sfd_chi=0.5, sfd_delta=0.3, sfd_init_iter=init)
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                  temporal_scheme='implicit', time_step=0.02, perturb=perturb, modulo_verif=modulo)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    neq = int(pint[36])
+    assert int(pint[62]) == 1
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z) if neq == 6 else None)
+    oz.fill_ghostcells()
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    for it in range(1, 7):
+        oz.verif = it % modulo == 0 or it == 1
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        e = rel_err(got, oz.ro, int(pint[41]), neq=neq)
+        assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+    FastS.sync_to_host(t)
+    rof = FastC.level_buffer(z, '_f')
+    assert np.abs(rof).max() > 0.1
+    assert rel_err(rof, oz.rof, int(pint[41]), neq=neq).max() < 1e-12
+
+
+def test_selective_frequency_damping_needs_the_implicit_scheme():
+    from fast_amd import _capi
+    t = cases.tgv((8, 8, 8), 'senseur', extra_numz=dict(SINGLE, sfd=1))
+    with pytest.raises(_capi.FastsHipError, match="frequency damping"):
+        FastS.warmup(t, None)

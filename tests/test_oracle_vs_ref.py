@@ -576,6 +576,40 @@ def test_implicit_lu_match_bit_exact(n, scheme, model, bcs, kw, blocks):
         np.testing.assert_allclose(s0.zones[0].ro, got, rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,scheme,model,bcs,perturb,init,verif", [
+    ((9, 8, 7), 'ausmpred', 'NSLaminar', None, 0., 1, False),
+    ((10, 9, 8), 'senseur', 'NSLaminar', {'jmin': 'BCWall'}, 0.15, 3, False),
+    ((10, 9, 8), 'roe', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 2, False),
+    ((10, 9, 8), 'senseur', 'NSLaminar', {'jmin': 'BCWall'}, 0.15, 2, True),
+])
+def test_selective_frequency_damping_bit_exact(n, scheme, model, bcs, perturb, init, verif):
+    """sfd.for, once per implicit time step in its last slot that runs (lhs.cpp:181-185): after the LU solve of the last
+    Newton sub-iteration, or, on a verification step, after the residual of the verification slot (then no join or BC
+    follows).  The restatement against sfd_ of the compiled reference: state and filtered state."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000,
+             'sfd': 1, 'sfd_chi': 0.5, 'sfd_delta': 0.3, 'sfd_init_iter': init}
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **IMPL)
+    so, sr = _pair(t)
+    assert int(so.zones[0].pint[62]) == 1 and int(so.zones[0].pint[63]) == init
+    so.zones[0].verif = verif; sr.verif = verif
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    before = None
+    for it in range(1, 6):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+        assert np.array_equal(so.zones[0].rof, sr.zones[0].rof), "filtered state, step %d" % it
+    assert np.abs(so.zones[0].rof).max() > 0.1
+    # the damping acts: not the undamped run
+    extra['sfd'] = 0
+    t0 = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **IMPL)
+    s0, _ = _pair(t0)
+    s0.zones[0].verif = verif
+    s0.fill_ghostcells()
+    for it in range(5):
+        s0.step()
+    assert np.abs(s0.zones[0].ro - so.zones[0].ro).max() > 1e-6
+
+
 @pytest.mark.parametrize("dim,n,scheme,model,bcs,perturb,nb_relax,lu_match", [
     (3, (10, 9, 8), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 2, 0),
     (3, (10, 9, 8), 'ausmpred', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 2, 1),
