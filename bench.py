@@ -31,7 +31,15 @@ BYTES_PER_CELL_STEP = {'senseur': 472.0, 'ausmpred': 400.0, 'roe': 400.0}
 
 
 def split_for(n):
-    return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n)
+    """Blocks of the periodic box per direction.  The i direction is never cut: a tile of the stage kernel is 64 cells
+    wide along i, so a cut there would put half of a 256-cell block into the tiles that feed halo messages."""
+    return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}.get(n)
+
+
+def block_cells(n, world):
+    """Cells of one block (one per GPU, n^3 cells each).  8 GPUs: the 512^3 box of the scaling configuration cut in
+    1 x 2 x 4 blocks of 2n x n x n/2 cells; fewer GPUs: cubic blocks."""
+    return (2 * n, n, n // 2) if world == 8 and n % 2 == 0 else (n, n, n)
 
 
 def _cpu_case(n, scheme):
@@ -162,7 +170,7 @@ def main():
         blocks = split_for(world)
         if blocks is None:
             raise SystemExit("bench.py: --gpus must be 1, 2, 4 or 8")
-        job = FastSmpi.tgv_job(a.n, blocks, a.scheme, model, rank, world, local_rank)
+        job = FastSmpi.tgv_job(block_cells(a.n, world), blocks, a.scheme, model, rank, world, local_rank)
         ctx = job.ctx
         run_step = job.step
         ncell_total = a.n ** 3 * world
@@ -217,7 +225,8 @@ def main():
                                    "TGV Re=1600 M=0.1, %d^3 cells per GPU, NSLaminar, scheme=%s, RK3, periodic"
                                    % (a.n, a.scheme) if model != 'Euler' else
                                    "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
-                       "blocks": list(split_for(world) or (1, 1, 1)), "ghost_layers": 2,
+                       "blocks": list(split_for(world) or (1, 1, 1)), "block_cells": list(block_cells(a.n, world)),
+                       "ghost_layers": 2,
                        "mesh": "two-dimensional C-mesh" if a.naca else ("curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"),
                        "time_scheme": ("implicit BDF1 local time step, LU-SGS, %d Newton sub-iterations" if a.naca else
                                        "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit if a.implicit else "explicit RK3"},

@@ -327,9 +327,9 @@ def _computeEnstrophy(t, metrics):
 
 
 class tgv_job:
-    """Weak-scaling Taylor-Green job: the periodic box is split in `blocks` equal blocks of n^3 cells,
-    dealt to the ranks in consecutive runs of blocks/world (one block per rank is the layout of
-    Fast/FastS/test/tgvMpi.py:29-50; several per rank gives local joins next to the messages)."""
+    """Weak-scaling Taylor-Green job: the periodic box is split in `blocks` equal blocks of n^3 cells (n: one number,
+    or the three cell counts of a block), dealt to the ranks in consecutive runs of blocks/world (one block per rank
+    is the layout of Fast/FastS/test/tgvMpi.py:29-50; several per rank gives local joins next to the messages)."""
 
     def __init__(self, n, blocks, scheme, model, my_rank=None, world=None, local_rank_=None, time_step=None,
                  transport=None, loopback=False, flat=False, **case_options):
@@ -343,13 +343,14 @@ class tgv_job:
         per = nb // world
         owner = [b // per for b in range(nb)]
         mine = [b for b in range(nb) if owner[b] == my_rank]
-        nn = (n * blocks[0], n * blocks[1], n * blocks[2])
+        nloc = (n, n, n) if isinstance(n, int) else tuple(int(v) for v in n)
+        nn = (nloc[0] * blocks[0], nloc[1] * blocks[1], nloc[2] * blocks[2])
         if time_step is None:
             time_step = 0.003 * 32. / max(nn)
         self.t = cases.tgv(nn, scheme, model=model, time_step=time_step, blocks=blocks, only=mine, **case_options)
         names = ['cart%d' % b for b in range(nb)]
         self.tc = C.node2Center(self.t)
-        joins = [j for j in connect.periodic_block_joins(blocks, (n, n, n)) if owner[j[1]] == my_rank]
+        joins = [j for j in connect.periodic_block_joins(blocks, nloc) if owner[j[1]] == my_rank]
         connect.add_joins_to_tc(self.tc, joins, names)
         self.graph = connect.graph_of(blocks, names, owner)
         if flat:     # hand the joins over as the flattened connectivity arrays (tc/Parameter_int, tc/Parameter_real)

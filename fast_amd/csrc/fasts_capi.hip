@@ -241,6 +241,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   z.nd = p[NDIMDX]; z.incj = z.ni; z.inck = (long long)z.ni * z.nj;
   z.kflu = p[KFLUDOM]; z.iflow = p[IFLOW]; z.neq = p[NEQ]; z.rk = p[RK]; z.nssiter = p[NSSITER];
   z.sensortype = p[SENSORTYPE];
+  z.split = 0;
   // constants, same expressions as Fast/FastS/FastS/Compute/template_FluxAndBalance.for:108-156
   const double *r = preal;
   z.tcx = mtr[0]; z.tcy = mtr[1]; z.tcz = mtr[2];
@@ -666,6 +667,7 @@ static int build_shell_lists(fs_ctx *ctx)
     for (auto &s : ctx->sends) if (s.donor_zone == (int)nz) zn.has_sends = true;
     for (auto &j : ctx->joins) if (j.donor_zone < 0 && j.rcv_zone == (int)nz) zn.has_recvs = true;
     if (z.ityp == 0 || ctx->implicit || z.iflow == 3 || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1) continue;   // these zones run their stage in one piece
+    zn.z.split = zn.has_sends ? 1 : 0;
     const FsTiling t = fsk_stage_dma_tiling(z);
     const int nblk = t.nti * t.ntj * t.ntk;
     std::vector<char> mark((size_t)nblk, 0);

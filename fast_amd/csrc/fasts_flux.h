@@ -39,6 +39,8 @@ struct FsZone {
   double gam4, sa_coesut, temp01, ratiom, sa_low_re, sa_rot_corr;
   // curvilinear zones (ityp 0): device arrays ti,tj,tk(ndm,3) and vol(ndm), dimensioned on the nodes;
   // metric index of cell (i,j,k) = (i+ific-1) + (j+ific-1)*mincj + (k+ifick-1)*minck
+  int split;               // some of its cells feed halo messages: the stage kernel is launched in two parts (the tiles
+                           // holding those cells first), so the zone is cut in more, thinner k chunks
   int ityp;
   int twod;                // two-dimensional zone (one cell along k, no k faces); handled as a curvilinear zone
                            // whose surface vectors have a zero z component and whose tk is zero

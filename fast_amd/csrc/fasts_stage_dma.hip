@@ -533,6 +533,9 @@ FsTiling fsk_stage_dma_tiling(const FsZone &z)
   }
   int nchunks = ncu / (t.nti * t.ntj);
   if (nchunks < 1) nchunks = 1;
+  // a zone whose stage runs in two parts around its halo messages: at least 8 chunks, so that the chunks that touch
+  // no k face (and the tiles that touch no i / j face) are most of the zone and run while the messages travel
+  if (z.split && nchunks < 8) nchunks = 8;
   t.kchunk = (z.kv + nchunks - 1) / nchunks;
   if (t.kchunk < 16) t.kchunk = 16;
   if (const char *ev = getenv("FASTS_HIP_KCHUNK")) t.kchunk = atoi(ev) > 0 ? atoi(ev) : t.kchunk;   // tuning aid
