@@ -255,16 +255,16 @@ FS_DEV double lane_next(double x)
   return __hiloint2double(hi, lo);
 }
 
-template <bool FULL, int NE>
+template <bool FULL, int NE, int U = 8>
 __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
                                                       const double *__restrict__ rop, double *__restrict__ dw,
                                                       const double *__restrict__ coe)
 {
-  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
+  const int u = threadIdx.x / U, m = threadIdx.x % U;
   // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
-  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
   const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * 8 + m;
+  const int i = r.i0 + cn * U + m;
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
   }
   LUSTAMP(2, true)
   // P of lane m holds: before its step, the increment of cell m-1 (lane 0: preloaded); after, its own
-  for (int st = 0; st < 8; st++) {
+  for (int st = 0; st < U; st++) {
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
@@ -328,23 +328,23 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
   LUSTAMP(4, true) LUSTAMP(7, false)
 }
 
-template <bool FULL, int NE>
+template <bool FULL, int NE, int U = 8>
 __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
                                                       const double *__restrict__ rop, const double *rop_kn,
                                                       double *rop_new, double *__restrict__ dw,
                                                       const double *__restrict__ coe)
 {
-  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
+  const int u = threadIdx.x / U, m = threadIdx.x % U;
   // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
-  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
   const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * 8 + m;
+  const int i = r.i0 + cn * U + m;
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
   const bool has_next = active && i < r.i1;
-  const bool last_of_unit = m == 7 || i == r.i1;     // its i+1 neighbour lies outside the unit
+  const bool last_of_unit = m == U - 1 || i == r.i1;     // its i+1 neighbour lies outside the unit
   double A[NE] = {}, P[NE] = {}, S[4] = {0., 0., 0., 0.};
   double CR = 0., XAL = 0., DG = 0., C6 = 1.;   // C6 = diagonal of the 6th equation, coe(:,6)
   double MI[26] = {};
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
       }
     }
   }
-  for (int st = 7; st >= 0; st--) {
+  for (int st = U - 1; st >= 0; st--) {
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
@@ -649,26 +649,36 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
   const bool sa = z.neq == 6;
-  const int nchunk = (ni + 7) / 8;
+  // units of U consecutive cells of an i-line: the recurrence of a launch has U steps, a sweep ni/U + nj + nk - 2
+  // launches of (cells of the hyperplane)/64 waves.  Measured at 256^3, 3 Newton sub-iterations: U = 4 40.2 ms per
+  // step (twice the waves in the large hyperplanes of mid-sweep), U = 8 31.5 ms, U = 16 33.5 ms; two-dimensional
+  // NACA0012 case 15.0 / 13.9 / 16.0 ms
+  constexpr int U = 8;
+  const int nchunk = (ni + U - 1) / U;
   const int nhc = nchunk + nj + nk - 2;
-  const unsigned gx8 = (unsigned)((nchunk + 7) / 8);
+  const int wpu = 64 / U;
+  const unsigned gx8 = (unsigned)((nchunk + wpu - 1) / wpu);
   for (int pass = 0; pass < 2; pass++)
     for (int n = 0; n < nhc; n++) {
       const int h = pass == 0 ? n : nhc - 1 - n;
       int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
       int khi = h < nk - 1 ? h : nk - 1;
       dim3 g(gx8, (unsigned)(khi - klo + 1));
+#define FS_LOW(F, N)                                                                                                            \
+  do {                                                                                                                          \
+    hipLaunchKernelGGL((k_lu_lower_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);             \
+  } while (0)
+#define FS_UPP(F, N)                                                                                                            \
+  do {                                                                                                                          \
+    hipLaunchKernelGGL((k_lu_upper_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe); \
+  } while (0)
       if (pass == 0) {
-        if (sa && full) hipLaunchKernelGGL((k_lu_lower_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-        else if (sa) hipLaunchKernelGGL((k_lu_lower_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-        else if (full) hipLaunchKernelGGL((k_lu_lower_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
-        else hipLaunchKernelGGL((k_lu_lower_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);
+        if (sa && full) FS_LOW(true, 6); else if (sa) FS_LOW(false, 6); else if (full) FS_LOW(true, 5); else FS_LOW(false, 5);
       } else {
-        if (sa && full) hipLaunchKernelGGL((k_lu_upper_wave<true, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-        else if (sa) hipLaunchKernelGGL((k_lu_upper_wave<false, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-        else if (full) hipLaunchKernelGGL((k_lu_upper_wave<true, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
-        else hipLaunchKernelGGL((k_lu_upper_wave<false, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe);
+        if (sa && full) FS_UPP(true, 6); else if (sa) FS_UPP(false, 6); else if (full) FS_UPP(true, 5); else FS_UPP(false, 5);
       }
+#undef FS_LOW
+#undef FS_UPP
     }
   if (inplace) {
     dim3 g((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
