@@ -39,7 +39,8 @@ def _run(world, args, timeout=240, worker='mpi_worker.py'):
 
 @pytest.mark.parametrize("world,blocks,nv", [(2, (1, 1, 2), (6, 5, 4)), (2, (2, 1, 1), (4, 6, 5)),
                                              (4, (1, 2, 2), (5, 4, 4)), (2, (1, 2, 2), (5, 4, 4)),
-                                             (2, (2, 2, 2), (4, 4, 4))])
+                                             (2, (2, 2, 2), (4, 4, 4)),
+                                             (8, (1, 2, 4), (8, 4, 4))])     # the 8-GPU split of bench.py
 def test_halo_exchange_matches_serial_multiblock(world, blocks, nv):
     rcs, outs = _run(world, list(blocks) + list(nv) + [3])
     assert rcs == [0] * world, "\n".join(outs)
