@@ -191,7 +191,9 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (sa && (p[47] > 1 || p[SA_DIST] != 1))
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented as plain SA (no DES variant), "
                 "with a TurbulentDistance field");
-  if (p[SLOPE] != 2) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: only slope 'o3' is implemented");
+  // slopes of the reference's flux tables: o3 for every scheme; o1 and minmod exist for roe alone (ROE/fluroe_select.for)
+  if (p[SLOPE] != 2 && !(p[KFLUDOM] == 5 && (p[SLOPE] == 1 || p[SLOPE] == 3)))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: slope must be 'o3' (or, with roe, 'o1' / 'minmod')");
   if (p[SFD] != 0 && p[SFD] != 1) return fail(ctx, FS_ERR_ARG, "fs_zone_add: SFD must be 0 or 1");
   if (p[SFD] == 1 && !implicit)
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: selective frequency damping is implemented with the implicit scheme");
@@ -259,6 +261,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   double c6 = 1. / 6.;
   z.c4 = 5. * c6; z.c5 = 2. * c6; z.c6 = -1. * c6;
   z.cvisq = 1. / 3;
+  z.slope = p[SLOPE];
+  z.tmin_1 = 100. / r[6];   // TINF (template_FluxAndBalance.for:136)
   z.dt = r[DTC];
   z.coe = r[DTC] / mtr[3];  // tstb3_global.for:72-78
   z.vol0 = mtr[3];

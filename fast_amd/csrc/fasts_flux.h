@@ -30,6 +30,8 @@ struct FsZone {
   int kflu, iflow, neq, rk, nssiter, sensortype;
   // fluid / scheme constants
   double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
+  double tmin_1;      // 100 / Tinf (minmod limiter)
+  int slope;          // 1 o1, 2 o3, 3 minmod (1 and 3: roe only)
   double tcx, tcy, tcz, si, sj, sk, volinv;
   double coe;              // dt/vol (constant on a Cartesian zone with a global time step)
   double vol0;             // cell volume of a Cartesian zone
@@ -77,6 +79,43 @@ template <class Q> FS_DEV double fs_wiggle(const Q &q)
   return test < -1e-12 ? 1. : 0.;
 }
 
+// statement function avmin of template_FluxAndBalance.for:92
+FS_DEV double fs_avmin(double c, double r)
+{
+  const double sg = copysign(1., c);
+  return sg * fs_max(0., fs_min(fabs(c), sg * r));
+}
+
+// Right (qm) and left (qp) states on the face between the cells of qm1_ and q0.  o3: Slope/o3_slope_var.for:2-3.
+// roe alone also has first-order states (slope 1, Slope/o1_slope_var.for) and the minmod limiter (slope 3,
+// Slope/minmod_slope_var.for: no slope where the temperature of the right cell is below 0.01 Tinf).
+template <int KFLU>
+FS_DEV void fs_states(const FsZone &z, const double *qm2, const double *qm1_, const double *q0, const double *qp1_,
+                      double *qm, double *qp)
+{
+  if (KFLU == 5 && z.slope != 2) {
+    if (z.slope == 1) {
+#pragma unroll
+      for (int e = 0; e < 5; e++) { qm[e] = q0[e]; qp[e] = qm1_[e]; }
+    } else {
+      const double roff = .5 * fs_max(0., fs_min(q0[4] * z.tmin_1 - .5, 1.));
+#pragma unroll
+      for (int e = 0; e < 5; e++) {
+        const double delm = q0[e] - qm1_[e], delp = qp1_[e] - q0[e], delq = qm1_[e] - qm2[e];
+        const double slp = roff * fs_avmin(delm, delp), slq = roff * fs_avmin(delq, delm);
+        qm[e] = q0[e] - slp;
+        qp[e] = qm1_[e] + slq;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    qm[e] = z.c4 * q0[e] + z.c5 * qm1_[e] + z.c6 * qp1_[e];
+    qp[e] = z.c4 * qm1_[e] + z.c6 * qm2[e] + z.c5 * q0[e];
+  }
+}
+
 // Inviscid flux through the face between cell l-inc and cell l in direction DIR.
 // qm2..qp1[e] = variable e at l-2inc, l-inc, l, l+inc; wg = sensor of the face (senseur only).
 // sa (may be NULL): receives u, tdu and the right / left density states, the inputs of the rho*nu_tilde flux
@@ -88,11 +127,7 @@ FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *q
   const double tc = DIR == 0 ? z.tcx : (DIR == 1 ? z.tcy : z.tcz);
   const double s = DIR == 0 ? z.si : (DIR == 1 ? z.sj : z.sk);
   double qm[5], qp[5];
-#pragma unroll
-  for (int e = 0; e < 5; e++) {
-    qm[e] = z.c4 * q0[e] + z.c5 * qm1_[e] + z.c6 * qp1_[e];
-    qp[e] = z.c4 * qm1_[e] + z.c6 * qm2[e] + z.c5 * q0[e];
-  }
+  fs_states<KFLU>(z, qm2, qm1_, q0, qp1_, qm, qp);
   constexpr int vn = 1 + DIR;
   double flu1, flu2, flu3, flu4, flu5;
   if (KFLU == 5) {
@@ -202,11 +237,7 @@ FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, doubl
 {
   const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
   double qm[5], qp[5];
-#pragma unroll
-  for (int e = 0; e < 5; e++) {
-    qm[e] = z.c4 * q0[e] + z.c5 * qm1_[e] + z.c6 * qp1_[e];
-    qp[e] = z.c4 * qm1_[e] + z.c6 * qm2[e] + z.c5 * q0[e];
-  }
+  fs_states<KFLU>(z, qm2, qm1_, q0, qp1_, qm, qp);
   double flu1, flu2, flu3, flu4, flu5;
   if (KFLU == 5) {
     const double gam = z.gam, rgp = z.rgp, gam1 = z.gam1, psiroe = z.psiroe;

@@ -7,9 +7,11 @@
  * (oracle/_ref/libfast_ref.so, built by oracle/build_ref.py) in tests/test_oracle_vs_ref.py
  * and against the fixtures under tests/golden/ that were generated from that library.
  *
- * Scope: zone type 2 (Cartesian, constant step), 5 equations, slope o3, schemes
- * ausmpred (1) / senseur (2) / roe (5), Euler or laminar Navier-Stokes, explicit RK1/2/3,
- * ghost fill for BCautoperiod, BCExtrapolate, BCFarfield, slip and adiabatic no-slip walls,
+ * Scope: zone types 0 (curvilinear), 1 (k-homogeneous), 2 (Cartesian, constant step) and 3 (two-dimensional);
+ * 5 equations or 6 (Spalart-Allmaras); schemes ausmpred (1) / senseur (2) / roe (5), slope o3 (roe also o1 and
+ * minmod); explicit RK1/2/3 with a global or a local time step; implicit BDF with LU-SGS, LU-SSOR, the overlap
+ * sweeps of lu_match and selective frequency damping; ghost fill for the boundary conditions cited at fo_bc_*,
+ * roe wall-flux correction,
  * edge/corner fix.  Array layout, loop ranges and
  * the order of floating-point operations follow the reference routines cited at each
  * function, so that with one cache block the results agree with the reference to rounding.
@@ -164,6 +166,8 @@ void fo_wiggle(const i32 *p, const i32 *ind, const double *rop, double *wig)
 
 typedef struct {
   int kflu, iflow;
+  int slope;        /* 1 o1, 2 o3, 3 minmod (roe only: ROE/fluroe_select.for) */
+  double tmin_1;    /* minmod: no slope below 0.01 Tinf (template_FluxAndBalance.for:136) */
   double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
   double tcx, tcy, tcz, si, sj, sk, volinv;
   /* Spalart-Allmaras (iflow 3): turbulent conductivity factor, Sutherland constants of mulam.for, 1/sigma */
@@ -176,6 +180,29 @@ typedef struct {
   long ndm, minc[3];
 } fluxctx;
 
+/* statement function of Fast/FastS/FastS/Compute/template_FluxAndBalance.for:92 */
+static inline double avmin(double c, double r)
+{
+  const double sg = copysign(1., c);
+  return sg * fmax(0., fmin(fabs(c), sg * r));
+}
+
+/* Right (qm) and left (qp) states of one variable q on the face between nm and l:
+ * Fast/FastS/FastS/Compute/Slope/o3_slope_var.for, o1_slope_var.for, minmod_slope_var.for.  t_l = temperature of l. */
+#define SLOPE_STATES(c, q, t_l, l, nm, nm2, np, qm_, qp_)                                   \
+  do {                                                                                     \
+    if ((c)->slope == 1) { qm_ = (q)[l]; qp_ = (q)[nm]; }                                  \
+    else if ((c)->slope == 3) {                                                            \
+      const double roff_ = .5 * fmax(0., fmin((t_l) * (c)->tmin_1 - .5, 1.));              \
+      const double delm_ = (q)[l] - (q)[nm], delp_ = (q)[np] - (q)[l], delq_ = (q)[nm] - (q)[nm2]; \
+      const double slp_ = roff_ * avmin(delm_, delp_), slq_ = roff_ * avmin(delq_, delm_); \
+      qm_ = (q)[l] - slp_; qp_ = (q)[nm] + slq_;                                           \
+    } else {                                                                               \
+      qm_ = (c)->c4 * (q)[l] + (c)->c5 * (q)[nm] + (c)->c6 * (q)[np];                      \
+      qp_ = (c)->c4 * (q)[nm] + (c)->c6 * (q)[nm2] + (c)->c5 * (q)[l];                     \
+    }                                                                                      \
+  } while (0)
+
 #define NIJK_MTR 5
 #define NDIMDX_MTR 43
 /* 0-based metric index (Fast/FastC/FastC/formule_mtr_param.h) */
@@ -184,7 +211,7 @@ typedef struct {
    (long)((k) + (p)[NIJK_MTR + 4] - 1) * (p)[NIJK_MTR + 2])
 
 /* Flux through the face between cell l-inc[dir] and cell l, direction dir (0 i, 1 j, 2 k).
- * Inviscid part: MUSCL o3 (Fast/FastS/FastS/Compute/Slope/o3_slope_var.for:2-3) then
+ * Inviscid part: left / right states (SLOPE_STATES: o3; o1 and minmod with roe) then
  *   ausmpred  Fast/FastS/FastS/Compute/AUSM/3dcart/fluFaceEuler_o3_3dcart_i.for + etat_GD.for
  *             + Vit_ent/qn_3dcart_i.for + Vit_ent/fluvector_3dcart_i.for
  *   senseur   Fast/FastS/FastS/Compute/SENSOR/3dcart/fluFaceEuler_o3_3dcart_i.for
@@ -201,8 +228,7 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
   double qm[5], qp[5];
   for (int e = 0; e < 5; e++) {
     const double *q = rop + e * nd;
-    qm[e] = c->c4 * q[l] + c->c5 * q[nm] + c->c6 * q[np];
-    qp[e] = c->c4 * q[nm] + c->c6 * q[nm2] + c->c5 * q[l];
+    SLOPE_STATES(c, q, rop[l + 4 * nd], l, nm, nm2, np, qm[e], qp[e]);
   }
   const int vn = 1 + dir; /* normal velocity component */
   double flu1, flu2, flu3, flu4, flu5, flu6 = 0., u_sa = 0., tdu_sa = 0.;
@@ -448,8 +474,7 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
   double qm[5], qp[5];
   for (int e = 0; e < 5; e++) {
     const double *q = rop + e * nd;
-    qm[e] = c->c4 * q[l] + c->c5 * q[nm] + c->c6 * q[np];
-    qp[e] = c->c4 * q[nm] + c->c6 * q[nm2] + c->c5 * q[l];
+    SLOPE_STATES(c, q, rop[l + 4 * nd], l, nm, nm2, np, qm[e], qp[e]);
   }
   double flu1, flu2, flu3, flu4, flu5, flu6 = 0., u_sa = 0., tdu_sa = 0.;
   if (c->kflu == 5) {
@@ -650,6 +675,8 @@ static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const doubl
   c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
   /* constants: Fast/FastS/FastS/Compute/template_FluxAndBalance.for:108-156 */
   c->kflu = p[KFLUDOM]; c->iflow = p[IFLOW];
+  c->slope = p[KFLUDOM] == 5 ? p[SLOPE] : 2;
+  c->tmin_1 = 100. / pr[TINF];
   c->tcx = ti[0]; c->tcy = tj[0]; c->tcz = p[ITYPZONE] == 3 ? 0. : tk[0];
   c->si = fabs(c->tcx); c->sj = fabs(c->tcy); c->sk = fabs(c->tcz);
   c->volinv = 0.5 / vol[0];

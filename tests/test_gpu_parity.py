@@ -187,3 +187,55 @@ def test_explicit_local_time_step(kind, n, scheme, model, perturb, bcs):
             np.testing.assert_allclose(l2, rl2, rtol=1e-11)
             np.testing.assert_allclose(loo, rloo, rtol=1e-13)
     assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-6
+
+
+@pytest.mark.parametrize("scheme,model,kind,n,perturb,bcs,kw", [
+    ('roe_min', 'NSLaminar', 'tgv', (70, 9, 12), 0., None, {}),                               # Cartesian zone
+    ('roe_nul', 'Euler', 'tgv', (16, 9, 8), 0., {'jmin': 'BCWall', 'jmax': 'BCWallInviscid', 'imin': 'BCFarfield'}, {}),
+    ('roe_min', 'Euler', 'tgv', (12, 9, 8), 0., {'jmin': 'BCWall', 'kmax': 'BCFarfield'}, {}),
+    ('roe_min', 'NSLaminar', 'tgv', (10, 9, 8), 0.15, {'jmin': 'BCWall', 'kmax': 'BCWallViscous'}, {}),
+    ('roe_nul', 'NSLaminar', 'tgv', (10, 9, 8), 0.15, None, {}),
+    ('roe_min', 'NSTurbulent', 'tgv', (10, 9, 8), 0.15, {'jmin': 'BCWall'}, {}),
+    ('roe_min', 'NSLaminar', 'tgv2d', (37, 9), 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {}),
+    ('roe_min', 'NSLaminar', 'tgv', (12, 10, 9), 0.2, {'jmin': 'BCWall'}, {'homo': True}),
+    ('roe_min', 'NSLaminar', 'tgv', (10, 9, 8), 0.15, {'jmin': 'BCWall'},
+     dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})),
+    ('roe_nul', 'NSLaminar', 'tgv', (34, 9, 8), 0., None,
+     dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})),
+])
+def test_roe_slopes(scheme, model, kind, n, perturb, bcs, kw):
+    """roe with the minmod limiter ('roe_min') and with first-order states ('roe_nul'): Slope/minmod_slope_var.for,
+    Slope/o1_slope_var.for through ROE/fluroe_select.for options 3xx / 1xx; the wall-face correction takes the flux of the
+    same slope back.  Bit for bit (1e-12 with Spalart-Allmaras)."""
+    from fast_amd import cases
+    from common import SINGLE, wall_distance
+    mk = cases.tgv if kind == 'tgv' else cases.tgv2d
+    t = mk(n, scheme, model=model, extra_numz=SINGLE, bcs=bcs, perturb=perturb, **kw)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[33]) == 5 and int(pint[64]) == (3 if scheme == 'roe_min' else 1)
+    neq = int(pint[36])
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z) if neq == 6 else None)
+    oz.fill_ghostcells()
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, 6):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        if neq == 6:
+            assert rel_err(got, oz.ro, int(pint[41]), neq=6).max() < 1e-12, "step %d" % it
+        else:
+            assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-5
+
+
+def test_slopes_without_a_reference_flux_are_refused():
+    from fast_amd import cases
+    t = cases.tgv(8, 'ausmpred', extra_numz={'slope': 'minmod'})
+    with pytest.raises(_capi.FastsHipError, match="slope"):
+        FastS.warmup(t, None)
+    t = cases.tgv(8, 'roe', extra_numz={'slope': 'o3sc'})
+    with pytest.raises(_capi.FastsHipError, match="slope"):
+        FastS.warmup(t, None)

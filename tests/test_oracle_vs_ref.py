@@ -801,3 +801,38 @@ def test_reference_on_threads_agrees_with_one_thread(n, scheme, threads):
     a, b = ref1.zones[0].ro, refn.zones[0].ro
     assert np.isfinite(b).all()
     assert np.abs(a - b).max() < 1e-13 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("scheme,model,perturb,dim,bcs,kw", [
+    ('roe_min', 'NSLaminar', 0., 3, None, {}),
+    ('roe_nul', 'NSLaminar', 0., 3, None, {}),
+    ('roe_min', 'Euler', 0., 3, {'jmin': 'BCWall', 'jmax': 'BCWallInviscid', 'imin': 'BCFarfield'}, {}),
+    ('roe_min', 'NSLaminar', 0.15, 3, {'jmin': 'BCWall', 'kmax': 'BCWallViscous'}, {}),
+    ('roe_nul', 'Euler', 0.15, 3, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {}),
+    ('roe_min', 'NSTurbulent', 0.15, 3, {'jmin': 'BCWall'}, {}),
+    ('roe_min', 'NSLaminar', 0.15, 2, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {}),
+    ('roe_nul', 'NSLaminar', 0.15, 2, None, {}),
+    ('roe_min', 'NSLaminar', 0.2, 3, {'jmin': 'BCWall'}, {'homo': True}),
+    ('roe_min', 'NSLaminar', 0.15, 3, {'jmin': 'BCWall'},
+     dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})),
+])
+def test_roe_slopes_bit_exact(scheme, model, perturb, dim, bcs, kw):
+    """roe with the minmod limiter ('roe_min', slope 3) and with first-order states ('roe_nul', slope 1):
+    ROE/fluroe_select.for options 1xx and 3xx, Slope/minmod_slope_var.for, Slope/o1_slope_var.for; the wall-face
+    correction takes the flux of the same slope back (ROE/correction_fluroe_select.for)."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    if dim == 3:
+        t = cases.tgv((9, 8, 7), scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **kw)
+    else:
+        t = cases.tgv2d((10, 8), scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **kw)
+    so, sr = _pair(t)
+    assert so.zones[0].pint[33] == 5 and so.zones[0].pint[64] == (3 if scheme == 'roe_min' else 1)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(so.zones[0].neq, -1).max(axis=1)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
