@@ -306,11 +306,13 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     const int tag = w.type;
     // DEFAULT_STATE of BCzone.cpp:26-48: a far field / inflow may carry its own uniform conservative state, as one
     // array of 6 values or as the 21 scalars of a ReferenceState node (state at positions 3..7 and 16)
-    const bool own_state = (tag == 1 || tag == 13 || tag == 2) &&
+    const bool own_state = (tag == 1 || tag == 13 || tag == 2 || tag == 10) &&
                            (p[pt + 8] == 21 || (p[pt + 8] == 1 && pt + 9 < n_int && p[pt + 9] == 6));
     if (tag == 11 || tag == 0 || tag == 1 || tag == 14) w.type = tag;   // 14: BCExtrapolateRANS, nu_tilde only
     else if ((tag == 13 || tag == 2) && (p[pt + 8] == 0 || own_state)) w.type = tag;   // BCInflow / BCInflowSupersonic on a uniform state
     else if (tag == 2 && p[pt + 8] == p[NEQ] && pt + 9 < n_int && p[pt + 9] > 6) w.type = tag;   // its own state: BCzone.cpp:421-448
+    // BCOutflow on a uniform state; with 6 equations the reference reads a variable it never sets (BCOutflow_firstrank.for:9)
+    else if (tag == 10 && p[NEQ] == 5 && (p[pt + 8] == 0 || own_state)) w.type = tag;
     else if (tag == 17 && p[pt + 8] == p[NEQ]) w.type = tag;   // BCInj1: d0x, d0y, d0z, pa, ha [, nu_tilde], BCzone.cpp:594-618
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
     else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;

@@ -38,12 +38,22 @@ __global__ void __launch_bounds__(256) k_invist(FsZone z, int depth, const doubl
 // (Fast/FastS/FastS/BC/BCFarfield.for, non_reflection.for:1-153; fixed mesh: qen = 0).
 // tc = face metric scaled by snorm (only the normal component is non zero on a Cartesian zone).
 // Returns true when the first characteristic enters the domain (eigv1 < 0).
+// OUT: BCOutflow (BCOutflow.for): the outside state is the inside one but for the pressure of st; the ghost cell keeps
+// the inside density, loses the entering part of the normal velocity and takes the temperature of the characteristic
+// energy.
+template <bool OUT = false>
 FS_DEV bool fs_bc_farfield_first(const FsZone &z, const double *st, double tcx, double tcy, double tcz,
                                  double *rop, long long l, long long l1)
 {
   const long long nd = z.nd;
   const double gam1 = z.gam - 1., gam1_1 = 1. / gam1, cvinv = 1. / z.cv;
-  const double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
+  double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
+  if (OUT) {
+    roe = rop[l1]; rue = rop[l1 + nd] * roe; rve = rop[l1 + 2 * nd] * roe; rwe = rop[l1 + 3 * nd] * roe;
+    const double roe_inv = 1. / st[0];
+    ete = st[4] - 0.5 * (st[1] * st[1] + st[2] * st[2] + st[3] * st[3]) * roe_inv +
+          0.5 * (rue * rop[l1 + nd] + rve * rop[l1 + 2 * nd] + rwe * rop[l1 + 3 * nd]);
+  }
   double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
   double roi = rop[l1], rui = rop[l1 + nd] * roi, rvi = rop[l1 + 2 * nd] * roi, rwi = rop[l1 + 3 * nd] * roi;
   double eti = rop[l1 + 4 * nd] * z.cv * roi + .5 * (rui * rui + rvi * rvi + rwi * rwi) / roi;
@@ -85,6 +95,14 @@ FS_DEV bool fs_bc_farfield_first(const FsZone &z, const double *st, double tcx, 
   svar4 = -rvar2 + tcz * s_1 * (rvar4 - rvar5);
   svar5 = r * c * (rvar4 + rvar5);
   qvar5 = .5 * (u * u + v * v + w * w) * svar1 + r * (u * svar2 + v * svar3 + w * svar4) + gam1_1 * svar5;
+  if (OUT) {
+    const double rog = rop[l1], roinv = 1. / rog;
+    double ug = rop[l1 + nd], vg = rop[l1 + 2 * nd], wg = rop[l1 + 3 * nd];
+    if (qn < 0) { ug = ug - qn / (sn * sn) * tcx; vg = vg - qn / (sn * sn) * tcy; wg = wg - qn / (sn * sn) * tcz; }
+    rop[l] = rog; rop[l + nd] = ug; rop[l + 2 * nd] = vg; rop[l + 3 * nd] = wg;
+    rop[l + 4 * nd] = (qvar5 * roinv - .5 * (ug * ug + vg * vg + wg * wg)) * cvinv;
+    return eigv1 < 0.;
+  }
   double roinv = 1. / svar1;
   u = u + r * svar2 * roinv; v = v + r * svar3 * roinv; w = w + r * svar4 * roinv;
   rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
@@ -241,6 +259,13 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
       g[5] = z.neq == 6 ? rop[l1 + 5 * nd] : 0.;
       for (int r = 1; r <= nr; r++)
         for (int e = 0; e < z.neq; e++) rop[l1 - r * inc + e * nd] = g[e];
+    } else if (w.type == FS_BC_OUTFLOW) {   // bvbs_outflow.for: BCOutflow_i.for, then BC_extrap_i.for (5 equations)
+      const double snorm = (w.idir & 1) ? -1. : 1.;
+      double tc[3];
+      fs_bc_metric(z, w, d, q, tc);
+      fs_bc_farfield_first<true>(z, w.st, tc[0] * snorm, tc[1] * snorm, tc[2] * snorm, rop, l1 - inc, l1);
+      for (int r = 2; r <= nr; r++)
+        for (int e = 0; e < 5; e++) rop[l1 - r * inc + e * nd] = rop[l1 - inc + e * nd];
     } else {  // FS_BC_FARFIELD, FS_BC_INFLOW (same characteristic state, BCInflow_i.for), FS_BC_SUPERSONIC
       const double snorm = (w.idir & 1) ? -1. : 1.;
       if (w.type == FS_BC_INJ1) {

@@ -1167,7 +1167,9 @@ void fo_bc_farfield(const i32 *p, const double *pr, int idir, const i32 *cl, dou
  * (bvbs_inflow_supersonic.for:127-135, BCInflowSupersonic_i.for), the next ranks are extrapolated as for the
  * far field.  mode 2 with data: the first ghost rank takes the conservative state stored per face cell of the BC
  * window, dsize values per variable (bvbs_inflow_supersonic_fich.for, BCInflowSupersonic_fich_firstrank.for,
- * BCInflowSupersonic_fich_firstrank_SA.for). */
+ * BCInflowSupersonic_fich_firstrank_SA.for).
+ * mode 4: BCOutflow (bvbs_outflow.for, BCOutflow.for), five equations (with six the reference reads a variable it
+ * never sets, BCOutflow_firstrank.for:9). */
 static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
                              const double *tj, const double *tk, int mode, const double *data, int dsize,
                              const int *inc_bc)
@@ -1189,7 +1191,7 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
     ronut = data[5];
     data = 0;
   }
-  const double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
+  double roe = st[0], rue = st[1], rve = st[2], rwe = st[3], ete = st[4];
   double tc[3];
   /* transverse window */
   int lo[3] = {cl[0], cl[2], cl[4]}, hi[3] = {cl[1], cl[3], cl[5]};
@@ -1261,6 +1263,12 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
           rop[l + 4 * nd] = t_state;
           if (p[NEQ] == 6) rop[l + 5 * nd] = ronut / st[0];
         } else {
+          if (mode == 4) {   /* BCOutflow.for:1-13: the outside state is the inside one but for the pressure */
+            roe = rop[l1]; rue = rop[l1 + nd] * roe; rve = rop[l1 + 2 * nd] * roe; rwe = rop[l1 + 3 * nd] * roe;
+            const double roe_inv = 1. / st[0];
+            ete = st[4] - 0.5 * (st[1] * st[1] + st[2] * st[2] + st[3] * st[3]) * roe_inv +
+                  0.5 * (rue * rop[l1 + nd] + rve * rop[l1 + 2 * nd] + rwe * rop[l1 + 3 * nd]);
+          }
           double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
           double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
           double roi = rop[l1], rui = rop[l1 + nd] * roi, rvi = rop[l1 + 2 * nd] * roi, rwi = rop[l1 + 3 * nd] * roi;
@@ -1305,6 +1313,22 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
           svar4 = -rvar2 + tcz * s_1 * (rvar4 - rvar5);
           svar5 = r * c * (rvar4 + rvar5);
           qvar5 = .5 * (u * u + v * v + w * w) * svar1 + r * (u * svar2 + v * svar3 + w * svar4) + gam1_1 * svar5;
+          if (mode == 4) {   /* BCOutflow.for:17-33; the next ranks copy the first one (BC_extrap_i.for) */
+            rop[l] = rop[l1];
+            const double roinv = 1. / rop[l];
+            if (qn < 0) {
+              rop[l + nd] = rop[l1 + nd] - qn / (sn * sn) * tcx;
+              rop[l + 2 * nd] = rop[l1 + 2 * nd] - qn / (sn * sn) * tcy;
+              rop[l + 3 * nd] = rop[l1 + 3 * nd] - qn / (sn * sn) * tcz;
+            } else {
+              rop[l + nd] = rop[l1 + nd]; rop[l + 2 * nd] = rop[l1 + 2 * nd]; rop[l + 3 * nd] = rop[l1 + 3 * nd];
+            }
+            rop[l + 4 * nd] = (qvar5 * roinv - .5 * (rop[l + nd] * rop[l + nd] + rop[l + 2 * nd] * rop[l + 2 * nd] +
+                                                      rop[l + 3 * nd] * rop[l + 3 * nd])) * cvinv;
+            for (int rk = 2; rk <= f.nr; rk++)
+              for (int e = 0; e < 5; e++) rop[l1 - rk * inc + e * nd] = rop[l + e * nd];
+            continue;
+          }
           double roinv = 1. / svar1;
           u = u + r * svar2 * roinv; v = v + r * svar3 * roinv; w = w + r * svar4 * roinv;
           rop[l] = svar1; rop[l + nd] = u; rop[l + 2 * nd] = v; rop[l + 3 * nd] = w;
@@ -1511,15 +1535,17 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
     else if (type == 14) fo_bc_extrapolate_nut(p, pr, idir, cl, rop);
     else if (type == 1 && p[pt + 8] == 0) fo_bc_farfield(p, pr, idir, cl, rop, ti, tj, tk);
     else if (type == 13 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 1, 0, 0, 0);
+    else if (type == 10 && p[pt + 8] == 0 && p[NEQ] == 5) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 4, 0, 0, 0);
     else if (type == 2 && p[pt + 8] == 0) fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 2, 0, 0, 0);
-    else if ((type == 1 || type == 13 || type == 2) && (p[pt + 8] == 21 || (p[pt + 8] == 1 && p[pt + 9] == 6))) {
+    else if ((type == 1 || type == 13 || type == 2 || (type == 10 && p[NEQ] == 5)) &&
+             (p[pt + 8] == 21 || (p[pt + 8] == 1 && p[pt + 9] == 6))) {
       /* the BC's own uniform state: one array of 6 conservative values, or a copy of a ReferenceState node
        * (21 scalars, the state at positions 3..7 and 16), BCzone.cpp:40-48 */
       const double *d = pr + p[pt_bcs + 1 + ndf + nb_of(p)];
       double stt[6];
       if (p[pt + 8] == 21) { for (int e = 0; e < 5; e++) stt[e] = d[3 + e]; stt[5] = d[16]; }
       else for (int e = 0; e < 6; e++) stt[e] = d[e];
-      fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, type == 1 ? 0 : (type == 13 ? 1 : 2), stt, -1, 0);
+      fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, type == 1 ? 0 : (type == 13 ? 1 : (type == 10 ? 4 : 2)), stt, -1, 0);
     }
     else if (type == 17 && p[pt + 8] == p[NEQ]) {   /* BCzone.cpp:594-618: d0x, d0y, d0z, pa, ha [, nu_tilde] */
       int inc_bc[3];

@@ -336,15 +336,15 @@ class RefSolver:
                                                _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut),
                                                _p(state), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]),
                                                _i(size0), _p(inc_bc))
-            elif btype in (1, 2, 3, 4, 5, 6, 13):
+            elif btype in (1, 2, 3, 4, 5, 6, 10, 13):
                 # dispatch of Fast/FastS/FastS/BC/BCzone.cpp:279-283,299-310,417-425,451-461,513-523 (these use ind_CL)
                 st = state
                 nbdata = int(p[pt_bc + 8])
                 if nbdata != 0:     # DEFAULT_STATE, BCzone.cpp:40-48: the BC's own uniform state
                     dd = zn.preal[int(p[pt_bcs + 1 + ndf + nb_bc]):]
-                    if btype in (1, 2, 13) and nbdata == 21:
+                    if btype in (1, 2, 10, 13) and nbdata == 21:
                         st = np.array([dd[3], dd[4], dd[5], dd[6], dd[7], dd[16]])
-                    elif btype in (1, 2, 13) and nbdata == 1 and int(p[pt_bc + 9]) == 6:
+                    elif btype in (1, 2, 10, 13) and nbdata == 1 and int(p[pt_bc + 9]) == 6:
                         st = np.ascontiguousarray(dd[:6])
                     else:
                         raise NotImplementedError("ref_harness: BC data")
@@ -355,6 +355,8 @@ class RefSolver:
                     fn = L.bvbs_inflow_
                 elif btype == 2:
                     fn = L.bvbs_inflow_supersonic_
+                elif btype == 10:
+                    fn = L.bvbs_outflow_
                 elif btype == 3 or (btype == 4 and p[IFLOW] == 1) or btype == 5:
                     fn = L.bvbs_wall_inviscid_
                 elif p[IFLOW] > 1:

@@ -78,8 +78,8 @@ def test_boundary_conditions_bit_exact(model, scheme, n, bcs):
 
 def test_unsupported_options_are_refused():
     from fast_amd import cases
-    t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCOutflow'})
-    with pytest.raises(_capi.FastsHipError, match="tag 10"):
+    t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCOutMFR'})
+    with pytest.raises(_capi.FastsHipError, match="tag 21"):
         FastS.warmup(t, None)
     t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'implicit_solver': 'gmres'})
     with pytest.raises(_capi.FastsHipError, match="GMRES"):
@@ -238,4 +238,46 @@ def test_slopes_without_a_reference_flux_are_refused():
         FastS.warmup(t, None)
     t = cases.tgv(8, 'roe', extra_numz={'slope': 'o3sc'})
     with pytest.raises(_capi.FastsHipError, match="slope"):
+        FastS.warmup(t, None)
+
+
+@pytest.mark.parametrize("model,scheme,kind,n,perturb,bcs,kw", [
+    ('NSLaminar', 'senseur', 'tgv', (70, 9, 12), 0., {'imax': 'BCOutflow', 'imin': 'BCInflow', 'jmin': 'BCWall'}, {}),
+    ('Euler', 'roe', 'tgv', (10, 9, 8), 0., {'imin': 'BCOutflow', 'kmax': 'BCOutflow', 'jmax': 'BCOutflow'}, {}),
+    ('NSLaminar', 'ausmpred', 'tgv', (10, 9, 8), 0.15, {'imax': 'BCOutflow', 'jmin': 'BCOutflow', 'kmin': 'BCOutflow', 'imin': 'BCFarfield'}, {}),
+    ('NSLaminar', 'ausmpred', 'tgv2d', (37, 9), 0.15, {'imax': 'BCOutflow', 'jmax': 'BCOutflow', 'jmin': 'BCWall'}, {}),
+    ('NSLaminar', 'senseur', 'tgv', (10, 9, 8), 0.15, {'imax': 'own', 'jmin': 'BCWall'}, {}),
+    ('NSLaminar', 'ausmpred', 'tgv', (10, 9, 8), 0.15, {'imax': 'BCOutflow', 'kmin': 'BCOutflow', 'jmin': 'BCWall'},
+     dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})),
+])
+def test_outflow(model, scheme, kind, n, perturb, bcs, kw):
+    """BCOutflow (tag 10, bvbs_outflow.for): on the reference state and on the BC's own uniform state; bit for bit."""
+    from fast_amd import cases
+    from common import SINGLE
+    cv = 1. / (1.4 * 0.4 * 1.4 * 0.01)
+    if bcs.get('imax') == 'own':
+        ro, u, T = 0.97, 0.8, 1.03
+        bcs = dict(bcs, imax=('BCOutflow', {'State': np.array([ro, ro * u, 0., 0., ro * (cv * T + 0.5 * u * u), 0.])}))
+    mk = cases.tgv if kind == 'tgv' else cases.tgv2d
+    t = mk(n, scheme, model=model, extra_numz=SINGLE, bcs=bcs, perturb=perturb, **kw)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)      # ghost fill of the initial field
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, 6):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-5
+
+
+def test_outflow_with_six_equations_is_refused():
+    from fast_amd import cases
+    t = cases.tgv(8, 'senseur', model='NSTurbulent', bcs={'jmin': 'BCWall', 'jmax': 'BCOutflow'})
+    with pytest.raises(_capi.FastsHipError, match="tag 10"):
         FastS.warmup(t, None)

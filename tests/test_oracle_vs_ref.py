@@ -836,3 +836,38 @@ def test_roe_slopes_bit_exact(scheme, model, perturb, dim, bcs, kw):
         d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(so.zones[0].neq, -1).max(axis=1)
         assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
+
+
+@pytest.mark.parametrize("model,scheme,perturb,dim,bcs,kw", [
+    ('NSLaminar', 'senseur', 0., 3, {'imax': 'BCOutflow', 'imin': 'BCInflow', 'jmin': 'BCWall'}, {}),
+    ('Euler', 'roe', 0., 3, {'imin': 'BCOutflow', 'kmax': 'BCOutflow', 'jmax': 'BCOutflow'}, {}),
+    ('NSLaminar', 'ausmpred', 0.15, 3, {'imax': 'BCOutflow', 'jmin': 'BCOutflow', 'kmin': 'BCOutflow', 'imin': 'BCFarfield'}, {}),
+    ('NSLaminar', 'ausmpred', 0.15, 2, {'imax': 'BCOutflow', 'jmax': 'BCOutflow', 'jmin': 'BCWall'}, {}),
+    ('NSLaminar', 'senseur', 0.15, 3, {'imax': 'own', 'jmin': 'BCWall'}, {}),
+    ('NSLaminar', 'ausmpred', 0.15, 3, {'imax': 'BCOutflow', 'kmin': 'BCOutflow', 'jmin': 'BCWall'},
+     dict(temporal_scheme='implicit', time_step=0.02, extra_numb={'ss_iteration': 3})),
+])
+def test_outflow_bit_exact(model, scheme, perturb, dim, bcs, kw):
+    """BCOutflow (tag 10, bvbs_outflow.for, BCOutflow.for): the reference pressure with the rest taken from inside, through
+    the characteristic relations of non_reflection.for; on the reference state or on the BC's own uniform state."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    cv = 1. / (1.4 * 0.4 * 1.4 * 0.01)
+    if bcs.get('imax') == 'own':
+        ro, u, T = 0.97, 0.8, 1.03
+        st = np.array([ro, ro * u, 0., 0., ro * (cv * T + 0.5 * u * u), 0.])
+        bcs = dict(bcs, imax=('BCOutflow', {'State': st}))
+    if dim == 3:
+        t = cases.tgv((9, 8, 7), scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **kw)
+    else:
+        t = cases.tgv2d((10, 8), scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, **kw)
+    so, sr = _pair(t)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(so.zones[0].neq, -1).max(axis=1)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
