@@ -314,6 +314,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     // BCOutflow on a uniform state; with 6 equations the reference reads a variable it never sets (BCOutflow_firstrank.for:9)
     else if (tag == 10 && p[NEQ] == 5 && (p[pt + 8] == 0 || own_state)) w.type = tag;
     else if (tag == 17 && p[pt + 8] == p[NEQ]) w.type = tag;   // BCInj1: d0x, d0y, d0z, pa, ha [, nu_tilde], BCzone.cpp:594-618
+    else if (tag == 20 && p[pt + 8] == p[NEQ]) w.type = tag;   // BCInjMFR: d0x, d0y, d0z, qp, ha [, nu_tilde], BCzone.cpp:377-398
+    else if (tag == 21 && p[pt + 8] == 1) w.type = tag;        // BCOutMFR: qp, BCzone.cpp:400-415
     else if (tag == 3 || tag == 5 || (tag == 4 && p[IFLOW] == 1)) w.type = FS_BC_WALL_SLIP;
     else if ((tag == 4 || tag == 6) && p[IFLOW] > 1) w.type = FS_BC_WALL_NOSLIP;
     else if (tag == 16 || (tag == 32 && p[IFLOW] > 1)) w.type = tag;   // BCOutpres, BCWallViscousIsothermal: window data
@@ -326,7 +328,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
     long long data_off = -1;
     w.data = nullptr; w.dlo[0] = w.dlo[1] = 0; w.dn = 1; w.dsize = 0;
     w.nit = p[65]; w.tol = r[37];   // NIT_INFLOW, EPSI_INFLOW
-    if ((tag == 2 && p[pt + 8] != 0 && !own_state) || tag == 17) {
+    if ((tag == 2 && p[pt + 8] != 0 && !own_state) || tag == 17 || tag == 20 || tag == 21) {
       // NEQ arrays of one size, one value per face cell of the window: rho, rho u, rho v, rho w, rho E [, rho nu_tilde]
       const int nbdata = p[pt + 8], size = p[pt + 9];
       const long long off = p[pt_bcs + 1 + ndf + nb];

@@ -8,7 +8,7 @@
 // (tag 4 is a slip wall for Euler and a no-slip wall otherwise)
 // FS_BC_ZERO: the extrapolation BC applied to the Newton residual (lrhs = 1): ghost = first interior cell * 0
 // (BCExtrapolate_init.for:2-6)
-enum { FS_BC_EXTRAPOLATE = 0, FS_BC_FARFIELD = 1, FS_BC_SUPERSONIC = 2, FS_BC_INFLOW = 13, FS_BC_WALL_SLIP = 3, FS_BC_WALL_NOSLIP = 6, FS_BC_OUTFLOW = 10, FS_BC_PERIODIC = 11, FS_BC_EXTRAP_NUT = 14, FS_BC_OUTPRES = 16, FS_BC_INJ1 = 17, FS_BC_WALL_ISOTHERMAL = 32, FS_BC_ZERO = 100 };
+enum { FS_BC_EXTRAPOLATE = 0, FS_BC_FARFIELD = 1, FS_BC_SUPERSONIC = 2, FS_BC_INFLOW = 13, FS_BC_WALL_SLIP = 3, FS_BC_WALL_NOSLIP = 6, FS_BC_OUTFLOW = 10, FS_BC_PERIODIC = 11, FS_BC_EXTRAP_NUT = 14, FS_BC_OUTPRES = 16, FS_BC_INJ1 = 17, FS_BC_INJMFR = 20, FS_BC_OUTMFR = 21, FS_BC_WALL_ISOTHERMAL = 32, FS_BC_ZERO = 100 };
 
 struct FsBcWin {
   int type;          // FS_BC_*

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         rop[l + 4 * nd] = 2. * tw - tm;
         if (z.neq == 6) rop[l + 5 * nd] = -rop[lm + 5 * nd];   // BCWallViscousIsothermal_firstrank_SA.for
       }
-    } else if (w.type == FS_BC_OUTPRES) {   // BCOutpres_i.for, linearization_state.for, BC_extrap_i.for
+    } else if (w.type == FS_BC_OUTPRES || w.type == FS_BC_OUTMFR) {   // BCOutpres_i.for / BCOutMFR.for, linearization_state.for, BC_extrap_i.for
       const double pext = w.data[(q[da] - w.dlo[0]) + (long long)(q[db] - w.dlo[1]) * w.dn];
       const double snorm = (w.idir & 1) ? -1. : 1.;
       double tc[3];
@@ -251,11 +251,25 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
       const double roi = rop[l1], ui = rop[l1 + nd], vi = rop[l1 + 2 * nd], wi = rop[l1 + 3 * nd], Ti = rop[l1 + 4 * nd];
       const double pi = roi * z.rgp * Ti;
       const double roc0 = sqrt(roi * z.gam * pi);
-      const double dqn = (pext - pi) / roc0;
-      const double rog = roi + roi * roi * dqn / roc0;
       double g[6];
-      g[0] = rog; g[1] = ui - dqn * tnx; g[2] = vi - dqn * tny; g[3] = wi - dqn * tnz;
-      g[4] = pext / (rog * z.rgp);
+      if (w.type == FS_BC_OUTMFR) {   // pext = mass flow rate per unit area: density from the C0 and C+ characteristics
+        double c0_2 = roc0 / roi;
+        c0_2 = c0_2 * c0_2;
+        const double coefa = c0_2;
+        const double coefb = -roc0 * (ui * tnx + vi * tny + wi * tnz - 0.) - c0_2 * roi;
+        const double coefc = roc0 * pext;
+        const double delta = coefb * coefb - 4 * coefa * coefc;
+        g[0] = (-coefb + sqrt(delta)) / (2 * coefa);
+        const double dp = c0_2 * (g[0] - roi);
+        const double dqn = dp / roc0;
+        g[1] = ui - dqn * tnx; g[2] = vi - dqn * tny; g[3] = wi - dqn * tnz;
+        g[4] = (dp + pi) / (g[0] * z.rgp);
+      } else {
+        const double dqn = (pext - pi) / roc0;
+        const double rog = roi + roi * roi * dqn / roc0;
+        g[0] = rog; g[1] = ui - dqn * tnx; g[2] = vi - dqn * tny; g[3] = wi - dqn * tnz;
+        g[4] = pext / (rog * z.rgp);
+      }
       g[5] = z.neq == 6 ? rop[l1 + 5 * nd] : 0.;
       for (int r = 1; r <= nr; r++)
         for (int e = 0; e < z.neq; e++) rop[l1 - r * inc + e * nd] = g[e];
@@ -311,6 +325,62 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
         const double pg = pa * pow(b, gam2), rog = gam2 * pg / (ha * b), Tg = pg / (rog * z.rgp);
         rop[l] = rog; rop[l + nd] = vg * d0x; rop[l + 2 * nd] = vg * d0y; rop[l + 3 * nd] = vg * d0z;
         rop[l + 4 * nd] = Tg;
+        if (z.neq == 6) rop[l + 5 * nd] = dt[5 * ds];
+      } else if (w.type == FS_BC_INJMFR) {
+        // direction d0, mass flow rate per unit area qp and stagnation enthalpy ha imposed (BCInjMFR.for; qen = 0): a
+        // Newton iteration on the pressure starts a state at rest, otherwise the normal velocity solves a quadratic
+        const long long l = l1 - inc;
+        const double *dt = w.data + (q[da] - w.dlo[0]) + (long long)(q[db] - w.dlo[1]) * w.dn;
+        const long long ds = w.dsize;
+        const double d0x = dt[0], d0y = dt[ds], d0z = dt[2 * ds], qp = dt[3 * ds], ha = dt[4 * ds];
+        const double gam2 = z.gam / (z.gam - 1.);
+        double tc[3];
+        fs_bc_metric(z, w, d, q, tc);
+        const double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
+        const double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz), s_1 = 1. / sn;
+        double tnx = 1., tny = 0., tnz = 0.;
+        if (sn != 0.) { tnx = tcx * s_1; tny = tcy * s_1; tnz = tcz * s_1; }
+        const double ro0 = rop[l1], u0 = rop[l1 + nd], v0 = rop[l1 + 2 * nd], w0 = rop[l1 + 3 * nd], T0 = rop[l1 + 4 * nd];
+        const double p0 = ro0 * z.rgp * T0, pi = p0;
+        const double qen = 0.;
+        const double roc0 = sqrt(ro0 * z.gam * p0);
+        const double usd0n = 1 / (d0x * tnx + d0y * tny + d0z * tnz), usd0n2 = usd0n * usd0n;
+        double wn = u0 * tnx + v0 * tny + w0 * tnz - qen;
+        if (fabs(wn) < 1.e-6) {
+          double residug = 1.e+20;
+          int nitnwt = 0;
+          double mach = sqrt((u0 * u0) + (v0 * v0) + (w0 * w0));
+          mach = mach * ro0 / roc0;
+          const double pt = p0 * pow(1 + 0.2 * (mach * mach), gam2);
+          const double ri = pi + roc0 * wn;
+          while (residug > w.tol && nitnwt < w.nit) {
+            nitnwt++;
+            residug = 0.;
+            const double b = fs_max(0.2, 1. - ((wn + qen) * (wn + qen)) * usd0n2 / (2. * ha));
+            const double pg = pt * pow(b, gam2);
+            const double rog = gam2 * pg / (ha * b);
+            const double fn = pg + roc0 * wn - ri;
+            const double df = roc0 - rog * (wn + qen) * usd0n2;
+            const double dwng = -fn / df;
+            wn = wn + dwng;
+            residug = fs_max(residug, fabs(dwng / wn));
+          }
+          const double qn = wn + qen;
+          const double b = fs_max(0.2, 1. - (qn * qn) * usd0n2 / (2. * ha));
+          const double pg = pt * pow(b, gam2), rog = gam2 * pg / (ha * b), Tg = pg / (rog * z.rgp);
+          const double vg = qn * usd0n;
+          rop[l] = rog; rop[l + nd] = vg * d0x; rop[l + 2 * nd] = vg * d0y; rop[l + 3 * nd] = vg * d0z;
+          rop[l + 4 * nd] = Tg;
+        } else {
+          const double coefa = 0.5 * qp * usd0n2 / gam2 + roc0;
+          const double coefb = p0 + roc0 * (u0 * tnx + v0 * tny + w0 * tnz - qen);
+          const double coefc = -ha * qp / gam2;
+          const double delta = coefb * coefb - 4. * coefa * coefc;
+          const double qn = (-coefb + sqrt(delta)) / (2. * coefa) + qen;
+          const double vg = qn * fabs(usd0n);
+          rop[l] = qp / qn; rop[l + nd] = vg * d0x; rop[l + 2 * nd] = vg * d0y; rop[l + 3 * nd] = vg * d0z;
+          rop[l + 4 * nd] = (ha - 0.5 * vg * vg) / (z.cv * z.gam);
+        }
         if (z.neq == 6) rop[l + 5 * nd] = dt[5 * ds];
       } else if (w.type == FS_BC_SUPERSONIC && w.data) {   // first rank = the window's own conservative state
         const long long l = l1 - inc;                 // (BCInflowSupersonic_fich_firstrank.for)

@@ -1246,6 +1246,63 @@ static void fo_bc_farfield_m(const i32 *p, const double *pr, int idir, const i32
           rop[l] = rog; rop[l + nd] = vg * d0x; rop[l + 2 * nd] = vg * d0y; rop[l + 3 * nd] = vg * d0z;
           rop[l + 4 * nd] = Tg;
           if (p[NEQ] == 6) rop[l + 5 * nd] = data[li + 5 * dsize];
+        } else if (mode == 5) {
+          /* BCInjMFR: direction d0, mass flow rate per unit area qp and stagnation enthalpy ha imposed
+           * (bvbs_injmfr.for, BCInjMFR.for, linearization_state.for; fixed mesh: qen = 0).  A Newton iteration on the
+           * pressure starts a flow at rest, otherwise the normal velocity is a root of a quadratic. */
+          const int q[3] = {i, j, k};
+          const int da = f.d == 0 ? 1 : 0, db = f.d == 2 ? 1 : 2;
+          const long li = (q[da] - inc_bc[1]) + (long)(q[db] - inc_bc[2]) * inc_bc[0];
+          const double d0x = data[li], d0y = data[li + dsize], d0z = data[li + 2 * dsize];
+          const double qp = data[li + 3 * dsize], ha = data[li + 4 * dsize];
+          const double gam = pr[GAMMA], gamm1 = gam - 1., gam2 = gam / gamm1, rgp = pr[CVINF] * gamm1;
+          const double tcx = tc[0] * snorm, tcy = tc[1] * snorm, tcz = tc[2] * snorm;
+          const double sn = sqrt(tcx * tcx + tcy * tcy + tcz * tcz), s_1 = 1. / sn;
+          double tnx, tny, tnz;
+          if (sn == 0.) { tnx = 1.; tny = 0.; tnz = 0.; } else { tnx = tcx * s_1; tny = tcy * s_1; tnz = tcz * s_1; }
+          const double roi = rop[l1], Ti = rop[l1 + 4 * nd];
+          const double pi = roi * rgp * Ti;
+          const double ro0 = roi, u0 = rop[l1 + nd], v0 = rop[l1 + 2 * nd], w0 = rop[l1 + 3 * nd], p0 = ro0 * rgp * Ti;
+          const double qen = 0.;
+          const double roc0 = sqrt(ro0 * gam * p0);
+          const double usd0n = 1 / (d0x * tnx + d0y * tny + d0z * tnz), usd0n2 = usd0n * usd0n;
+          double wn = u0 * tnx + v0 * tny + w0 * tnz - qen;
+          if (fabs(wn) < 1.e-6) {
+            double residug = 1.e+20;
+            int nitnwt = 0;
+            double mach = sqrt((u0 * u0) + (v0 * v0) + (w0 * w0));
+            mach = mach * ro0 / roc0;
+            const double pt = p0 * pow(1 + 0.2 * (mach * mach), gam2);
+            const double ri = pi + roc0 * wn;
+            while (residug > pr[37] && nitnwt < p[65]) {
+              nitnwt++;
+              residug = 0.;
+              const double b = dmax(0.2, 1. - ((wn + qen) * (wn + qen)) * usd0n2 / (2. * ha));
+              const double pg = pt * pow(b, gam2);
+              const double rog = gam2 * pg / (ha * b);
+              const double fn = pg + roc0 * wn - ri;
+              const double df = roc0 - rog * (wn + qen) * usd0n2;
+              const double dwng = -fn / df;
+              wn = wn + dwng;
+              residug = dmax(residug, fabs(dwng / wn));
+            }
+            const double qn = wn + qen;
+            const double b = dmax(0.2, 1. - (qn * qn) * usd0n2 / (2. * ha));
+            const double pg = pt * pow(b, gam2), rog = gam2 * pg / (ha * b), Tg = pg / (rog * rgp);
+            const double w = qn * usd0n;
+            rop[l] = rog; rop[l + nd] = w * d0x; rop[l + 2 * nd] = w * d0y; rop[l + 3 * nd] = w * d0z;
+            rop[l + 4 * nd] = Tg;
+          } else {
+            const double coefa = 0.5 * qp * usd0n2 / gam2 + roc0;
+            const double coefb = p0 + roc0 * (u0 * tnx + v0 * tny + w0 * tnz - qen);
+            const double coefc = -ha * qp / gam2;
+            const double delta = coefb * coefb - 4. * coefa * coefc;
+            const double qn = (-coefb + sqrt(delta)) / (2. * coefa) + qen;
+            const double w = qn * fabs(usd0n);
+            rop[l] = qp / qn; rop[l + nd] = w * d0x; rop[l + 2 * nd] = w * d0y; rop[l + 3 * nd] = w * d0z;
+            rop[l + 4 * nd] = (ha - 0.5 * w * w) / (pr[CVINF] * gam);
+          }
+          if (p[NEQ] == 6) rop[l + 5 * nd] = data[li + 5 * dsize];
         } else if (mode == 2 && data) {
           const int q[3] = {i, j, k};
           const int da = f.d == 0 ? 1 : 0, db = f.d == 2 ? 1 : 2;
@@ -1372,8 +1429,18 @@ static const double *fo_bc_data(const i32 *p, const double *pr, int ndf, int *in
 /* Pressure outlet: first ghost rank from the interior state and the imposed pressure along the face normal
  * (Fast/FastS/FastS/BC/bvbs_outpres.for:151-197, BCOutpres_i.for, linearization_state.for), the next ranks copy
  * the first one (BC_extrap_i.for); nu_tilde copied from the interior (BCOutpresSA_i.for). */
+static void fo_bc_outpres_m(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
+                            const double *tj, const double *tk, const double *pext, const int *inc_bc, int mfr);
 void fo_bc_outpres(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
                    const double *tj, const double *tk, const double *pext, const int *inc_bc)
+{
+  fo_bc_outpres_m(p, pr, idir, cl, rop, ti, tj, tk, pext, inc_bc, 0);
+}
+
+/* mfr = 1: BCOutMFR, the imposed quantity is the mass flow rate per unit area qp; the density of the ghost cell is a
+ * root of the quadratic that the C0 and C+ characteristics give (bvbs_outmfr.for, BCOutMFR.for with qen = 0). */
+static void fo_bc_outpres_m(const i32 *p, const double *pr, int idir, const i32 *cl, double *rop, const double *ti,
+                            const double *tj, const double *tk, const double *pext, const int *inc_bc, int mfr)
 {
   GEOM(p)
   const fo_face f = fo_face_of(p, idir);
@@ -1402,6 +1469,26 @@ void fo_bc_outpres(const i32 *p, const double *pr, int idir, const i32 *cl, doub
         const double pi = roi * rgp * Ti;
         const double ro0 = roi, p0 = ro0 * rgp * Ti;
         const double roc0 = sqrt(ro0 * gam * p0);
+        if (mfr) {
+          const double u0 = ui, v0 = vi, w0 = wi, qen = 0.;
+          double c0_2 = roc0 / ro0;
+          c0_2 = c0_2 * c0_2;
+          const double coefa = c0_2;
+          const double coefb = -roc0 * (u0 * tnx + v0 * tny + w0 * tnz - qen) - c0_2 * roi;
+          const double coefc = roc0 * pext[li];
+          const double delta = coefb * coefb - 4 * coefa * coefc;
+          rop[l] = (-coefb + sqrt(delta)) / (2 * coefa);
+          const double dp = c0_2 * (rop[l] - ro0);
+          const double dqn = dp / roc0;
+          rop[l + nd] = ui - dqn * tnx;
+          rop[l + 2 * nd] = vi - dqn * tny;
+          rop[l + 3 * nd] = wi - dqn * tnz;
+          rop[l + 4 * nd] = (dp + pi) / (rop[l] * rgp);
+          if (p[NEQ] == 6) rop[l + 5 * nd] = rop[l1 + 5 * nd];
+          for (int r = 2; r <= f.nr; r++)
+            for (int e = 0; e < p[NEQ]; e++) rop[l1 - r * inc + e * nd] = rop[l + e * nd];
+          continue;
+        }
         const double dqn = (pext[li] - pi) / roc0;
         const double rog = roi + ro0 * ro0 * dqn / roc0;
         rop[l] = rog;
@@ -1553,6 +1640,18 @@ int fo_bczone(const i32 *p, const double *pr, double *rop, const double *ti, con
       const double *d = fo_bc_data(p, pr, ndf, inc_bc);
       if (save == 1) return -1;
       fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 3, d, save, inc_bc);
+    }
+    else if (type == 20 && p[pt + 8] == p[NEQ]) {   /* BCzone.cpp:377-398: d0x, d0y, d0z, qp, ha [, nu_tilde] */
+      int inc_bc[3];
+      const int save = p[pt + 9];
+      const double *d = fo_bc_data(p, pr, ndf, inc_bc);
+      if (save == 1) return -1;
+      fo_bc_farfield_m(p, pr, idir, cl, rop, ti, tj, tk, 5, d, save, inc_bc);
+    }
+    else if (type == 21 && p[pt + 8] == 1 && p[pt + 9] > 1) {   /* BCzone.cpp:400-415: qp per face cell */
+      int inc_bc[3];
+      const double *d = fo_bc_data(p, pr, ndf, inc_bc);
+      fo_bc_outpres_m(p, pr, idir, cl, rop, ti, tj, tk, d, inc_bc, 1);
     }
     else if (type == 2 && p[pt + 8] == p[NEQ] && p[pt + 9] > 6) {   /* BCzone.cpp:421-448: arrays of more than 6 values */
       int inc_bc[3];

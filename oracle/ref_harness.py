@@ -304,18 +304,33 @@ class RefSolver:
                    _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
                    _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state),
                    _p(data), _i(int(p[pt_bc + 9])), _p(inc_bc))
-            elif btype == 17:
-                # Fast/FastS/FastS/BC/BCzone.cpp:594-618: direction, stagnation pressure and enthalpy per face cell
+            elif btype == 21:
+                # Fast/FastS/FastS/BC/BCzone.cpp:400-415: mass flow rate per unit area, one value per face cell
+                if int(p[pt_bc + 8]) != 1:
+                    raise NotImplementedError("ref_harness: BCOutMFR with %d data arrays" % int(p[pt_bc + 8]))
+                off = int(p[pt_bcs + 1 + ndf + nb_bc])
+                if idir <= 2: inc_bc = [fen[3] - fen[2] + 1, fen[2], fen[4]]
+                elif idir <= 4: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[4]]
+                else: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[2]]
+                inc_bc = np.array(inc_bc, dtype=np.int32)
+                L.bvbs_outmfr_(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl),
+                               _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
+                               _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut), _p(state),
+                               _p(zn.preal[off:]), _i(int(p[pt_bc + 9])), _p(inc_bc))
+            elif btype in (17, 20):
+                # Fast/FastS/FastS/BC/BCzone.cpp:594-618 (BCInj1: direction, stagnation pressure and enthalpy per face
+                # cell) and :377-398 (BCInjMFR: direction, mass flow rate per unit area and stagnation enthalpy)
                 nbdata = int(p[pt_bc + 8]); size0 = int(p[pt_bc + 9])
                 if nbdata != int(p[NEQ]):
-                    raise NotImplementedError("ref_harness: BCInj1 with %d data arrays" % nbdata)
+                    raise NotImplementedError("ref_harness: BCInj1 / BCInjMFR with %d data arrays" % nbdata)
                 off = int(p[pt_bcs + 1 + ndf + nb_bc])
                 if idir <= 2: inc_bc = [fen[3] - fen[2] + 1, fen[2], fen[4]]
                 elif idir <= 4: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[4]]
                 else: inc_bc = [fen[1] - fen[0] + 1, fen[0], fen[2]]
                 inc_bc = np.array(inc_bc, dtype=np.int32)
                 d = [zn.preal[off + e * size0:] for e in range(6)]
-                L.bvbs_inflow_newton_(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl),
+                fn = L.bvbs_inflow_newton_ if btype == 17 else L.bvbs_injmfr_
+                fn(_i(idir), _i(0), _i(nstep), _i(neq_mtr), _d(1.), _p(p), _p(ind_cl),
                                       _p(zn.preal), _d(5. / 6.), _d(2. / 6.), _d(-1. / 6.),
                                       _p(zn.x), _p(zn.y), _p(zn.z), _p(zn.ro), _p(tijk), _p(rop), _p(zn.xmut),
                                       _p(state), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]),

@@ -113,3 +113,24 @@ def own_state_bcs():
             'kmax': ('BCInflowSupersonic', {'State': state(1.01, 0.2, 0.1, -1.2, 1., 1e-5)}),
             'jmax': ('BCFarfield', {'s%02d' % i: _np.array([ref21[i]]) for i in range(21)}),
             'jmin': 'BCWall'}
+
+
+def mfr_bcs(n, model='NSLaminar', rest_face=True):
+    """Mass-flow-rate BCs with window data: BCOutMFR on imax (qp per face cell), BCInjMFR on imin (direction, qp and
+    stagnation enthalpy per face cell [, nu_tilde]) and, with rest_face, on kmin, where the Taylor-Green field has no
+    normal velocity, so that the first ghost fill takes the Newton start of BCInjMFR.for."""
+    ni, nj, nk = n
+    neq = 6 if model == 'NSTurbulent' else 5
+    cv = 1. / (1.4 * 0.4 * 1.4 * 0.01)
+    hinf = 1.4 * cv * 1. + 0.5 * 1.
+    bcs = {'imax': ('BCOutMFR', {'qp': window_data((nj * nk,), 0.6, 0.05)}), 'jmin': 'BCWall', 'jmax': 'BCFarfield'}
+    def inj(ng, d, q):
+        dd = {'d0x': numpy_full(ng, d[0]), 'd0y': numpy_full(ng, d[1]), 'd0z': window_data((ng,), d[2], 0.1),
+              'qp': window_data((ng,), q, 0.03), 'StagnationEnthalpy': window_data((ng,), hinf, 0.001)}
+        if neq == 6:
+            dd['TurbulentSANuTilde'] = window_data((ng,), 2e-5, 0.3)
+        return dd
+    bcs['imin'] = ('BCInjMFR', inj(nj * nk, (0.99, 0.05, 0.02), 0.7))
+    if rest_face:
+        bcs['kmin'] = ('BCInjMFR', inj(ni * nj, (0.05, 0.02, 0.99), 0.3))
+    return bcs

@@ -70,3 +70,41 @@ def test_window_data_must_match_the_window():
     t = cases.tgv(n, 'senseur', extra_numz=SINGLE, bcs={'imax': 'BCOutpres'})
     with pytest.raises(_capi.FastsHipError, match="window data"):
         FastS.warmup(t, None)
+
+
+@pytest.mark.parametrize("model,scheme,n,perturb,temporal", [
+    ('NSLaminar', 'ausmpred', (70, 9, 12), 0., 'explicit'),
+    ('Euler', 'roe', (10, 9, 8), 0., 'explicit'),
+    ('NSLaminar', 'senseur', (10, 9, 8), 0.15, 'explicit'),
+    ('NSTurbulent', 'ausmpred', (10, 9, 8), 0.15, 'explicit'),
+    ('NSLaminar', 'ausmpred', (10, 9, 8), 0.15, 'implicit'),
+])
+def test_mass_flow_rate_bcs(model, scheme, n, perturb, temporal):
+    """BCOutMFR (bvbs_outmfr.for) and BCInjMFR (bvbs_injmfr.for, the quadratic and the Newton start): device against the
+    CPU restatement, itself bit-exact against the compiled reference.  1e-12: the Newton start raises to the power
+    gamma/(gamma-1), and the device pow is not the host's."""
+    from fast_amd import cases, FastC, Internal
+    import fast_amd.PyTree as FastS
+    from oracle import oracle as O
+    from common import SINGLE, mfr_bcs, zone_arrays, rel_err, wall_distance
+    bcs = mfr_bcs(n, model)
+    if model == 'Euler':
+        bcs['jmin'] = 'BCWallInviscid'
+    t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, bcs=bcs, perturb=perturb,
+                  temporal_scheme=temporal, time_step=0.02 if temporal == 'implicit' else None)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    neq = int(pint[36])
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z) if neq == 6 else None)
+    oz.fill_ghostcells()
+    assert rel_err(FastC.level_buffer(z), oz.ro, int(pint[41]), neq=neq).max() < 1e-12
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, 6):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        e = rel_err(got, oz.ro, int(pint[41]), neq=neq)
+        assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-5

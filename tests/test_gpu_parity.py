@@ -78,8 +78,8 @@ def test_boundary_conditions_bit_exact(model, scheme, n, bcs):
 
 def test_unsupported_options_are_refused():
     from fast_amd import cases
-    t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCOutMFR'})
-    with pytest.raises(_capi.FastsHipError, match="tag 21"):
+    t = cases.tgv(8, 'senseur', bcs={'jmin': 'BCWallModel'})
+    with pytest.raises(_capi.FastsHipError, match="tag 30"):
         FastS.warmup(t, None)
     t = cases.tgv(8, 'senseur', temporal_scheme='implicit', extra_numz={'implicit_solver': 'gmres'})
     with pytest.raises(_capi.FastsHipError, match="GMRES"):

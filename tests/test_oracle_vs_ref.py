@@ -871,3 +871,34 @@ def test_outflow_bit_exact(model, scheme, perturb, dim, bcs, kw):
         d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(so.zones[0].neq, -1).max(axis=1)
         assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
     assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
+
+
+@pytest.mark.parametrize("model,scheme,perturb,temporal", [
+    ('NSLaminar', 'ausmpred', 0., 'explicit'),
+    ('Euler', 'roe', 0., 'explicit'),
+    ('NSLaminar', 'senseur', 0.15, 'explicit'),
+    ('NSTurbulent', 'ausmpred', 0.15, 'explicit'),
+    ('NSLaminar', 'ausmpred', 0.15, 'implicit'),
+])
+def test_mass_flow_rate_bcs_bit_exact(model, scheme, perturb, temporal):
+    """BCOutMFR (tag 21, bvbs_outmfr.for) and BCInjMFR (tag 20, bvbs_injmfr.for: both the quadratic for a moving state and
+    the Newton start for a state at rest) of the compiled reference, Cartesian and curvilinear, 5 and 6 equations."""
+    from common import mfr_bcs
+    n = (9, 8, 7)
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000}
+    bcs = mfr_bcs(n, model)
+    if model == 'Euler':
+        bcs['jmin'] = 'BCWallInviscid'
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb,
+                  temporal_scheme=temporal, time_step=0.02 if temporal == 'implicit' else None)
+    so, sr = _pair(t)
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    assert np.array_equal(so.zones[0].ro, sr.zones[0].ro)
+    for a, b in zip(so.zones, sr.zones):
+        a.ro_m1[:] = a.ro; a.ro_p1[:] = a.ro; b.ro_m1[:] = b.ro; b.ro_p1[:] = b.ro
+    ro0 = so.zones[0].ro.copy()
+    for it in range(1, 5):
+        so.step(); sr.step(it)
+        d = np.abs(so.zones[0].ro - sr.zones[0].ro).reshape(so.zones[0].neq, -1).max(axis=1)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d: %s" % (it, d)
+    assert np.isfinite(so.zones[0].ro).all() and np.abs(so.zones[0].ro - ro0).max() > 1e-5
