@@ -29,8 +29,26 @@ template <int DIR> FS_DEV long long minc_of(const FsZone &z) { return DIR == 0 ?
 // FIRST: the sensor of the face is evaluated from the stencil and stored (0/1 byte); later stages read it.
 // TWOD: two-dimensional zone; the k stride of the field is taken as 0 (the cross terms along k then read the
 // cell itself and meet zero metrics: they vanish exactly, as in the reference's 2d fragments fluvisq_2d_{i,j}.for).
-template <int KFLU, int IFLOW, int DIR, bool FIRST, bool TWOD, bool HOMO = false>
-FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
+// Readers of the field around the thread's own cell, rd(e, di, dj, dk) = variable e at (i+di, j+dj, k+dk).
+// RdGlobal: from global memory (the k stride is 0 on a two-dimensional zone).  RdLds: from the three planes
+// k-1, k, k+1 of the patch staged in LDS (LI x LJ cells per variable and plane, halo of 2 cells).
+constexpr int LI = TI + 4, LJ = TJ + 4;
+struct RdGlobal {
+  const double *__restrict__ rop;
+  long long nd, l, incj, inck;
+  __device__ __forceinline__ double operator()(int e, int di, int dj, int dk) const { return rop[e * nd + l + di + dj * incj + dk * inck]; }
+};
+struct RdLds {
+  const double *pm, *p0, *pp;   // own cell in the planes k-1, k, k+1 (variable 0)
+  __device__ __forceinline__ double operator()(int e, int di, int dj, int dk) const
+  {
+    const double *p = dk < 0 ? pm : (dk == 0 ? p0 : pp);
+    return p[(e * LJ + dj) * LI + di];
+  }
+};
+
+template <int KFLU, int IFLOW, int DIR, bool FIRST, bool TWOD, bool HOMO = false, class RD>
+FS_DEV void face_full(const FsZone &z, const RD &rd, const double *__restrict__ xmut,
                       unsigned char *__restrict__ wig, long long l, long long lt, const double *qm2,
                       const double *qm1, const double *q0, const double *qp1, double *flu)
 {
@@ -73,11 +91,13 @@ FS_DEV void face_full(const FsZone &z, const double *__restrict__ rop, const dou
   }
   if (IFLOW >= 2) {
     constexpr int A = (DIR + 1) % 3, B = (DIR + 2) % 3;
-    const long long inc = inc_of<DIR>(z), ia = (TWOD && A == 2) ? 0 : inc_of<A>(z), ib = (TWOD && B == 2) ? 0 : inc_of<B>(z);
+    const long long inc = inc_of<DIR>(z);
     const long long md = minc_of<DIR>(z), ma = minc_of<A>(z), mb = minc_of<B>(z);
     auto q = [&](int e, int da, int db, int dn) -> double {
       if (da == 0 && db == 0) return dn == 0 ? q0[e] : qm1[e];
-      return rop[e * nd + l + dn * inc + da * ia + db * ib];
+      int o[3];
+      o[DIR] = dn; o[A] = da; o[B] = db;
+      return rd(e, o[0], o[1], o[2]);
     };
     auto T = [&](int c, int m, int o) -> double {
       const double *__restrict__ t = c == 0 ? Tn : (c == 1 ? z.mt[A] : z.mt[B]);
@@ -178,7 +198,9 @@ FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, co
 
 // BDF = false: Runge-Kutta stage.  BDF = true: Newton residual of the implicit scheme (rop_out unused).
 // TWOD: one plane, no k faces: the cell is finished in the same step (+Fj- +Fi- -Fi+ -Fj+).
-template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO = false>
+// LQ: the planes k-1, k, k+1 of the patch (halo included) are staged in LDS, one new plane per step of the march, and
+// the transverse neighbours are read from there instead of the vector L1 (three-dimensional zones, 5 variables).
+template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO = false, bool LQ = false>
 __global__ void __launch_bounds__(256)
 k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
@@ -186,6 +208,8 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
 {
   constexpr int NQ = IFLOW == 3 ? 6 : 5;   // Spalart-Allmaras: 6th variable nu_tilde
   __shared__ double sfj[2][NQ][TJ][TI];
+  __shared__ double spl[LQ ? 3 : 1][LQ ? NQ * LJ * LI : 1];
+  static_assert(!LQ || (!TWOD && NQ == 5), "LDS planes: three-dimensional zones with 5 variables");
   const int ti = threadIdx.x & 31, tj = threadIdx.x >> 5;
   const int i = 1 + blockIdx.x * OI + ti, j = 1 + blockIdx.y * OJ + tj;
   const int k0 = 1 + blockIdx.z * kchunk;
@@ -209,12 +233,33 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
     qd[e] = 0.;
   }
   double part[NQ] = {};
+  // stage plane kk of the patch (cells i0-2 .. i0+TI+1, j0-2 .. j0+TJ+1, clipped to the array) into slot sl
+  auto stage_plane = [&](int kk, int sl) {
+    const int i0 = 1 + blockIdx.x * OI, j0 = 1 + blockIdx.y * OJ;
+    for (int idx = threadIdx.x; idx < LI * LJ; idx += 256) {
+      const int jj = idx / LI, ii = idx - jj * LI;
+      const int gi = i0 - 2 + ii, gj = j0 - 2 + jj;
+      if (gi > z.iv + z.ific || gj > z.jv + z.ific) continue;
+      const long long lg = (long long)(gi + z.ific - 1) + (long long)(gj + z.ific - 1) * z.incj + (long long)(kk + z.ifick - 1) * z.inck;
+#pragma unroll
+      for (int e = 0; e < NQ; e++) spl[sl][e * LJ * LI + idx] = rop[e * nd + lg];
+    }
+  };
+  int sm = 0, s0 = 1, sp = 2;   // slots of the planes k-1, k, k+1
+  if (LQ) { stage_plane(k0 - 1, 0); stage_plane(k0, 1); }
   for (int k = k0; k <= (TWOD ? k0 : k1 + 1); k++) {
     const bool last = !TWOD && k > k1;
     if (!TWOD) {
 #pragma unroll
       for (int e = 0; e < NQ; e++) qd[e] = rop[e * nd + l + z.inck];
     }
+    if (LQ) {   // plane k+1 takes the slot plane k-2 has left (last read before the barrier of the previous step)
+      stage_plane(k + 1, sp);
+      __syncthreads();
+    }
+    const int own_off = (tj + 2) * LI + ti + 2;
+    const RdLds rdl = {LQ ? &spl[sm][own_off] : nullptr, LQ ? &spl[s0][own_off] : nullptr, LQ ? &spl[sp][own_off] : nullptr};
+    const RdGlobal rdg = {rop, nd, l, z.incj, TWOD ? 0 : z.inck};
     double fk[NQ] = {};
     // finish: the balance of a cell is complete (3-D: cell k-1 once its k+1/2 face is known; 2-D: the cell itself)
     auto finish = [&](long long lb, long long ltb, const double *qcell, const double *d) {
@@ -263,7 +308,8 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
         }
     };
     if (own && !TWOD) {
-      face_full<KFLU, IFLOW, 2, FIRST, TWOD, HOMO>(z, rop, xmut, wig, l, lt, qa, qb, qc, qd, fk);
+      if constexpr (LQ) face_full<KFLU, IFLOW, 2, FIRST, TWOD, HOMO>(z, rdl, xmut, wig, l, lt, qa, qb, qc, qd, fk);
+      else face_full<KFLU, IFLOW, 2, FIRST, TWOD, HOMO>(z, rdg, xmut, wig, l, lt, qa, qb, qc, qd, fk);
       if (k > k0) {   // the cell below is complete
         double d[NQ];
 #pragma unroll
@@ -275,22 +321,34 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
       double fim[NQ] = {}, fjm[NQ] = {};
       if (do_fj) {
         double m2[NQ], m1[NQ], p1[NQ];
+        if constexpr (LQ) {
 #pragma unroll
-        for (int e = 0; e < NQ; e++) {
-          m2[e] = rop[e * nd + l - 2 * z.incj]; m1[e] = rop[e * nd + l - z.incj]; p1[e] = rop[e * nd + l + z.incj];
+          for (int e = 0; e < NQ; e++) { m2[e] = rdl(e, 0, -2, 0); m1[e] = rdl(e, 0, -1, 0); p1[e] = rdl(e, 0, 1, 0); }
+          face_full<KFLU, IFLOW, 1, FIRST, TWOD, HOMO>(z, rdl, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
+        } else {
+#pragma unroll
+          for (int e = 0; e < NQ; e++) {
+            m2[e] = rop[e * nd + l - 2 * z.incj]; m1[e] = rop[e * nd + l - z.incj]; p1[e] = rop[e * nd + l + z.incj];
+          }
+          face_full<KFLU, IFLOW, 1, FIRST, TWOD, HOMO>(z, rdg, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
         }
-        face_full<KFLU, IFLOW, 1, FIRST, TWOD, HOMO>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fjm);
       }
       const int buf = (k - k0) & 1;
 #pragma unroll
       for (int e = 0; e < NQ; e++) sfj[buf][e][tj][ti] = fjm[e];
       if (do_fi) {
         double m2[NQ], m1[NQ], p1[NQ];
+        if constexpr (LQ) {
 #pragma unroll
-        for (int e = 0; e < NQ; e++) {
-          m2[e] = rop[e * nd + l - 2]; m1[e] = rop[e * nd + l - 1]; p1[e] = rop[e * nd + l + 1];
+          for (int e = 0; e < NQ; e++) { m2[e] = rdl(e, -2, 0, 0); m1[e] = rdl(e, -1, 0, 0); p1[e] = rdl(e, 1, 0, 0); }
+          face_full<KFLU, IFLOW, 0, FIRST, TWOD, HOMO>(z, rdl, xmut, wig, l, lt, m2, m1, qc, p1, fim);
+        } else {
+#pragma unroll
+          for (int e = 0; e < NQ; e++) {
+            m2[e] = rop[e * nd + l - 2]; m1[e] = rop[e * nd + l - 1]; p1[e] = rop[e * nd + l + 1];
+          }
+          face_full<KFLU, IFLOW, 0, FIRST, TWOD, HOMO>(z, rdg, xmut, wig, l, lt, m2, m1, qc, p1, fim);
         }
-        face_full<KFLU, IFLOW, 0, FIRST, TWOD, HOMO>(z, rop, xmut, wig, l, lt, m2, m1, qc, p1, fim);
       }
       double fip[NQ];
 #pragma unroll
@@ -311,6 +369,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
 #pragma unroll
     for (int e = 0; e < NQ; e++) { qa[e] = qb[e]; qb[e] = qc[e]; qc[e] = qd[e]; }
     l += z.inck; lt += z.minck;
+    { const int t = sm; sm = s0; s0 = sp; sp = t; }
   }
 }
 
@@ -361,9 +420,17 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
   dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
+  static const bool lds_planes = !(getenv("FASTS_HIP_FULL_LDS") && atoi(getenv("FASTS_HIP_FULL_LDS")) == 0);
 #define FS_GO(K, F, FIRST_, BDF_)                                                                             \
   do {                                                                                                        \
-    if (z.twod)                                                                                               \
+    if (!z.twod && F == 2 && lds_planes) {                                                                    \
+      if (z.homo)                                                                                             \
+        hipLaunchKernelGGL((k_stage_full<K, (F == 2 ? 2 : 1), FIRST_, BDF_, false, true, (F == 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, \
+                           keep_balance, rop, rop_out, drodm, xmut, wig, b, dist);                            \
+      else                                                                                                    \
+        hipLaunchKernelGGL((k_stage_full<K, (F == 2 ? 2 : 1), FIRST_, BDF_, false, false, (F == 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, \
+                           keep_balance, rop, rop_out, drodm, xmut, wig, b, dist);                            \
+    } else if (z.twod)                                                                                               \
       hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop,  \
                          rop_out, drodm, xmut, wig, b, dist);                                                 \
     else if (z.homo && F >= 2)   /* the Euler fluxes of a k-homogeneous zone are the general ones */         \
