@@ -13,8 +13,10 @@
 //
 // Accumulation order of a cell = the order in which the reference's scatter loops reach it:
 //   drodm*coefH + Fk- + Fj- + Fi- - Fi+ - Fj+ - Fk+       (template_FluxAndBalance.for:192-271)
-// The own column's four k-planes are carried in registers; everything else (transverse neighbours,
-// metrics, viscosity) is read from global memory and served by the vector L1 / L2.
+// The own column's four k-planes are carried in registers.  On laminar three-dimensional zones the planes k-1, k, k+1
+// of the patch (2-cell margin) sit in a ring of three LDS slots, one new plane per step, and the transverse neighbours
+// are read from there; metrics and viscosity, and the neighbours of the other variants, come from global memory
+// through the vector L1 / L2.
 #include "fasts_kernels.h"
 #include "fasts_flux.h"
 
