@@ -407,13 +407,36 @@ void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, do
   else hipLaunchKernelGGL(k_sa_coe6_full<false>, g, dim3(256), 0, s, z, rop, dist, coe);
 }
 
+// Variant of the kernel for one (scheme, model, stage kind): two-dimensional zones; laminar three-dimensional zones with
+// the state planes in LDS (k-homogeneous or general); Euler and Spalart-Allmaras three-dimensional zones (the Euler fluxes
+// of a k-homogeneous zone are the general ones).
+template <int K, int F, bool FIRST_, bool BDF_>
+static void launch_full(const FsZone &z, dim3 g, hipStream_t s, double coefH, double coefW, int kchunk, int keep_balance,
+                        const double *rop, double *rop_out, double *drodm, const double *xmut, unsigned char *wig,
+                        const FsBdf &b, const double *dist)
+{
+#define FS_L(...) hipLaunchKernelGGL((k_stage_full<__VA_ARGS__>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop, \
+                                     rop_out, drodm, xmut, wig, b, dist)
+  if (z.twod) { FS_L(K, F, FIRST_, BDF_, true); return; }
+  if constexpr (F == 2) {
+    if (z.homo) FS_L(K, F, FIRST_, BDF_, false, true, true);
+    else FS_L(K, F, FIRST_, BDF_, false, false, true);
+  } else if constexpr (F == 3) {
+    if (z.homo) FS_L(K, F, FIRST_, BDF_, false, true);
+    else FS_L(K, F, FIRST_, BDF_, false);
+  } else {
+    FS_L(K, F, FIRST_, BDF_, false);
+  }
+#undef FS_L
+}
+
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                    double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, const double *dist,
                    int keep_balance, hipStream_t s)
 {
   if (z.ityp != 0 || !z.vol || !z.mt[0] || !z.mt[1] || !z.mt[2]) return -1;
   if (z.iflow == 3 && (z.neq != 6 || !dist)) return -1;
-  int kchunk = 16;   // 256^3: 2.85 ms per stage against 2.96 with 32 (more workgroups in flight per CU)
+  int kchunk = 16;   // 256^3 senseur laminar: 2.18 ms per stage; 8: 2.21, 32: 2.26, 64: 2.47 (workgroups in flight per CU)
   if (const char *ev = getenv("FASTS_HIP_KCHUNK_FULL")) {
     int v = atoi(ev);
     if (v >= 1) kchunk = v;
@@ -422,26 +445,7 @@ int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const
   dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
-  static const bool lds_planes = !(getenv("FASTS_HIP_FULL_LDS") && atoi(getenv("FASTS_HIP_FULL_LDS")) == 0);
-#define FS_GO(K, F, FIRST_, BDF_)                                                                             \
-  do {                                                                                                        \
-    if (!z.twod && F == 2 && lds_planes) {                                                                    \
-      if (z.homo)                                                                                             \
-        hipLaunchKernelGGL((k_stage_full<K, (F == 2 ? 2 : 1), FIRST_, BDF_, false, true, (F == 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, \
-                           keep_balance, rop, rop_out, drodm, xmut, wig, b, dist);                            \
-      else                                                                                                    \
-        hipLaunchKernelGGL((k_stage_full<K, (F == 2 ? 2 : 1), FIRST_, BDF_, false, false, (F == 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, \
-                           keep_balance, rop, rop_out, drodm, xmut, wig, b, dist);                            \
-    } else if (z.twod)                                                                                               \
-      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop,  \
-                         rop_out, drodm, xmut, wig, b, dist);                                                 \
-    else if (z.homo && F >= 2)   /* the Euler fluxes of a k-homogeneous zone are the general ones */         \
-      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false, (F >= 2)>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, \
-                         rop, rop_out, drodm, xmut, wig, b, dist);                                            \
-    else                                                                                                      \
-      hipLaunchKernelGGL((k_stage_full<K, F, FIRST_, BDF_, false>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop, \
-                         rop_out, drodm, xmut, wig, b, dist);                                                 \
-  } while (0)
+#define FS_GO(K, F, FIRST_, BDF_) launch_full<K, F, FIRST_, BDF_>(z, g, s, coefH, coefW, kchunk, keep_balance, rop, rop_out, drodm, xmut, wig, b, dist)
 #define FS_CASE(K, F)                                                                                         \
   if (z.kflu == K && z.iflow == F) {                                                                          \
     if (bdf) { if (first) FS_GO(K, F, true, true); else FS_GO(K, F, false, true); }                           \
