@@ -123,6 +123,9 @@ def main():
                     'C-mesh (Spalart-Allmaras, implicit LU-SGS, local time step; 2*NFOIL + 2*(NFOIL/3) cells around, '
                     '2*NFOIL/3 across; Newton sub-iterations from --implicit, default 3); not the headline workload')
     ap.add_argument('--cfl', type=float, default=1., help='CFL number of the local time step (--naca)')
+    ap.add_argument('--channel', type=int, nargs=3, default=None, metavar=('BI', 'BJ', 'BK'), help='one GPU\'s share of a '
+                    'multi-block channel: the --cells^3 box cut in BI x 1 x BK curvilinear blocks (BJ must be 1), no-slip '
+                    'walls on jmin / jmax, periodic along i and k through match joins; not the headline workload')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -142,6 +145,9 @@ def main():
         raise SystemExit("bench.py: --perturb / --implicit are single-GPU options")
     if a.naca and world > 1:
         raise SystemExit("bench.py: --naca is a single-GPU option")
+    if a.channel and (world > 1 or a.channel[1] != 1 or a.naca):
+        raise SystemExit("bench.py: --channel BI 1 BK is a single-GPU option")
+    nblk = 1
     if a.naca:
         from fast_amd import connect
         import fast_amd.pytree_lite as C
@@ -155,6 +161,24 @@ def main():
         ctx = FastC.HOOK['ctx']
         run_step = lambda it: FastS._compute(t, metrics, it, tc)
         ncell_total = (2 * nf + 2 * nw) * nj
+    elif a.channel:
+        from fast_amd import connect
+        import fast_amd.pytree_lite as C
+        blocks = tuple(a.channel)
+        nblk = blocks[0] * blocks[1] * blocks[2]
+        a.perturb = a.perturb or 0.2
+        nv = tuple(a.n // b for b in blocks)
+        kw = {}
+        if a.implicit:
+            kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': a.implicit}}
+        t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n * (10. if a.implicit else 1.), blocks=blocks,
+                      perturb=a.perturb, bcs={'jmin': 'BCWall', 'jmax': 'BCWall'}, **kw)
+        tc = C.node2Center(t)
+        connect.add_joins_to_tc(tc, connect.periodic_block_joins(blocks, nv), [z[0] for z in Internal.getZones(t)])
+        (t, tc, metrics) = FastS.warmup(t, tc, device=local_rank)
+        ctx = FastC.HOOK['ctx']
+        run_step = lambda it: FastS._compute(t, metrics, it, tc)
+        ncell_total = nv[0] * nv[1] * nv[2] * nblk
     elif world == 1:
         kw = {}
         if a.implicit:
@@ -210,7 +234,7 @@ def main():
             with open(tf) as fh:
                 traffic = json.load(fh).get('traffic_bytes_per_launch')
         # algorithmic bytes per launch; per-cell metrics (9 surface-vector components + volume) are read once per stage
-        bpl = (BYTES_PER_CELL_STEP[a.scheme] + (240.0 if (a.perturb or a.naca) else 0.)) / 3.0 * (ncell_total // world)
+        bpl = (BYTES_PER_CELL_STEP[a.scheme] + (240.0 if (a.perturb or a.naca) else 0.)) / 3.0 * (ncell_total // world // nblk)
         ach = bpl / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.
         out = {
             "metric": "Mcell-iter/s (fp64 RK3 TGV 256^3)",
@@ -222,10 +246,13 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "NACA0012 C-mesh %d x %d cells, NSTurbulent (Spalart-Allmaras), scheme=%s, wall + far field + "
                                    "wake match join" % (2 * a.naca + 2 * (a.naca // 3), 2 * a.naca // 3, a.scheme) if a.naca else
+                                   "channel share: %d^3 cells in %d x %d x %d curvilinear blocks, %s, scheme=%s, RK3, no-slip walls on "
+                                   "j, periodic i and k through match joins" % ((a.n,) + tuple(a.channel) + (model, a.scheme)) if a.channel else
                                    "TGV Re=1600 M=0.1, %d^3 cells per GPU, NSLaminar, scheme=%s, RK3, periodic"
                                    % (a.n, a.scheme) if model != 'Euler' else
                                    "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
-                       "blocks": list(split_for(world) or (1, 1, 1)), "block_cells": list(block_cells(a.n, world)),
+                       "blocks": list(a.channel) if a.channel else list(split_for(world) or (1, 1, 1)),
+                       "block_cells": [a.n // b for b in a.channel] if a.channel else list(block_cells(a.n, world)),
                        "ghost_layers": 2,
                        "mesh": "two-dimensional C-mesh" if a.naca else ("curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"),
                        "time_scheme": ("implicit BDF1 local time step, LU-SGS, %d Newton sub-iterations" if a.naca else
