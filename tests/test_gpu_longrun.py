@@ -42,6 +42,26 @@ def test_many_steps_bit_exact(n, scheme, nit):
         os.environ.pop('FASTS_HIP_LAZY_SYNC', None)
 
 
+@pytest.mark.parametrize("scheme,bcs", [('senseur', None), ('roe_min', {'jmin': 'BCWall', 'jmax': 'BCOutflow'})])
+def test_curvilinear_hundred_steps_bit_exact(scheme, bcs):
+    """100 steps on a curvilinear 48 x 40 x 36 zone (several patches and k chunks of the stage kernel that keeps the state
+    planes in LDS): bit for bit, the 0/1 sensor of senseur included."""
+    os.environ['FASTS_HIP_LAZY_SYNC'] = '1'
+    try:
+        t, metrics, z, oz = _pair(cases.tgv((48, 40, 36), scheme, extra_numz=SINGLE, perturb=0.2, bcs=bcs))
+        oz.fill_ghostcells()
+        for it in range(1, 101):
+            FastS._compute(t, metrics, it, None)
+            oz.step()
+            if it % 25 == 0:
+                FastS.sync_to_host(t)
+                got = FastC.level_buffer(z)
+                assert np.array_equal(got, oz.ro), "step %d: max abs diff %g" % (it, np.abs(got - oz.ro).max())
+        assert np.isfinite(got).all()
+    finally:
+        os.environ.pop('FASTS_HIP_LAZY_SYNC', None)
+
+
 def test_sa_hundred_steps():
     """The device pow of the destruction term differs from the host pow in the last bit: 1e-11 after 100 steps."""
     t, metrics, z, oz = _pair(cases.tgv((24, 20, 16), 'senseur', model='NSTurbulent', extra_numz=SINGLE,
