@@ -122,6 +122,8 @@ def main():
     ap.add_argument('--naca', type=int, default=0, metavar='NFOIL', help='steady-RANS set-up on a two-dimensional NACA0012 '
                     'C-mesh (Spalart-Allmaras, implicit LU-SGS, local time step; 2*NFOIL + 2*(NFOIL/3) cells around, '
                     '2*NFOIL/3 across; Newton sub-iterations from --implicit, default 3); not the headline workload')
+    ap.add_argument('--lu-threads', type=int, default=1, metavar='T', help='with --implicit / --naca: LU-SGS solve in the '
+                    'blocks of T OpenMP threads of the reference (its result with OMP_NUM_THREADS=T); 1 = one sweep per zone')
     ap.add_argument('--cfl', type=float, default=1., help='CFL number of the local time step (--naca)')
     ap.add_argument('--channel', type=int, nargs=3, default=None, metavar=('BI', 'BJ', 'BK'), help='one GPU\'s share of a '
                     'multi-block channel: the --cells^3 box cut in BI x 1 x BK curvilinear blocks (BJ must be 1), no-slip '
@@ -140,6 +142,7 @@ def main():
     import fast_amd.Mpi as FastSmpi
 
     model = 'Euler' if a.scheme == 'roe' else 'NSLaminar'
+    FastC.OMP_NUM_THREADS = max(1, a.lu_threads)
 
     if (a.perturb or a.implicit) and world > 1:
         raise SystemExit("bench.py: --perturb / --implicit are single-GPU options")
@@ -256,7 +259,9 @@ def main():
                        "ghost_layers": 2,
                        "mesh": "two-dimensional C-mesh" if a.naca else ("curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"),
                        "time_scheme": ("implicit BDF1 local time step, LU-SGS, %d Newton sub-iterations" if a.naca else
-                                       "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit if a.implicit else "explicit RK3"},
+                                       "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit +
+                                      (", LU-SGS in the blocks of %d threads" % a.lu_threads if a.lu_threads > 1 else "")
+                                      if a.implicit else "explicit RK3"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n,

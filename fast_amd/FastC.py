@@ -75,7 +75,11 @@ varsN = ['Density']
 varsP = ['Density_P1']
 varsM = ['Density_M1']
 
-OMP_NUM_THREADS = 1          # the device engine has no host thread team
+# The device engine has no host thread team.  The one place where the reference's result depends on its number of
+# OpenMP threads is the LU-SGS solve of the implicit scheme, which every thread runs on its own block of a zone
+# (lu_thread_blocks below): OMP_NUM_THREADS > 1 asks the device for the result of the reference run with that many
+# threads (and gives it that many independent blocks to sweep side by side); 1 = one sweep per zone.
+OMP_NUM_THREADS = int(os.environ.get('FASTS_HIP_LU_THREADS', '1'))
 MX_SYNCHRO = 1000
 MX_SSZONE = 10
 MX_OMP_SIZE_INT = -1
@@ -366,6 +370,82 @@ def _build_omp(t):
         datap[SCHEDULER] = c
         p[1] = datap
     return None
+
+
+def lu_thread_blocks(pint, nthreads, lmin=10):
+    """Blocks of interior cells that the reference's OpenMP threads take in a zone (omp_mode 0: every zone is cut among
+    all the threads, Fast/FastC/FastC/HPC_LAYER/distributeThreads.cpp:90-95 -> indice_boucle_lu.for:94-335), as an
+    (n, 6) int32 array of (imin, imax, jmin, jmax, kmin, kmax), cells numbered from 1; threads left without cells are
+    dropped.  The cut is p x q with p a divisor of nthreads not larger than 8, along k and j when both directions
+    offer enough slices of lmin cells (10 with the implicit scheme), else along j and i; the pair with the smallest
+    load imbalance wins (an uneven cut along the second direction counts 2 or 5 times)."""
+    n = int(nthreads)
+    size = [int(pint[IJKV]), int(pint[IJKV + 1]), int(pint[IJKV + 2])]
+    whole = numpy.array([[1, size[0], 1, size[1], 1, size[2]]], dtype=numpy.int32)
+    if n <= 1:
+        return whole
+    slices = [max(1, v // lmin) for v in size]
+    if size[2] == 1:
+        slices[2] = 1
+    divisors = [1] + [q for q in range(2, 9) if n % q == 0]
+    f32 = numpy.float32
+
+    def imbalance(a, ca, b, cb, weight):     # direction a cut in ca, direction b in cb
+        return float(f32(size[a] % ca) / f32(size[a] // ca)) + float(f32(size[b] % cb) / f32(size[b] // cb)) * weight
+
+    def best_cut(a, b, weight, small_first):
+        """(count along a, count along b) or None; a = the direction the reference prefers to cut.  small_first: the
+        pair with the divisor along a is tried before the pair with it along b (a later pair wins only when cheaper)."""
+        best, cost_best = None, 100000.
+        for p1 in divisors:
+            p2 = n // p1
+            for (ca, cb) in (((p1, p2), (p2, p1)) if small_first else ((p2, p1), (p1, p2))):
+                if ca <= slices[a] and cb <= slices[b]:
+                    cost = imbalance(a, ca, b, cb, weight)
+                    if cost < cost_best:
+                        best, cost_best = (ca, cb), cost
+        return best
+
+    counts = None
+    failed = False
+    if slices[2] * slices[1] >= n:
+        cut = best_cut(2, 1, 2., False)
+        if cut is not None:
+            counts = [1, cut[1], cut[0]]
+        else:
+            failed = True
+    if counts is None and slices[0] * slices[1] >= n:
+        cut = best_cut(1, 0, 5., True)
+        if cut is not None:
+            counts = [cut[1], cut[0], 1]
+        else:
+            failed = True
+    if counts is None:
+        if failed:
+            return whole                      # the first thread takes the zone
+        # not enough slices for every thread: as many blocks as there are slices, the other threads idle
+        if slices[0] * slices[1] > slices[1] * slices[2]:
+            counts = [slices[0], slices[1], 1]
+        else:
+            counts = [1, slices[1], slices[2]]
+
+    def part(d, q):                            # q-th (from 0) of counts[d] parts of direction d
+        c, v = counts[d], size[d]
+        sz, rest = v // c, v % c
+        if q < rest:
+            return 1 + (sz + 1) * q, (sz + 1) * (q + 1)
+        return 1 + sz * q + rest, sz * (q + 1) + rest
+
+    blocks = []
+    if counts[0] == 1:
+        for t in range(min(n, counts[1] * counts[2])):
+            kq, jq = divmod(t, counts[1])
+            blocks.append((1, size[0]) + part(1, jq) + part(2, kq))
+    else:
+        for t in range(min(n, counts[0] * counts[1])):
+            jq, iq = divmod(t, counts[0])
+            blocks.append(part(0, iq) + part(1, jq) + (1, size[2]))
+    return numpy.array(blocks, dtype=numpy.int32)
 
 
 # ======================================================================================

@@ -118,6 +118,9 @@ def _new_context(zones, metrics, dtloc, device):
             ctx.zone_set_distance(nd, dist[1])
         if int(pint[62]) == 1:     # selective frequency damping: the compacted *_f fields
             ctx.zone_set_filtered(nd, FastC.level_buffer(z, '_f'))
+        if int(pint[29]) == 1 and FastC.OMP_NUM_THREADS > 1:
+            # LU-SGS solve in the blocks of that many OpenMP threads of the reference (distributeThreads.cpp:90-95)
+            ctx.zone_set_lu_blocks(nd, FastC.lu_thread_blocks(pint, FastC.OMP_NUM_THREADS))
         names[z[0]] = nd
     return ctx, names
 

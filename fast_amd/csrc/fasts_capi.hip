@@ -86,7 +86,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
     if (zn.ev_lu_fork) (void)hipEventDestroy(zn.ev_lu_fork);
     if (zn.ev_lu_join) (void)hipEventDestroy(zn.ev_lu_join);
@@ -135,6 +135,49 @@ extern "C" int fs_zone_set_filtered(fs_ctx *ctx, int zone, double *rof, long lon
   if (zn.pint[SFD] != 1) return fail(ctx, FS_ERR_STATE, "fs_zone_set_filtered: the zone does not use selective frequency damping");
   if (n != (long long)zn.z.neq * zn.z.nd) return fail(ctx, FS_ERR_ARG, "fs_zone_set_filtered: NEQ * NDIMDX values expected");
   zn.rof_host = rof;
+  return FS_OK;
+}
+
+extern "C" int fs_zone_set_lu_blocks(fs_ctx *ctx, int zone, int nblocks, const int32_t *ind_sdm)
+{
+  if (!ctx || (nblocks > 0 && !ind_sdm)) return ctx ? fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: null argument") : FS_ERR_ARG;
+  if (zone < 0 || zone >= (int)ctx->zones.size()) return fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: zone index out of range");
+  if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_zone_set_lu_blocks: call before fs_upload");
+  Zone &zn = ctx->zones[zone];
+  if (!ctx->implicit) return fail(ctx, FS_ERR_STATE, "fs_zone_set_lu_blocks: the zone does not use the implicit scheme");
+  if (nblocks <= 1) { zn.lu_blocks.clear(); return FS_OK; }
+  if (nblocks > 4096) return fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: at most 4096 blocks");
+  if (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_set_lu_blocks: thread blocks with nb_relax > 1 or lu_match = 1 are not supported");
+  // the blocks tile the interior: each inside it, pairwise disjoint, volumes adding up to the zone's
+  const int hi[3] = {zn.z.iv, zn.z.jv, zn.z.kv};
+  long long cells = 0;
+  for (int b = 0; b < nblocks; b++) {
+    const int32_t *q = ind_sdm + 6 * b;
+    long long v = 1;
+    for (int d = 0; d < 3; d++) {
+      if (q[2 * d] < 1 || q[2 * d + 1] > hi[d] || q[2 * d + 1] < q[2 * d])
+        return fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: block " + std::to_string(b) + " is empty or leaves the interior of the zone");
+      v *= q[2 * d + 1] - q[2 * d] + 1;
+    }
+    cells += v;
+    for (int a = 0; a < b; a++) {
+      const int32_t *o = ind_sdm + 6 * a;
+      bool apart = false;
+      for (int d = 0; d < 3; d++) apart = apart || q[2 * d] > o[2 * d + 1] || o[2 * d] > q[2 * d + 1];
+      if (!apart) return fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: blocks " + std::to_string(a) + " and " + std::to_string(b) + " overlap");
+    }
+  }
+  if (cells != (long long)hi[0] * hi[1] * hi[2]) return fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: the blocks do not cover the interior of the zone");
+  // LU range of a block: its own bounds, and on a face of the zone that of the zone (one ghost layer more over a
+  // wall, Fast/FastS/FastS/BC/BCzone.cpp:99-127: the test is made per thread block)
+  zn.lu_blocks.assign((size_t)6 * nblocks, 0);
+  for (int b = 0; b < nblocks; b++)
+    for (int d = 0; d < 3; d++) {
+      const int32_t lo = ind_sdm[6 * b + 2 * d], up = ind_sdm[6 * b + 2 * d + 1];
+      zn.lu_blocks[6 * b + 2 * d] = lo == 1 ? zn.lu[2 * d] : lo;
+      zn.lu_blocks[6 * b + 2 * d + 1] = up == hi[d] ? zn.lu[2 * d + 1] : up;
+    }
   return FS_OK;
 }
 
@@ -462,7 +505,7 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       e = hipMemcpy(zn.mtr_dev, mtr, nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(zn.mtr_dev);
-    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
       return fail(ctx, FS_ERR_HIP, std::string("fs_zone_add: metric upload: ") + hipGetErrorString(e));
     }
     z.mt[0] = zn.mtr_dev; z.mt[1] = zn.mtr_dev + 3 * z.ndm; z.mt[2] = zn.mtr_dev + 6 * z.ndm;
@@ -570,6 +613,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
       if (ctx->implicit) {
         HIPCHK(ctx, hipMalloc(&zn.scratch, nb));
         HIPCHK(ctx, hipMemsetAsync(zn.scratch, 0, nb, ctx->stream));
+        if (!zn.lu_blocks.empty()) {
+          HIPCHK(ctx, hipMalloc(&zn.lu_blocks_dev, sizeof(int) * zn.lu_blocks.size()));
+          HIPCHK(ctx, hipMemcpy(zn.lu_blocks_dev, zn.lu_blocks.data(), sizeof(int) * zn.lu_blocks.size(), hipMemcpyHostToDevice));
+        }
         if (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0) {   // increments and accumulator of the SSOR relaxations (Compute/ssor.cpp)
           HIPCHK(ctx, hipMalloc(&zn.ssor_work, 2 * nb));
           HIPCHK(ctx, hipMemsetAsync(zn.ssor_work, 0, 2 * nb, ctx->stream));
@@ -874,7 +921,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       const int lrc = (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
                           ? fsk_lussor(z, zn.lu, sdm, zn.pint[NB_RELAX], zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
                                        zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
-                          : fsk_lusgs(z, zn.lu, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
+                          : fsk_lusgs(z, zn.lu, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.preal[GAMMA], zn.dev[in],
+                                      zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
       if (sfd && !verif && nstep == z.nssiter - 1)
         fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, zn.coe, ls);
       if (ctx->lu_nstreams > 0) {

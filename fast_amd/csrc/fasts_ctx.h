@@ -27,6 +27,10 @@ struct Zone {
   FsBcWin *rhs_face_dev = nullptr, *rhs_bc_dev = nullptr;
   long long rhs_max_cells = 0;
   int lu[6] = {0, 0, 0, 0, 0, 0};
+  // LU ranges of the blocks swept independently of each other (fs_zone_set_lu_blocks), 6 integers each; empty = the
+  // whole range `lu` in one lexicographic sweep
+  std::vector<int> lu_blocks;
+  int *lu_blocks_dev = nullptr;
   double *res_part = nullptr, *res_out = nullptr;   // res_out: 12 residual sums / maxima per sub-iteration, then the CFL triple
   int res_slots = 0;              // sub-iterations of the last verification step whose norms are in res_out
   bool have_cfl = false;

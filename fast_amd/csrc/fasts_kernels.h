@@ -86,8 +86,8 @@ void fsk_tgv_sums(const FsZone &z, const double *rop, double *part, double *out,
 void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, double gamma, double prandtl, double rgp,
                       const double *rop, const double *xmut, double *coe, hipStream_t s);
 // range[6] = cells swept (interior, plus one ghost layer on wall faces)
-int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out, double *scratch,
-              double *dw, const double *coe, hipStream_t s);
+int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
+              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s);
 int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nb_relax, int overlap, double gamma, const double *rop, double *rop_out,
                double *scratch, const double *din, double *work, const double *coe, hipStream_t s);
 

@@ -255,11 +255,35 @@ FS_DEV double lane_next(double x)
   return __hiloint2double(hi, lo);
 }
 
+// Range, hyperplane and first k-plane of a workgroup.  tab != NULL: one range per blockIdx.z -- the blocks that the
+// reference's OpenMP threads sweep independently of each other (each thread calls invlu on its own range and skips the
+// neighbour terms across its borders, Fast/FastS/FastS/Compute/lhs.cpp:149-161, LU/invlu_l.for:90-215) -- else r0.
+// n numbers the launches of a sweep: the lower sweep of a block runs its hyperplanes upwards from 0, the upper sweep
+// downwards from its last one, so that blocks of different sizes all start at launch 0.  False when the block has no
+// hyperplane for launch n.
+template <int U, bool UPPER>
+FS_DEV bool lu_block(const LuRange &r0, const LuRange *__restrict__ tab, int n, LuRange &r, int &nchunk, int &h, int &kbase)
+{
+  r = r0;
+  if (tab) r = tab[blockIdx.z];
+  nchunk = (r.i1 - r.i0 + U) / U;
+  const int nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
+  const int nhc = nchunk + nj + nk - 2;
+  h = UPPER ? nhc - 1 - n : n;
+  if (h < 0 || h >= nhc) return false;
+  const int klo = h - (nchunk - 1) - (nj - 1);
+  kbase = r.k0 + (klo < 0 ? 0 : klo);
+  return true;
+}
+
 template <bool FULL, int NE, int U = 8>
-__global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+__global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r0, const LuRange *__restrict__ tab, int n,
                                                       const double *__restrict__ rop, double *__restrict__ dw,
                                                       const double *__restrict__ coe)
 {
+  LuRange r;
+  int nchunk, h, kbase;
+  if (!lu_block<U, false>(r0, tab, n, r, nchunk, h, kbase)) return;
   const int u = threadIdx.x / U, m = threadIdx.x % U;
   // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
   const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
@@ -329,11 +353,14 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
 }
 
 template <bool FULL, int NE, int U = 8>
-__global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+__global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRange r0, const LuRange *__restrict__ tab, int n,
                                                       const double *__restrict__ rop, const double *rop_kn,
                                                       double *rop_new, double *__restrict__ dw,
                                                       const double *__restrict__ coe)
 {
+  LuRange r;
+  int nchunk, h, kbase;
+  if (!lu_block<U, true>(r0, tab, n, r, nchunk, h, kbase)) return;
   const int u = threadIdx.x / U, m = threadIdx.x % U;
   // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
   const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
@@ -634,8 +661,12 @@ void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, doub
 // LU-SGS on the interior of the zone + Newton update.  rop = current iterate; the new iterate is
 // written to rop_out.  When rop_out == rop (in-place update, sub-iterations after the first) the new
 // state is built in scratch (a full time level) and copied back.
-int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out, double *scratch,
-              double *dw, const double *coe, hipStream_t s)
+// nblocks > 1: the range is cut in blocks that are swept independently of each other, as the OpenMP threads of the
+// reference do (blocks = their LU ranges on the host, 6 integers each; blocks_dev = the same table on the device); the
+// blocks tile `range`.  A launch then advances every block by one hyperplane (blockIdx.z = block).
+template <int U>
+static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
+                        const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s)
 {
   LuConst c;
   c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
@@ -649,28 +680,45 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
   const bool sa = z.neq == 6;
-  // units of U consecutive cells of an i-line: the recurrence of a launch has U steps, a sweep ni/U + nj + nk - 2
-  // launches of (cells of the hyperplane)/64 waves.  Measured at 256^3, 3 Newton sub-iterations: U = 4 40.2 ms per
-  // step (twice the waves in the large hyperplanes of mid-sweep), U = 8 31.5 ms, U = 16 33.5 ms; two-dimensional
-  // NACA0012 case 15.0 / 13.9 / 16.0 ms
-  constexpr int U = 8;
-  const int nchunk = (ni + U - 1) / U;
-  const int nhc = nchunk + nj + nk - 2;
   const int wpu = 64 / U;
-  const unsigned gx8 = (unsigned)((nchunk + wpu - 1) / wpu);
+  const bool multi = nblocks > 1 && blocks && blocks_dev;
+  const int nb = multi ? nblocks : 1;
+  const int *br = multi ? blocks : range;
+  const LuRange *tab = multi ? reinterpret_cast<const LuRange *>(blocks_dev) : nullptr;
+  int max_nhc = 0;
+  for (int b = 0; b < nb; b++) {
+    const int *q = br + 6 * b;
+    const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
+    if (bi < 1 || bj < 1 || bk < 1) return -1;
+    const int nhc = (bi + U - 1) / U + bj + bk - 2;
+    if (nhc > max_nhc) max_nhc = nhc;
+  }
   for (int pass = 0; pass < 2; pass++)
-    for (int n = 0; n < nhc; n++) {
-      const int h = pass == 0 ? n : nhc - 1 - n;
-      int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
-      int khi = h < nk - 1 ? h : nk - 1;
-      dim3 g(gx8, (unsigned)(khi - klo + 1));
+    for (int n = 0; n < max_nhc; n++) {
+      // grid of launch n: the widest hyperplane among the blocks that have one
+      unsigned gx = 0, gy = 0;
+      for (int b = 0; b < nb; b++) {
+        const int *q = br + 6 * b;
+        const int bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
+        const int nchunk = (q[1] - q[0] + U) / U;
+        const int nhc = nchunk + bj + bk - 2;
+        const int h = pass == 0 ? n : nhc - 1 - n;
+        if (h < 0 || h >= nhc) continue;
+        int klo = h - (nchunk - 1) - (bj - 1); if (klo < 0) klo = 0;
+        const int khi = h < bk - 1 ? h : bk - 1;
+        const unsigned x = (unsigned)((nchunk + wpu - 1) / wpu), y = (unsigned)(khi - klo + 1);
+        if (x > gx) gx = x;
+        if (y > gy) gy = y;
+      }
+      if (!gx || !gy) continue;
+      dim3 g(gx, gy, (unsigned)nb);
 #define FS_LOW(F, N)                                                                                                            \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((k_lu_lower_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, dw, coe);             \
+    hipLaunchKernelGGL((k_lu_lower_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, tab, n, rop, dw, coe);                             \
   } while (0)
 #define FS_UPP(F, N)                                                                                                            \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((k_lu_upper_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dw, coe); \
+    hipLaunchKernelGGL((k_lu_upper_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, tab, n, rop, rop_kn, rop_new, dw, coe);            \
   } while (0)
       if (pass == 0) {
         if (sa && full) FS_LOW(true, 6); else if (sa) FS_LOW(false, 6); else if (full) FS_LOW(true, 5); else FS_LOW(false, 5);
@@ -685,6 +733,27 @@ int fsk_lusgs(const FsZone &z, const int *range, double gamma, const double *rop
     hipLaunchKernelGGL(k_copy_range, g, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
   }
   return 0;
+}
+
+int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
+              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s)
+{
+  // units of U consecutive cells of an i-line: the recurrence of a launch has U steps, a sweep ni/U + nj + nk - 2
+  // launches of (cells of the hyperplane)/64 waves.  One sweep of the zone is bound by the latency of a launch:
+  // measured at 256^3, 3 Newton sub-iterations: U = 4 40.2 ms per step (twice the waves in the large hyperplanes of
+  // mid-sweep), U = 8 31.5 ms, U = 16 33.5 ms; two-dimensional NACA0012 case 15.0 / 13.9 / 16.0 ms.  With thread blocks
+  // a launch carries a hyperplane of every block and is bound by memory instead: a unit of 16 cells is a whole
+  // 128-byte line of every array where 8 cells use half of each line they touch (256^3 in the blocks of 64 threads:
+  // 23.4 ms per step with U = 8, 17.2 ms with U = 16; NACA0012 in 24 blocks 5.6 / 4.1 ms).
+  // FASTS_HIP_LU_UNIT = 8 | 16 overrides the choice (measurements).
+  static int unit = -1;
+  if (unit < 0) {
+    const char *ev = getenv("FASTS_HIP_LU_UNIT");
+    unit = ev ? atoi(ev) : 0;
+  }
+  const int u = unit ? unit : (nblocks > 1 ? 16 : 8);
+  if (u == 16) return lusgs_sweeps<16>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s);
+  return lusgs_sweeps<8>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s);
 }
 
 // LU-SSOR with nb_relax >= 2 on the range `range`, Newton update on the cells of `sdm` (the interior of the zone).

@@ -2689,10 +2689,30 @@ void fo_sfd(const i32 *p, const double *pr, int nitrun, double *rop, double *rof
  * reference tabulates (Fast/FastS/FastS/Compute/residus_navier.h, cprdu3s1_incl.for:47-71).
  * rhs_only != 0: the verification slot of a step (last of the NSSITER slots on a verification step,
  * Fast/FastC/FastC/Compute/souszones_list.cpp:81-83 lexit_lu): the residual is evaluated and the LU solve skipped. */
+int fo_subiter_implicit_blocks(const i32 *p, const double *pr, int nitcfg, int first_it, const double *ro,
+                               const double *ro_m1, double *ro_p1, double *drodm, double *coe, double *xmut,
+                               double *wig, const double *ti, const double *tj, const double *tk, const double *vol,
+                               double *newton_rhs, int rhs_only, int nblk, const i32 *blk);
+
 int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it, const double *ro,
                         const double *ro_m1, double *ro_p1, double *drodm, double *coe, double *xmut,
                         double *wig, const double *ti, const double *tj, const double *tk, const double *vol,
                         double *newton_rhs, int rhs_only)
+{
+  return fo_subiter_implicit_blocks(p, pr, nitcfg, first_it, ro, ro_m1, ro_p1, drodm, coe, xmut, wig, ti, tj, tk, vol,
+                                    newton_rhs, rhs_only, 0, NULL);
+}
+
+/* The same with the LU-SGS solve cut in the blocks of the reference's OpenMP threads: blk holds nblk ranges of
+ * interior cells (ind_dm_thread of Fast/FastS/FastS/Compute/lhs.cpp:129-131, from indice_boucle_lu.for); every thread
+ * calls invlu on its own block (lhs.cpp:149-161), extended by the ghost layer on the faces of the zone where the block
+ * touches a wall (BC/BCzone.cpp:99-127), and invlu skips the neighbour terms across the borders of its range: the
+ * blocks are independent of each other, so solving them one after the other gives what the threads give.  The
+ * right-hand side (one thread here) does not depend on the blocks.  nblk <= 1: one block, the zone. */
+int fo_subiter_implicit_blocks(const i32 *p, const double *pr, int nitcfg, int first_it, const double *ro,
+                               const double *ro_m1, double *ro_p1, double *drodm, double *coe, double *xmut,
+                               double *wig, const double *ti, const double *tj, const double *tk, const double *vol,
+                               double *newton_rhs, int rhs_only, int nblk, const i32 *blk)
 {
   const int iv = p[IJKV], jv = p[IJKV + 1], kv = p[IJKV + 2];
   const int f = p[NIJK + 3], fk = p[NIJK + 4];
@@ -2722,6 +2742,7 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
   i32 lu[6];
   if (fo_bczone_rhs(p, drodm, ti, tj, tk, lu)) return -1;
   if (p[NB_RELAX] > 1 || p[LU_MATCH] != 0) {
+    if (nblk > 1) return -1;
     const size_t n = (size_t)p[NEQ] * p[NDIMDX];
     double *w = (double *)calloc(2 * n, sizeof(double));
     if (!w) return -1;
@@ -2729,6 +2750,17 @@ int fo_subiter_implicit(const i32 *p, const double *pr, int nitcfg, int first_it
                                     : fo_invlussor(p, pr, lu, sdm, drodm, w, w + n, rop_ss, ro_p1, ti, tj, tk, coe);
     free(w);
     return rc;
+  }
+  if (nblk > 1 && blk) {
+    for (int b = 0; b < nblk; b++) {
+      i32 r[6];
+      for (int d = 0; d < 3; d++) {
+        r[2 * d] = blk[6 * b + 2 * d] == sdm[2 * d] ? lu[2 * d] : blk[6 * b + 2 * d];
+        r[2 * d + 1] = blk[6 * b + 2 * d + 1] == sdm[2 * d + 1] ? lu[2 * d + 1] : blk[6 * b + 2 * d + 1];
+      }
+      fo_invlu(p, pr, r, drodm, rop_ss, ro_p1, ti, tj, tk, coe);
+    }
+    return 0;
   }
   fo_invlu(p, pr, lu, drodm, rop_ss, ro_p1, ti, tj, tk, coe);
   return 0;

@@ -60,6 +60,7 @@ def lib():
         _lib.fo_step_mt.restype = ctypes.c_int
         _lib.fo_bczone.restype = ctypes.c_int
         _lib.fo_subiter_implicit.restype = ctypes.c_int
+        _lib.fo_subiter_implicit_blocks.restype = ctypes.c_int
     return _lib
 
 
@@ -222,10 +223,14 @@ class OracleZone:
         if self.implicit:
             rhs_only = nstep == int(self.pint[NSSITER])
             keep = self.stage1_rhs if nstep == 1 else (self.drodm_keep() if self.verif else None)
-            rc = lib().fo_subiter_implicit(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), ctypes.c_int(self.first_it),
-                                           _p(self.ro), _p(self.ro_m1), _p(self.ro_p1), _p(self.drodm), _p(self.coe),
-                                           _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj), _p(self.tk), _p(self.vol),
-                                           _p(keep) if keep is not None else None, ctypes.c_int(int(rhs_only)))
+            # lu_blocks: (n, 6) int32 ranges of interior cells, the blocks of the reference's OpenMP threads, or None
+            blk = getattr(self, 'lu_blocks', None)
+            nblk = 0 if blk is None else len(blk)
+            rc = lib().fo_subiter_implicit_blocks(_p(self.pint), _p(self.preal), ctypes.c_int(nstep), ctypes.c_int(self.first_it),
+                                                  _p(self.ro), _p(self.ro_m1), _p(self.ro_p1), _p(self.drodm), _p(self.coe),
+                                                  _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj), _p(self.tk), _p(self.vol),
+                                                  _p(keep) if keep is not None else None, ctypes.c_int(int(rhs_only)),
+                                                  ctypes.c_int(nblk), _p(blk) if nblk else None)
             if rc != 0:
                 raise NotImplementedError("oracle: implicit options outside LU-SGS nb_relax=1 / lu_match=0 / no wall")
             if self.verif:

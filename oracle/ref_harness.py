@@ -468,6 +468,20 @@ class RefSolver:
         L.correct_coins_(_i(nd), _p(p), _p(shift), _p(zn.drodm))
         return shift
 
+    def lu_thread_blocks(self, nd, zn, nthreads):
+        """ind_dm_thread of the nthreads OpenMP threads in zone nd with omp_mode 0 (every zone cut among all the threads,
+        Fast/FastC/FastC/HPC_LAYER/distributeThreads.cpp:90-95): indice_boucle_lu_ of the compiled reference; threads
+        left without cells are dropped."""
+        L = lib()
+        topo = np.ones(3, dtype=np.int32)
+        blocks = []
+        for ith in range(1, int(nthreads) + 1):
+            ind = np.zeros(6, dtype=np.int32)
+            L.indice_boucle_lu_(_i(nd), _i(ith), _i(int(nthreads)), _i(10), _p(zn.ind_dm), _p(topo), _p(ind))
+            if ind[1] >= ind[0] and ind[3] >= ind[2] and ind[5] >= ind[4]:
+                blocks.append(ind)
+        return np.array(blocks, dtype=np.int32)
+
     def _invlu(self, nd, zn, nitrun, nstep, ro_ssiter):
         """Fast/FastS/FastS/Compute/lhs.cpp:135-161.  nb_relax > 1 or lu_match = 1: the increments are built in a work
         array (iptdrodm_out = ssortmp, lhs.cpp:148) next to the accumulator ssor, both dimensioned on the window of
@@ -488,6 +502,20 @@ class RefSolver:
                      _p(zn.coe), _p(zn.ssor), _i(ssor_size))
             return
         dummy = np.zeros(8)
+        if getattr(self, 'lu_threads', 1) > 1:
+            # every thread solves its own block (lhs.cpp:129-161); its LU range takes the ghost layer of a wall face of
+            # the zone where the block touches it (BC/BCzone.cpp:99-127).  The blocks do not read each other's cells,
+            # so one call after the other gives what the threads give.
+            for blk in self.lu_thread_blocks(nd, zn, self.lu_threads):
+                sh = blk.copy()
+                for q in range(6):
+                    if blk[q] == zn.ind_dm[q]:
+                        sh[q] = shift[q]
+                L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(sh), _p(blk), _i(1),
+                         _p(zn.ro_p1), _p(ro_ssiter), _p(zn.drodm), _p(zn.drodm),
+                         _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),
+                         _p(zn.coe), _p(dummy), _i(1))
+            return
         L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(shift), _p(zn.ind_dm), _i(1),
                  _p(zn.ro_p1), _p(ro_ssiter), _p(zn.drodm), _p(zn.drodm),
                  _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),

@@ -15,8 +15,8 @@ for r in c.execute("select name, total_calls, total_duration, average from top_k
 # duration against the number of workgroups of the launch
 import collections
 for key in (sys.argv[2:] or ['k_lu_lower_wave', 'k_lu_upper_wave']):
-    rows2 = [(gx // max(wx, 1) * (gy // max(wy, 1)), (e - s) / 1000.) for n, s, e, gx, gy, wx, wy in
-             c.execute("select name, start, end, grid_x, grid_y, workgroup_x, workgroup_y from kernels order by start") if key in n]
+    rows2 = [(gx // max(wx, 1) * (gy // max(wy, 1)) * max(gz, 1), (e - s) / 1000.) for n, s, e, gx, gy, gz, wx, wy in
+             c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, workgroup_y from kernels order by start") if key in n]
     bins = collections.defaultdict(list)
     for nwg, d in rows2:
         b = 1

@@ -1,0 +1,113 @@
+"""GPU parity of the LU-SGS solve cut in the blocks of the reference's OpenMP threads (fs_zone_set_lu_blocks) against
+the CPU restatement, itself bit-exact against invlu_ of the compiled reference called once per thread block
+(test_lu_thread_blocks.py).  The device advances every block by one hyperplane per launch."""
+import numpy as np
+import pytest
+
+from fast_amd import cases, FastC, Internal, _capi
+import fast_amd.PyTree as FastS
+from oracle import oracle as O
+from common import zone_arrays, rel_err, SINGLE, wall_distance
+
+pytestmark = pytest.mark.gpu
+
+FAR = {f: 'BCFarfield' for f in ('imin', 'imax', 'jmin', 'jmax', 'kmin', 'kmax')}
+
+
+@pytest.fixture
+def threads():
+    """Sets the thread count the host model hands to warmup and restores it."""
+    old = FastC.OMP_NUM_THREADS
+
+    def set_(n):
+        FastC.OMP_NUM_THREADS = n
+    yield set_
+    FastC.OMP_NUM_THREADS = old
+
+
+CASES = [
+    # n, scheme, model, perturb, bcs, ss_iteration, threads, expected blocks
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 3, 4, 4),
+    ((12, 24, 33), 'senseur', 'NSLaminar', 0., None, 3, 6, 6),
+    ((40, 33, 47), 'ausmpred', 'NSLaminar', 0., None, 2, 12, 12),      # blocks of unequal sizes, several chunks
+    ((12, 23, 21), 'roe', 'Euler', 0.15, None, 3, 4, 4),               # curvilinear
+    ((35, 31, 10), 'senseur', 'NSLaminar', 0.15, None, 2, 3, 3),
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 3, 4, 4),
+    ((11, 22, 23), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 3, 4, 4),
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., FAR, 3, 2, 2),
+    ((12, 9, 10), 'ausmpred', 'NSLaminar', 0., None, 3, 8, 1),         # too small to cut: one block
+    ((12, 24, 22), 'ausmpred', 'NSTurbulent', 0., {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 4, 4),
+    ((12, 22, 21), 'roe', 'NSTurbulent', 0.15, None, 3, 4, 4),
+    ((34, 22), 'ausmpred', 'NSLaminar', 0.15, None, 3, 4, 4),          # two-dimensional: cut along j and i
+    ((45, 23), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 6, 6),
+]
+
+
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs,ssit,nthreads,nblocks", CASES)
+def test_block_lusgs_matches_oracle(threads, n, scheme, model, perturb, bcs, ssit, nthreads, nblocks):
+    make = cases.tgv if len(n) == 3 else cases.tgv2d
+    t = make(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': ssit}, bcs=bcs,
+             temporal_scheme='implicit', time_step=0.02, perturb=perturb)
+    threads(nthreads)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    neq = int(pint[36])
+    blocks = FastC.lu_thread_blocks(pint, nthreads)
+    assert len(blocks) == nblocks
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0], wall_distance(z))
+    oz.lu_blocks = blocks
+    oz.fill_ghostcells()
+    assert np.array_equal(FastC.level_buffer(z), oz.ro)
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    ro0 = oz.ro.copy()
+    for it in range(1, 5):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        if neq == 5:
+            assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+        else:    # the device power function of the Spalart-Allmaras source term is not the host's
+            e = rel_err(got, oz.ro, int(pint[41]), neq=6)
+            assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+    assert np.isfinite(got).all() and np.abs(got - ro0).max() > 1e-4
+    if nblocks > 1:
+        # the blocks matter: the single sweep of the zone gives another field
+        one = O.OracleZone(pint, preal, ro0.copy(), metrics[0][0], wall_distance(z))
+        one.ro_m1[:] = one.ro; one.ro_p1[:] = one.ro
+        for it in range(1, 5):
+            one.step()
+        assert not np.array_equal(one.ro, oz.ro)
+
+
+def test_lu_blocks_are_validated():
+    t = cases.tgv((12, 24, 22), 'ausmpred', extra_numz=SINGLE, extra_numb={'ss_iteration': 2},
+                  temporal_scheme='implicit', time_step=0.02)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    lv = [FastC.level_buffer(z, s) for s in ('', '_M1', '_P1')]
+    ctx = _capi.Context(0)
+    ctx.zone_add(pint, preal, lv[0], lv[1], lv[2], metrics[0][0])
+    good = FastC.lu_thread_blocks(pint, 4)
+    ctx.zone_set_lu_blocks(0, good)
+    with pytest.raises(_capi.FastsHipError, match="overlap"):
+        bad = good.copy(); bad[1, 2] -= 1
+        ctx.zone_set_lu_blocks(0, bad)
+    with pytest.raises(_capi.FastsHipError, match="cover"):
+        ctx.zone_set_lu_blocks(0, good[:3])
+    with pytest.raises(_capi.FastsHipError, match="interior"):
+        bad = good.copy(); bad[0, 0] = 0
+        ctx.zone_set_lu_blocks(0, bad)
+    ctx.zone_set_lu_blocks(0, None)          # back to one sweep
+    ctx.close()
+    # relaxations with thread blocks are not built
+    t = cases.tgv((12, 24, 22), 'ausmpred', extra_numz=dict(SINGLE, nb_relax=2), extra_numb={'ss_iteration': 2},
+                  temporal_scheme='implicit', time_step=0.02)
+    old = FastC.OMP_NUM_THREADS
+    FastC.OMP_NUM_THREADS = 4
+    try:
+        with pytest.raises(_capi.FastsHipError, match="nb_relax"):
+            FastS.warmup(t, None)
+    finally:
+        FastC.OMP_NUM_THREADS = old
