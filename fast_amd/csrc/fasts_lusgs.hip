@@ -255,17 +255,22 @@ FS_DEV double lane_next(double x)
   return __hiloint2double(hi, lo);
 }
 
-// Range, hyperplane and first k-plane of a workgroup.  tab != NULL: one range per blockIdx.z -- the blocks that the
+// Range, hyperplane and first k-plane of a workgroup.  MULTI: tab holds one range per blockIdx.z -- the blocks that the
 // reference's OpenMP threads sweep independently of each other (each thread calls invlu on its own range and skips the
-// neighbour terms across its borders, Fast/FastS/FastS/Compute/lhs.cpp:149-161, LU/invlu_l.for:90-215) -- else r0.
-// n numbers the launches of a sweep: the lower sweep of a block runs its hyperplanes upwards from 0, the upper sweep
-// downwards from its last one, so that blocks of different sizes all start at launch 0.  False when the block has no
-// hyperplane for launch n.
-template <int U, bool UPPER>
-FS_DEV bool lu_block(const LuRange &r0, const LuRange *__restrict__ tab, int n, LuRange &r, int &nchunk, int &h, int &kbase)
+// neighbour terms across its borders, Fast/FastS/FastS/Compute/lhs.cpp:149-161, LU/invlu_l.for:90-215) -- and n numbers
+// the launches of a sweep: the lower sweep of a block runs its hyperplanes upwards from 0, the upper sweep downwards
+// from its last one, so that blocks of different sizes all start at launch 0; false when the block has no hyperplane
+// for launch n.  Otherwise (one sweep of the range r0) the host passes the chunk count, the hyperplane and the first
+// k-plane: these launches are bound by their latency, and working the three out here costs them 0.6 us each.
+template <int U, bool UPPER, bool MULTI>
+FS_DEV bool lu_block(const LuRange &r0, const LuRange *__restrict__ tab, int nchunk0, int n, int kbase0, LuRange &r,
+                     int &nchunk, int &h, int &kbase)
 {
-  r = r0;
-  if (tab) r = tab[blockIdx.z];
+  if (!MULTI) {
+    r = r0; nchunk = nchunk0; h = n; kbase = kbase0;
+    return true;
+  }
+  r = tab[blockIdx.z];
   nchunk = (r.i1 - r.i0 + U) / U;
   const int nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
   const int nhc = nchunk + nj + nk - 2;
@@ -276,14 +281,14 @@ FS_DEV bool lu_block(const LuRange &r0, const LuRange *__restrict__ tab, int n, 
   return true;
 }
 
-template <bool FULL, int NE, int U = 8>
-__global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r0, const LuRange *__restrict__ tab, int n,
+template <bool FULL, int NE, int U = 8, bool MULTI = false>
+__global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r0, int nchunk0, int n, int kbase0,
                                                       const double *__restrict__ rop, double *__restrict__ dw,
-                                                      const double *__restrict__ coe)
+                                                      const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
   LuRange r;
   int nchunk, h, kbase;
-  if (!lu_block<U, false>(r0, tab, n, r, nchunk, h, kbase)) return;
+  if (!lu_block<U, false, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
   const int u = threadIdx.x / U, m = threadIdx.x % U;
   // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
   const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
@@ -352,15 +357,15 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
   LUSTAMP(4, true) LUSTAMP(7, false)
 }
 
-template <bool FULL, int NE, int U = 8>
-__global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRange r0, const LuRange *__restrict__ tab, int n,
+template <bool FULL, int NE, int U = 8, bool MULTI = false>
+__global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRange r0, int nchunk0, int n, int kbase0,
                                                       const double *__restrict__ rop, const double *rop_kn,
                                                       double *rop_new, double *__restrict__ dw,
-                                                      const double *__restrict__ coe)
+                                                      const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
   LuRange r;
   int nchunk, h, kbase;
-  if (!lu_block<U, true>(r0, tab, n, r, nchunk, h, kbase)) return;
+  if (!lu_block<U, true, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
   const int u = threadIdx.x / U, m = threadIdx.x % U;
   // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
   const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
@@ -695,8 +700,10 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
   }
   for (int pass = 0; pass < 2; pass++)
     for (int n = 0; n < max_nhc; n++) {
-      // grid of launch n: the widest hyperplane among the blocks that have one
+      // grid of launch n: the widest hyperplane among the blocks that have one.  One sweep of the range (no table):
+      // the launch walks hyperplane h of the range, its chunk count and first k-plane go in as arguments
       unsigned gx = 0, gy = 0;
+      int h1 = 0, nchunk1 = 0, kbase1 = 0;
       for (int b = 0; b < nb; b++) {
         const int *q = br + 6 * b;
         const int bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
@@ -709,16 +716,19 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
         const unsigned x = (unsigned)((nchunk + wpu - 1) / wpu), y = (unsigned)(khi - klo + 1);
         if (x > gx) gx = x;
         if (y > gy) gy = y;
+        h1 = h; nchunk1 = nchunk; kbase1 = q[4] + klo;
       }
       if (!gx || !gy) continue;
       dim3 g(gx, gy, (unsigned)nb);
 #define FS_LOW(F, N)                                                                                                            \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((k_lu_lower_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, tab, n, rop, dw, coe);                             \
+    if (multi) hipLaunchKernelGGL((k_lu_lower_wave<F, N, U, true>), g, dim3(64), 0, s, z, c, r, 0, n, 0, rop, dw, coe, tab);     \
+    else hipLaunchKernelGGL((k_lu_lower_wave<F, N, U, false>), g, dim3(64), 0, s, z, c, r, nchunk1, h1, kbase1, rop, dw, coe, tab); \
   } while (0)
 #define FS_UPP(F, N)                                                                                                            \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((k_lu_upper_wave<F, N, U>), g, dim3(64), 0, s, z, c, r, tab, n, rop, rop_kn, rop_new, dw, coe);            \
+    if (multi) hipLaunchKernelGGL((k_lu_upper_wave<F, N, U, true>), g, dim3(64), 0, s, z, c, r, 0, n, 0, rop, rop_kn, rop_new, dw, coe, tab); \
+    else hipLaunchKernelGGL((k_lu_upper_wave<F, N, U, false>), g, dim3(64), 0, s, z, c, r, nchunk1, h1, kbase1, rop, rop_kn, rop_new, dw, coe, tab); \
   } while (0)
       if (pass == 0) {
         if (sa && full) FS_LOW(true, 6); else if (sa) FS_LOW(false, 6); else if (full) FS_LOW(true, 5); else FS_LOW(false, 5);
