@@ -124,6 +124,7 @@ def main():
                     '2*NFOIL/3 across; Newton sub-iterations from --implicit, default 3); not the headline workload')
     ap.add_argument('--lu-threads', type=int, default=1, metavar='T', help='with --implicit / --naca: LU-SGS solve in the '
                     'blocks of T OpenMP threads of the reference (its result with OMP_NUM_THREADS=T); 1 = one sweep per zone')
+    ap.add_argument('--nb-relax', type=int, default=1, metavar='R', help='with --implicit / --naca: LU-SSOR with R relaxations')
     ap.add_argument('--cfl', type=float, default=1., help='CFL number of the local time step (--naca)')
     ap.add_argument('--channel', type=int, nargs=3, default=None, metavar=('BI', 'BJ', 'BK'), help='one GPU\'s share of a '
                     'multi-block channel: the --cells^3 box cut in BI x 1 x BK curvilinear blocks (BJ must be 1), no-slip '
@@ -156,7 +157,8 @@ def main():
         import fast_amd.pytree_lite as C
         nf, nw, nj = a.naca, a.naca // 3, 2 * a.naca // 3
         a.implicit = a.implicit or 3
-        t = cases.naca_cmesh(nfoil=nf, nwake=nw, nj=nj, scheme=a.scheme, ss_iteration=a.implicit, cfl=a.cfl)
+        t = cases.naca_cmesh(nfoil=nf, nwake=nw, nj=nj, scheme=a.scheme, ss_iteration=a.implicit, cfl=a.cfl,
+                             extra_numz={'nb_relax': a.nb_relax} if a.nb_relax > 1 else None)
         tc = C.node2Center(t)
         rp, dp = connect.cmesh_wake_join(2 * nf + 2 * nw, nj, nw)
         connect.add_joins_to_tc(tc, [(0, 0, rp, dp)], [z[0] for z in Internal.getZones(t)])
@@ -186,6 +188,8 @@ def main():
         kw = {}
         if a.implicit:
             kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': a.implicit}}
+        if a.implicit and a.nb_relax > 1:
+            kw['extra_numz'] = {'nb_relax': a.nb_relax}
         t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n * (10. if a.implicit else 1.),
                       perturb=a.perturb, **kw)
         (t, tc, metrics) = FastS.warmup(t, None, device=local_rank)
@@ -260,6 +264,7 @@ def main():
                        "mesh": "two-dimensional C-mesh" if a.naca else ("curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"),
                        "time_scheme": ("implicit BDF1 local time step, LU-SGS, %d Newton sub-iterations" if a.naca else
                                        "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit +
+                                      (", %d LU-SSOR relaxations" % a.nb_relax if a.nb_relax > 1 else "") +
                                       (", LU-SGS in the blocks of %d threads" % a.lu_threads if a.lu_threads > 1 else "")
                                       if a.implicit else "explicit RK3"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,

@@ -147,8 +147,8 @@ extern "C" int fs_zone_set_lu_blocks(fs_ctx *ctx, int zone, int nblocks, const i
   if (!ctx->implicit) return fail(ctx, FS_ERR_STATE, "fs_zone_set_lu_blocks: the zone does not use the implicit scheme");
   if (nblocks <= 1) { zn.lu_blocks.clear(); return FS_OK; }
   if (nblocks > 4096) return fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: at most 4096 blocks");
-  if (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_set_lu_blocks: thread blocks with nb_relax > 1 or lu_match = 1 are not supported");
+  if (zn.pint[LU_MATCH] != 0)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_set_lu_blocks: thread blocks with lu_match = 1 are not supported");
   // the blocks tile the interior: each inside it, pairwise disjoint, volumes adding up to the zone's
   const int hi[3] = {zn.z.iv, zn.z.jv, zn.z.kv};
   long long cells = 0;
@@ -919,7 +919,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       // ghost cells of match joins first (lhs.cpp:1-15); no sweep reads them (the range grows into ghost cells only
       // over walls, whose BC then overwrites them, and between the thread blocks of a zone): nothing to do here
       const int lrc = (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
-                          ? fsk_lussor(z, zn.lu, sdm, zn.pint[NB_RELAX], zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
+                          ? fsk_lussor(z, zn.lu, sdm, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.pint[NB_RELAX],
+                                       zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
                                        zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
                           : fsk_lusgs(z, zn.lu, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.preal[GAMMA], zn.dev[in],
                                       zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);

@@ -88,8 +88,9 @@ void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, doub
 // range[6] = cells swept (interior, plus one ghost layer on wall faces)
 int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
               const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s);
-int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nb_relax, int overlap, double gamma, const double *rop, double *rop_out,
-               double *scratch, const double *din, double *work, const double *coe, hipStream_t s);
+int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nblocks, const int *blocks, const int *blocks_dev,
+               int nb_relax, int overlap, double gamma, const double *rop, double *rop_out, double *scratch, const double *din,
+               double *work, const double *coe, hipStream_t s);
 
 // roe + walls (fasts_wallflux.hip): correction of the balance on the cells next to one wall window (glo/ghi = its
 // ghost-cell window, tag = BC tag of the reference), then the end of the stage redone from the corrected balance

@@ -454,16 +454,19 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
 // behind the sweep, when every successor of a cell has read its increment: after the sweep is the same).
 // LAST: last upper sweep, followed by the Newton update of the cells inside sdm (mjr_newton.for).
 // ------------------------------------------------------------------------------------------------------
-template <bool FULL, bool FIRSTM, int NE = 5>
-__global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuRange r, int nchunk, int h, int kbase,
+template <bool FULL, bool FIRSTM, int NE = 5, int U = 8, bool MULTI = false>
+__global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuRange r0, int nchunk0, int n, int kbase0,
                                                         const double *__restrict__ rop, const double *__restrict__ din,
                                                         double *__restrict__ dout, double *__restrict__ ssor,
-                                                        const double *__restrict__ coe)
+                                                        const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
-  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
-  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  LuRange r;
+  int nchunk, h, kbase;
+  if (!lu_block<U, false, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
+  const int u = threadIdx.x / U, m = threadIdx.x % U;
+  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
   const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * 8 + m;
+  const int i = r.i0 + cn * U + m;
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
@@ -492,7 +495,7 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
       }
     }
   }
-  for (int st = 0; st < 8; st++) {
+  for (int st = 0; st < U; st++) {
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
@@ -530,23 +533,26 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
 
 // LUD: the upper sweep of LU-SGS with lu_match = 1 (LU/invlu_overlap_u.for): the increment of the lower sweep is
 // multiplied by the diagonal first (lu_d.for), the terms follow in the order i, j, k, no accumulator.
-template <bool FULL, bool LAST, bool LUD = false, int NE = 5>
-__global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuRange r, LuRange sdm, int nchunk, int h, int kbase,
+template <bool FULL, bool LAST, bool LUD = false, int NE = 5, int U = 8, bool MULTI = false>
+__global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuRange r0, LuRange sdm, int nchunk0, int n, int kbase0,
                                                         const double *__restrict__ rop, const double *rop_kn, double *rop_new,
                                                         double *__restrict__ dout, double *__restrict__ ssor,
-                                                        const double *__restrict__ coe)
+                                                        const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
-  const int u = threadIdx.x >> 3, m = threadIdx.x & 7;
-  const int cn = blockIdx.x * 8 + u, k = kbase + blockIdx.y;
+  LuRange r;
+  int nchunk, h, kbase;
+  if (!lu_block<U, true, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
+  const int u = threadIdx.x / U, m = threadIdx.x % U;
+  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
   const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * 8 + m;
+  const int i = r.i0 + cn * U + m;
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
   const bool has_next = active && i < r.i1;
   const bool has_j = active && j < r.j1, has_k = active && k < r.k1;
-  const bool last_of_unit = m == 7 || i == r.i1;
+  const bool last_of_unit = m == U - 1 || i == r.i1;
   double A[NE] = {}, S[NE] = {}, P[NE] = {}, BJ[NE] = {}, BK[NE] = {}, ST[4] = {0., 0., 0., 0.};
   double CR = 0., XAL = 0., DG = 0., C6 = 1.;
   double MI[26] = {};
@@ -576,7 +582,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
       }
     }
   }
-  for (int st = 7; st >= 0; st--) {
+  for (int st = U - 1; st >= 0; st--) {
     double pin[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
@@ -771,8 +777,13 @@ int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks,
 // overlap (nb_relax = 1): LU-SGS as the reference runs it with lu_match = 1 (LU/invlu.for:98-109, invlu_overlap_l.for,
 // invlu_overlap_u.for): one lower and one upper sweep with the neighbour terms in the order i, j, k, the increments
 // in the work array, the Newton update on `sdm`.
-int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax, int overlap, double gamma, const double *rop,
-               double *rop_out, double *scratch, const double *din, double *work, const double *coe, hipStream_t s)
+// nblocks > 1 (not with overlap): the relaxations run block by block as the reference's threads run them, each on work
+// arrays of its own window (Compute/ssor.cpp, LU/prep_lussor.h) -- here the shared arrays, no sweep reading across the
+// borders of its block; see fsk_lusgs.
+template <int U>
+static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int nblocks, const int *blocks, const int *blocks_dev,
+                         int nb_relax, int overlap, double gamma, const double *rop, double *rop_out, double *scratch,
+                         const double *din, double *work, const double *coe, hipStream_t s)
 {
   if ((z.neq != 5 && z.neq != 6) || (overlap ? nb_relax != 1 : nb_relax < 2)) return -1;
   const bool sa = z.neq == 6;
@@ -789,9 +800,19 @@ int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax,
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
   double *dout = work, *ssor = work + (size_t)z.neq * z.nd;
-  const int nchunk = (ni + 7) / 8;
-  const int nhc = nchunk + nj + nk - 2;
-  const unsigned gx8 = (unsigned)((nchunk + 7) / 8);
+  const int wpu = 64 / U;
+  const bool multi = nblocks > 1 && blocks && blocks_dev && !overlap;
+  const int nb = multi ? nblocks : 1;
+  const int *br = multi ? blocks : range;
+  const LuRange *tab = multi ? reinterpret_cast<const LuRange *>(blocks_dev) : nullptr;
+  int max_nhc = 0;
+  for (int b = 0; b < nb; b++) {
+    const int *q = br + 6 * b;
+    const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
+    if (bi < 1 || bj < 1 || bk < 1) return -1;
+    const int nhc = (bi + U - 1) / U + bj + bk - 2;
+    if (nhc > max_nhc) max_nhc = nhc;
+  }
   const dim3 gr((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
   if (inplace) {
     // cells of the range outside sdm keep their state: the copy back below covers the whole range
@@ -800,21 +821,37 @@ int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax,
   for (int m = 1; m <= nb_relax; m++) {
     const bool last = m == nb_relax;
     for (int pass = 0; pass < 2; pass++) {
-      for (int n = 0; n < nhc; n++) {
-        const int h = pass == 0 ? n : nhc - 1 - n;
-        int klo = h - (nchunk - 1) - (nj - 1); if (klo < 0) klo = 0;
-        int khi = h < nk - 1 ? h : nk - 1;
-        dim3 g(gx8, (unsigned)(khi - klo + 1));
-#define FS_LO(F, M1)                                                                                                   \
+      for (int n = 0; n < max_nhc; n++) {
+        unsigned gx = 0, gy = 0;
+        int h1 = 0, nchunk1 = 0, kbase1 = 0;
+        for (int b = 0; b < nb; b++) {
+          const int *q = br + 6 * b;
+          const int bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
+          const int nchunk = (q[1] - q[0] + U) / U;
+          const int nhc = nchunk + bj + bk - 2;
+          const int h = pass == 0 ? n : nhc - 1 - n;
+          if (h < 0 || h >= nhc) continue;
+          int klo = h - (nchunk - 1) - (bj - 1); if (klo < 0) klo = 0;
+          const int khi = h < bk - 1 ? h : bk - 1;
+          const unsigned x = (unsigned)((nchunk + wpu - 1) / wpu), y = (unsigned)(khi - klo + 1);
+          if (x > gx) gx = x;
+          if (y > gy) gy = y;
+          h1 = h; nchunk1 = nchunk; kbase1 = q[4] + klo;
+        }
+        if (!gx || !gy) continue;
+        dim3 g(gx, gy, (unsigned)nb);
+#define FS_LO2(F, M1, N)                                                                                               \
   do {                                                                                                                 \
-    if (sa) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, 6>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, din, dout, ssor, coe); \
-    else hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, 5>), g, dim3(64), 0, s, z, c, r, nchunk, h, r.k0 + klo, rop, din, dout, ssor, coe);    \
+    if (multi) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, N, U, true>), g, dim3(64), 0, s, z, c, r, 0, n, 0, rop, din, dout, ssor, coe, tab); \
+    else hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, N, U, false>), g, dim3(64), 0, s, z, c, r, nchunk1, h1, kbase1, rop, din, dout, ssor, coe, tab); \
   } while (0)
-#define FS_UPX(F, L, D)                                                                                                \
+#define FS_LO(F, M1) do { if (sa) FS_LO2(F, M1, 6); else FS_LO2(F, M1, 5); } while (0)
+#define FS_UPX2(F, L, D, N)                                                                                            \
   do {                                                                                                                 \
-    if (sa) hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, 6>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe); \
-    else hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, 5>), g, dim3(64), 0, s, z, c, r, sdm, nchunk, h, r.k0 + klo, rop, rop_kn, rop_new, dout, ssor, coe);    \
+    if (multi) hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, true>), g, dim3(64), 0, s, z, c, r, sdm, 0, n, 0, rop, rop_kn, rop_new, dout, ssor, coe, tab); \
+    else hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, false>), g, dim3(64), 0, s, z, c, r, sdm, nchunk1, h1, kbase1, rop, rop_kn, rop_new, dout, ssor, coe, tab); \
   } while (0)
+#define FS_UPX(F, L, D) do { if (sa) FS_UPX2(F, L, D, 6); else FS_UPX2(F, L, D, 5); } while (0)
 #define FS_UP(F, L) FS_UPX(F, L, false)
 #define FS_UPD(F) FS_UPX(F, true, true)
         if (overlap) {
@@ -828,13 +865,25 @@ int fsk_lussor(const FsZone &z, const int *range, const int *sdm_, int nb_relax,
           else { if (last) FS_UP(false, true); else FS_UP(false, false); }
         }
 #undef FS_LO
+#undef FS_LO2
 #undef FS_UP
 #undef FS_UPD
 #undef FS_UPX
+#undef FS_UPX2
       }
       if (!overlap && !(last && pass == 1)) hipLaunchKernelGGL(k_ssor_reset, gr, dim3(256), 0, s, z, r, din, dout, ssor);
     }
   }
   if (inplace) hipLaunchKernelGGL(k_copy_range, gr, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
   return 0;
+}
+
+int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nblocks, const int *blocks, const int *blocks_dev,
+               int nb_relax, int overlap, double gamma, const double *rop, double *rop_out, double *scratch, const double *din,
+               double *work, const double *coe, hipStream_t s)
+{
+  // unit length as in fsk_lusgs: 8 cells for one sweep of the zone, 16 with thread blocks
+  if (nblocks > 1 && !overlap)
+    return lussor_sweeps<16>(z, range, sdm, nblocks, blocks, blocks_dev, nb_relax, overlap, gamma, rop, rop_out, scratch, din, work, coe, s);
+  return lussor_sweeps<8>(z, range, sdm, 0, nullptr, nullptr, nb_relax, overlap, gamma, rop, rop_out, scratch, din, work, coe, s);
 }

@@ -112,7 +112,7 @@ int fs_zone_set_distance(fs_ctx *ctx, int zone, const double *dist, int n);
  * host's: results agree with the reference to 1e-12, not bit for bit.  Call before fs_upload. */
 int fs_zone_set_filtered(fs_ctx *ctx, int zone, double *rof, long long n_doubles);
 
-/* Blocks of the LU-SGS solve of a zone (implicit scheme, nb_relax = 1, lu_match = 0).  The reference gives every OpenMP
+/* Blocks of the LU-SGS / LU-SSOR solve of a zone (implicit scheme, lu_match = 0).  The reference gives every OpenMP
  * thread a block of the zone (indice_boucle_lu, Fast/FastC/FastC/HPC_LAYER/indice_boucle_lu.for:94-335: cut along k
  * and j, along j and i on a two-dimensional zone, no block thinner than 10 cells) and each thread runs invlu on its own
  * block, skipping the neighbour terms across its borders (Fast/FastS/FastS/Compute/lhs.cpp:129-161,
@@ -121,8 +121,10 @@ int fs_zone_set_filtered(fs_ctx *ctx, int zone, double *rof, long long n_doubles
  * holds nblocks ranges (imin, imax, jmin, jmax, kmin, kmax; interior cells numbered from 1, as ind_dm_thread of the
  * reference) that tile the interior, and the library gives the result of the reference run with those thread blocks:
  * the blocks are swept side by side, one hyperplane of every block per launch; a block that touches a face of the zone
- * carrying a wall takes the ghost layer there as the reference's test per thread does (BC/BCzone.cpp:99-127).
- * nblocks <= 1 restores the single sweep.  Call before fs_upload. */
+ * carrying a wall takes the ghost layer there as the reference's test per thread does (BC/BCzone.cpp:99-127).  With
+ * nb_relax > 1 every block is relaxed on its own as the threads do on work arrays of their own window
+ * (Compute/ssor.cpp:52-70, LU/prep_lussor.h).  nblocks <= 1 restores the single sweep; refused with lu_match = 1 (there
+ * the reference lets the ranges of the threads overlap, BC/BCzone.cpp:129-149).  Call before fs_upload. */
 int fs_zone_set_lu_blocks(fs_ctx *ctx, int zone, int nblocks, const int32_t *ind_sdm);
 
 /* Match-join ghost transfer tables (one entry per join "rac"): receiver zone, donor zone and

@@ -2742,10 +2742,26 @@ int fo_subiter_implicit_blocks(const i32 *p, const double *pr, int nitcfg, int f
   i32 lu[6];
   if (fo_bczone_rhs(p, drodm, ti, tj, tk, lu)) return -1;
   if (p[NB_RELAX] > 1 || p[LU_MATCH] != 0) {
-    if (nblk > 1) return -1;
+    if (nblk > 1 && p[LU_MATCH] != 0) return -1;
     const size_t n = (size_t)p[NEQ] * p[NDIMDX];
     double *w = (double *)calloc(2 * n, sizeof(double));
     if (!w) return -1;
+    if (nblk > 1 && blk) {
+      /* every thread relaxes its own block on work arrays of its own window (Compute/ssor.cpp:52-70, LU/prep_lussor.h;
+       * window index formule_ssor_param.h) and updates the state of its own cells (ind_loop_sdm = its block): here the
+       * shared arrays, whose cells outside a block its sweeps never read */
+      int rc = 0;
+      for (int b = 0; b < nblk && !rc; b++) {
+        i32 r[6];
+        for (int d = 0; d < 3; d++) {
+          r[2 * d] = blk[6 * b + 2 * d] == sdm[2 * d] ? lu[2 * d] : blk[6 * b + 2 * d];
+          r[2 * d + 1] = blk[6 * b + 2 * d + 1] == sdm[2 * d + 1] ? lu[2 * d + 1] : blk[6 * b + 2 * d + 1];
+        }
+        rc = fo_invlussor(p, pr, r, blk + 6 * b, drodm, w, w + n, rop_ss, ro_p1, ti, tj, tk, coe);
+      }
+      free(w);
+      return rc;
+    }
     const int rc = (p[LU_MATCH] != 0 && p[NB_RELAX] == 1) ? fo_invlu_overlap(p, pr, lu, sdm, drodm, w, rop_ss, ro_p1, ti, tj, tk, coe)
                                     : fo_invlussor(p, pr, lu, sdm, drodm, w, w + n, rop_ss, ro_p1, ti, tj, tk, coe);
     free(w);

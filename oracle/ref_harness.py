@@ -491,6 +491,26 @@ class RefSolver:
         # lu_match = 1: the copy of the residual into the ghost cells of joins (lhs.cpp:1-15) is left out: with one
         # thread per zone no sweep reads them (BC/BCzone.cpp:122-149)
         shift = self._bczone_rhs(nd, zn, nstep)
+        if p[71] > 1 and p[75] == 0 and getattr(self, 'lu_threads', 1) > 1:
+            # every thread relaxes its own block on work arrays of its own window (Compute/ssor.cpp:52-70: the block
+            # with its ghost layers; LU/prep_lussor.h)
+            neq = int(p[36]); f = int(p[NIJK + 3]); fk = int(p[NIJK + 4])
+            if getattr(zn, 'ssor_thread', None) is None:
+                zn.ssor_thread = {}
+            for ib, blk in enumerate(self.lu_thread_blocks(nd, zn, self.lu_threads)):
+                sh = blk.copy()
+                for q in range(6):
+                    if blk[q] == zn.ind_dm[q]:
+                        sh[q] = shift[q]
+                size = int((blk[1] - blk[0] + 1 + 2 * f) * (blk[3] - blk[2] + 1 + 2 * f) * (blk[5] - blk[4] + 1 + 2 * fk))
+                if ib not in zn.ssor_thread:
+                    zn.ssor_thread[ib] = (np.zeros(size * neq), np.zeros(size * neq))
+                ssor, ssortmp = zn.ssor_thread[ib]
+                L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(p), _p(zn.preal), _p(sh), _p(blk), _i(1),
+                         _p(zn.ro_p1), _p(ro_ssiter), _p(zn.drodm), _p(ssortmp),
+                         _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),
+                         _p(zn.coe), _p(ssor), _i(size))
+            return
         if p[71] > 1 or p[75] != 0:
             ssor_size = int(p[NIJK]) * int(p[NIJK + 1]) * int(p[NIJK + 2])
             neq = int(p[36])

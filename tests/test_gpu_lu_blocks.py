@@ -26,7 +26,7 @@ def threads():
 
 
 CASES = [
-    # n, scheme, model, perturb, bcs, ss_iteration, threads, expected blocks
+    # n, scheme, model, perturb, bcs, ss_iteration, threads, expected blocks[, nb_relax]
     ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 3, 4, 4),
     ((12, 24, 33), 'senseur', 'NSLaminar', 0., None, 3, 6, 6),
     ((40, 33, 47), 'ausmpred', 'NSLaminar', 0., None, 2, 12, 12),      # blocks of unequal sizes, several chunks
@@ -40,13 +40,20 @@ CASES = [
     ((12, 22, 21), 'roe', 'NSTurbulent', 0.15, None, 3, 4, 4),
     ((34, 22), 'ausmpred', 'NSLaminar', 0.15, None, 3, 4, 4),          # two-dimensional: cut along j and i
     ((45, 23), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 6, 6),
+    # LU-SSOR relaxations block by block
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 3, 4, 4, 2),
+    ((40, 33, 47), 'senseur', 'NSLaminar', 0., None, 2, 12, 12, 2),
+    ((12, 23, 21), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 3, 4, 4, 3),
+    ((12, 24, 22), 'roe', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 4, 4, 2),
+    ((45, 23), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 6, 6, 2),
 ]
+CASES = [c if len(c) == 9 else c + (1,) for c in CASES]
 
 
-@pytest.mark.parametrize("n,scheme,model,perturb,bcs,ssit,nthreads,nblocks", CASES)
-def test_block_lusgs_matches_oracle(threads, n, scheme, model, perturb, bcs, ssit, nthreads, nblocks):
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs,ssit,nthreads,nblocks,nb_relax", CASES)
+def test_block_lusgs_matches_oracle(threads, n, scheme, model, perturb, bcs, ssit, nthreads, nblocks, nb_relax):
     make = cases.tgv if len(n) == 3 else cases.tgv2d
-    t = make(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': ssit}, bcs=bcs,
+    t = make(n, scheme, model=model, extra_numz=dict(SINGLE, nb_relax=nb_relax), extra_numb={'ss_iteration': ssit}, bcs=bcs,
              temporal_scheme='implicit', time_step=0.02, perturb=perturb)
     threads(nthreads)
     (t, tc, metrics) = FastS.warmup(t, None)
@@ -101,13 +108,13 @@ def test_lu_blocks_are_validated():
         ctx.zone_set_lu_blocks(0, bad)
     ctx.zone_set_lu_blocks(0, None)          # back to one sweep
     ctx.close()
-    # relaxations with thread blocks are not built
-    t = cases.tgv((12, 24, 22), 'ausmpred', extra_numz=dict(SINGLE, nb_relax=2), extra_numb={'ss_iteration': 2},
+    # lu_match = 1 with thread blocks is not built
+    t = cases.tgv((12, 24, 22), 'ausmpred', extra_numz=dict(SINGLE, lu_match=1), extra_numb={'ss_iteration': 2},
                   temporal_scheme='implicit', time_step=0.02)
     old = FastC.OMP_NUM_THREADS
     FastC.OMP_NUM_THREADS = 4
     try:
-        with pytest.raises(_capi.FastsHipError, match="nb_relax"):
+        with pytest.raises(_capi.FastsHipError, match="lu_match"):
             FastS.warmup(t, None)
     finally:
         FastC.OMP_NUM_THREADS = old

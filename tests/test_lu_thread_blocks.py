@@ -74,24 +74,30 @@ def _pair(t):
 
 @pytest.mark.ref
 @pytest.mark.skipif(not R.available(), reason="compiled reference not built")
-@pytest.mark.parametrize("n,scheme,model,perturb,bcs,threads", [
-    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 4),
-    ((12, 24, 33), 'senseur', 'NSLaminar', 0., None, 6),
-    ((12, 23, 21), 'roe', 'Euler', 0.15, None, 4),
-    ((12, 31, 10), 'senseur', 'NSLaminar', 0.15, None, 3),
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs,threads,nb_relax", [
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 4, 1),
+    ((12, 24, 33), 'senseur', 'NSLaminar', 0., None, 6, 1),
+    ((12, 23, 21), 'roe', 'Euler', 0.15, None, 4, 1),
+    ((12, 31, 10), 'senseur', 'NSLaminar', 0.15, None, 3, 1),
     # walls: a block that touches the wall face takes its ghost layer
-    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 4),
-    ((11, 22, 23), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 4),
-    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., FAR, 2),
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWallViscous'}, 4, 1),
+    ((11, 22, 23), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 4, 1),
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., FAR, 2, 1),
     # Spalart-Allmaras (6 equations), Cartesian and curvilinear
-    ((12, 24, 22), 'ausmpred', 'NSTurbulent', 0., {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 4),
-    ((12, 22, 21), 'roe', 'NSTurbulent', 0.15, None, 4),
+    ((12, 24, 22), 'ausmpred', 'NSTurbulent', 0., {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 4, 1),
+    ((12, 22, 21), 'roe', 'NSTurbulent', 0.15, None, 4, 1),
     # two-dimensional zones: cut along j and i
-    ((34, 22), 'ausmpred', 'NSLaminar', 0.15, None, 4),
-    ((45, 23), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 6),
+    ((34, 22), 'ausmpred', 'NSLaminar', 0.15, None, 4, 1),
+    ((45, 23), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 6, 1),
+    # LU-SSOR relaxations, every thread on work arrays of its own window
+    ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 4, 2),
+    ((12, 23, 21), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 4, 3),
+    ((12, 24, 22), 'roe', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 4, 2),
+    ((45, 23), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 6, 2),
 ])
-def test_block_lusgs_bit_exact(n, scheme, model, perturb, bcs, threads):
+def test_block_lusgs_bit_exact(n, scheme, model, perturb, bcs, threads, nb_relax):
     make = cases.tgv if len(n) == 3 else cases.tgv2d
+    SINGLE = dict(globals()['SINGLE'], nb_relax=nb_relax)
     t = make(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': 3}, bcs=bcs,
              temporal_scheme='implicit', time_step=0.02, perturb=perturb)
     so, sr = _pair(t)
