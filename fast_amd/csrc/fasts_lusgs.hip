@@ -255,6 +255,40 @@ FS_DEV double lane_next(double x)
   return __hiloint2double(hi, lo);
 }
 
+// Units on 128-byte lines.  A unit of 16 cells is one line of every array when it starts on a multiple of 16 cells in
+// memory, and straddles two otherwise (the sweeps of the blocks are bound by memory: FETCH_SIZE was 1.9 x the bytes they
+// use).  The i-lines of a zone start p0 + a (j - j0) + b (k - k0) cells after such a multiple, modulo U (a, b: the row
+// and plane strides modulo U).  Shifting the units of line (j, k) down by that many cells -- without the modulo, so
+// that the shift never decreases from a line to the next -- puts every unit on a line and keeps the order of the
+// hyperplanes: the j - 1 and k - 1 neighbours of the cells of unit cn then sit in units cn - 1 or cn of their lines,
+// never cn + 1.  The price is (p0 + a (nj - 1) + b (nk - 1)) / U more chunk columns, i.e. hyperplanes.  Measured
+// (ms per implicit step, 3 Newton sub-iterations, shift off / on): 252^3 in 64 blocks, a = b = 0, no extra hyperplane:
+// 17.0 / 13.6; 256^3 (a = 4) in 128 blocks, 12 % more hyperplanes: 16.9 / 15.7; in 64 blocks, 17 %: 17.0 / 16.7; in 16
+// blocks, 22 %: 23.5 / 25.4; two-dimensional 1024 x 256 zone (small launches, bound by latency) in 200 blocks, 11 %:
+// 1.44 / 1.65.  So enable = 1 shifts when no hyperplane is added, or at most a tenth on a three-dimensional zone;
+// enable = 2 whenever the stride between variables keeps the alignment (tests of the general case).
+// All zero: units start at the first cell of the range.
+struct LuSkew { int p0, a, b; };
+// chunk columns of a block with its skew
+template <int U>
+__host__ __device__ inline int lu_nchunk(const LuSkew &s, int ni, int nj, int nk)
+{
+  return (ni + s.p0 + s.a * (nj - 1) + s.b * (nk - 1) + U - 1) / U;
+}
+template <int U>
+__host__ __device__ inline LuSkew lu_skew(const FsZone &z, int i0, int i1, int j0, int j1, int k0, int k1, int enable)
+{
+  LuSkew s = {0, 0, 0};
+  if (!enable || z.nd % U != 0) return s;
+  const int a = (int)(z.incj % U), b = (int)(z.inck % U);
+  const int p0 = ((i0 + z.ific - 1) + (j0 + z.ific - 1) * a + (k0 + z.ifick - 1) * b) % U;
+  const int nj = j1 - j0 + 1, nk = k1 - k0 + 1;
+  const int extra = lu_nchunk<U>(LuSkew{p0, a, b}, i1 - i0 + 1, nj, nk) - (i1 - i0 + U) / U;
+  if (enable == 1 && extra > 0 && (z.nk == 1 || 10 * extra > (i1 - i0 + U) / U + nj + nk - 2)) return s;
+  s.p0 = p0; s.a = a; s.b = b;
+  return s;
+}
+
 // Range, hyperplane and first k-plane of a workgroup.  MULTI: tab holds one range per blockIdx.z -- the blocks that the
 // reference's OpenMP threads sweep independently of each other (each thread calls invlu on its own range and skips the
 // neighbour terms across its borders, Fast/FastS/FastS/Compute/lhs.cpp:149-161, LU/invlu_l.for:90-215) -- and n numbers
@@ -263,16 +297,17 @@ FS_DEV double lane_next(double x)
 // for launch n.  Otherwise (one sweep of the range r0) the host passes the chunk count, the hyperplane and the first
 // k-plane: these launches are bound by their latency, and working the three out here costs them 0.6 us each.
 template <int U, bool UPPER, bool MULTI>
-FS_DEV bool lu_block(const LuRange &r0, const LuRange *__restrict__ tab, int nchunk0, int n, int kbase0, LuRange &r,
-                     int &nchunk, int &h, int &kbase)
+FS_DEV bool lu_block(const FsZone &z, const LuRange &r0, const LuRange *__restrict__ tab, int nchunk0, int n, int kbase0,
+                     LuRange &r, LuSkew &sk, int &nchunk, int &h, int &kbase)
 {
   if (!MULTI) {
-    r = r0; nchunk = nchunk0; h = n; kbase = kbase0;
+    r = r0; sk.p0 = 0; sk.a = 0; sk.b = 0; nchunk = nchunk0; h = n; kbase = kbase0;
     return true;
   }
   r = tab[blockIdx.z];
-  nchunk = (r.i1 - r.i0 + U) / U;
   const int nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
+  sk = lu_skew<U>(z, r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, nchunk0);   // with a block table the chunk-count argument carries the switch
+  nchunk = lu_nchunk<U>(sk, r.i1 - r.i0 + 1, nj, nk);
   const int nhc = nchunk + nj + nk - 2;
   h = UPPER ? nhc - 1 - n : n;
   if (h < 0 || h >= nhc) return false;
@@ -281,20 +316,41 @@ FS_DEV bool lu_block(const LuRange &r0, const LuRange *__restrict__ tab, int nch
   return true;
 }
 
+// Unit and cell of a lane: chunk column cn, line j and cell i of hyperplane h in plane k.  With a skew the chunk columns
+// of a plane that hold cells of the hyperplane start at cn_min (those before it lie left of the range or past its
+// last line); without, at 0.
+template <int U, bool MULTI>
+FS_DEV void lu_lane(const LuRange &r, const LuSkew &sk, int h, int k, int &cn, int &j, int &i, int &m)
+{
+  const int u = threadIdx.x / U;
+  m = threadIdx.x % U;
+  const int kp = k - r.k0;
+  int cn_min = 0;
+  if (MULTI) {
+    const int t = sk.p0 + sk.a * (h - kp) + sk.b * kp - U + 1;      // cn (U + a) >= t: the unit reaches the first cell
+    if (t > 0) cn_min = (t + U + sk.a - 1) / (U + sk.a);
+    const int cj = h - kp - (r.j1 - r.j0);                          // cn >= cj: line j <= j1
+    if (cj > cn_min) cn_min = cj;
+  }
+  cn = cn_min + blockIdx.x * (64 / U) + u;
+  j = r.j0 + h - cn - kp;
+  i = r.i0 - (sk.p0 + sk.a * (j - r.j0) + sk.b * kp) + cn * U + m;
+}
+
 template <bool FULL, int NE, int U = 8, bool MULTI = false>
 __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRange r0, int nchunk0, int n, int kbase0,
                                                       const double *__restrict__ rop, double *__restrict__ dw,
                                                       const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
   LuRange r;
+  LuSkew sk;
   int nchunk, h, kbase;
-  if (!lu_block<U, false, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
-  const int u = threadIdx.x / U, m = threadIdx.x % U;
-  // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
-  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
-  const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * U + m;
-  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
+  if (!lu_block<U, false, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
+  const int k = kbase + blockIdx.y;
+  int cn, j, i, m;
+  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
@@ -364,14 +420,14 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
                                                       const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
   LuRange r;
+  LuSkew sk;
   int nchunk, h, kbase;
-  if (!lu_block<U, true, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
-  const int u = threadIdx.x / U, m = threadIdx.x % U;
-  // units of a wave: the same k-plane, 8 consecutive chunks of the hyperplane (so 8 consecutive j-lines, descending)
-  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
-  const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * U + m;
-  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
+  if (!lu_block<U, true, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
+  const int k = kbase + blockIdx.y;
+  int cn, j, i, m;
+  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
@@ -461,13 +517,14 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
                                                         const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
   LuRange r;
+  LuSkew sk;
   int nchunk, h, kbase;
-  if (!lu_block<U, false, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
-  const int u = threadIdx.x / U, m = threadIdx.x % U;
-  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
-  const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * U + m;
-  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
+  if (!lu_block<U, false, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
+  const int k = kbase + blockIdx.y;
+  int cn, j, i, m;
+  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
@@ -540,13 +597,14 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
                                                         const double *__restrict__ coe, const LuRange *__restrict__ tab)
 {
   LuRange r;
+  LuSkew sk;
   int nchunk, h, kbase;
-  if (!lu_block<U, true, MULTI>(r0, tab, nchunk0, n, kbase0, r, nchunk, h, kbase)) return;
-  const int u = threadIdx.x / U, m = threadIdx.x % U;
-  const int cn = blockIdx.x * (64 / U) + u, k = kbase + blockIdx.y;
-  const int j = r.j0 + h - cn - (k - r.k0);
-  const int i = r.i0 + cn * U + m;
-  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i <= r.i1;
+  if (!lu_block<U, true, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
+  const int k = kbase + blockIdx.y;
+  int cn, j, i, m;
+  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
   const long long lt = FULL ? (active ? lmtr(z, i, j, k) : lmtr(z, r.i0, r.j0, r.k0)) : 0;
@@ -692,6 +750,8 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
   const double *rop_kn = inplace ? scratch : rop;
   const bool sa = z.neq == 6;
   const int wpu = 64 / U;
+  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");      // 0 off, 1 where it pays (default), 2 wherever possible
+  const int align = align_env ? atoi(align_env) : 1;
   const bool multi = nblocks > 1 && blocks && blocks_dev;
   const int nb = multi ? nblocks : 1;
   const int *br = multi ? blocks : range;
@@ -701,7 +761,8 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
     const int *q = br + 6 * b;
     const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
     if (bi < 1 || bj < 1 || bk < 1) return -1;
-    const int nhc = (bi + U - 1) / U + bj + bk - 2;
+    const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+    const int nhc = lu_nchunk<U>(sk, bi, bj, bk) + bj + bk - 2;
     if (nhc > max_nhc) max_nhc = nhc;
   }
   for (int pass = 0; pass < 2; pass++)
@@ -712,14 +773,17 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
       int h1 = 0, nchunk1 = 0, kbase1 = 0;
       for (int b = 0; b < nb; b++) {
         const int *q = br + 6 * b;
-        const int bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
-        const int nchunk = (q[1] - q[0] + U) / U;
+        const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
+        const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+        const int nchunk = lu_nchunk<U>(sk, bi, bj, bk);
         const int nhc = nchunk + bj + bk - 2;
         const int h = pass == 0 ? n : nhc - 1 - n;
         if (h < 0 || h >= nhc) continue;
         int klo = h - (nchunk - 1) - (bj - 1); if (klo < 0) klo = 0;
         const int khi = h < bk - 1 ? h : bk - 1;
-        const unsigned x = (unsigned)((nchunk + wpu - 1) / wpu), y = (unsigned)(khi - klo + 1);
+        // chunk columns of one plane that can hold cells of a hyperplane (the kernel starts at the first of them)
+        int width = (bi + U - 2) / (U + sk.a) + 2; if (width > nchunk) width = nchunk;
+        const unsigned x = (unsigned)((width + wpu - 1) / wpu), y = (unsigned)(khi - klo + 1);
         if (x > gx) gx = x;
         if (y > gy) gy = y;
         h1 = h; nchunk1 = nchunk; kbase1 = q[4] + klo;
@@ -728,12 +792,12 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
       dim3 g(gx, gy, (unsigned)nb);
 #define FS_LOW(F, N)                                                                                                            \
   do {                                                                                                                          \
-    if (multi) hipLaunchKernelGGL((k_lu_lower_wave<F, N, U, true>), g, dim3(64), 0, s, z, c, r, 0, n, 0, rop, dw, coe, tab);     \
+    if (multi) hipLaunchKernelGGL((k_lu_lower_wave<F, N, U, true>), g, dim3(64), 0, s, z, c, r, align, n, 0, rop, dw, coe, tab);     \
     else hipLaunchKernelGGL((k_lu_lower_wave<F, N, U, false>), g, dim3(64), 0, s, z, c, r, nchunk1, h1, kbase1, rop, dw, coe, tab); \
   } while (0)
 #define FS_UPP(F, N)                                                                                                            \
   do {                                                                                                                          \
-    if (multi) hipLaunchKernelGGL((k_lu_upper_wave<F, N, U, true>), g, dim3(64), 0, s, z, c, r, 0, n, 0, rop, rop_kn, rop_new, dw, coe, tab); \
+    if (multi) hipLaunchKernelGGL((k_lu_upper_wave<F, N, U, true>), g, dim3(64), 0, s, z, c, r, align, n, 0, rop, rop_kn, rop_new, dw, coe, tab); \
     else hipLaunchKernelGGL((k_lu_upper_wave<F, N, U, false>), g, dim3(64), 0, s, z, c, r, nchunk1, h1, kbase1, rop, rop_kn, rop_new, dw, coe, tab); \
   } while (0)
       if (pass == 0) {
@@ -801,6 +865,8 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
   const double *rop_kn = inplace ? scratch : rop;
   double *dout = work, *ssor = work + (size_t)z.neq * z.nd;
   const int wpu = 64 / U;
+  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");      // 0 off, 1 where it pays (default), 2 wherever possible
+  const int align = align_env ? atoi(align_env) : 1;
   const bool multi = nblocks > 1 && blocks && blocks_dev && !overlap;
   const int nb = multi ? nblocks : 1;
   const int *br = multi ? blocks : range;
@@ -810,7 +876,8 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
     const int *q = br + 6 * b;
     const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
     if (bi < 1 || bj < 1 || bk < 1) return -1;
-    const int nhc = (bi + U - 1) / U + bj + bk - 2;
+    const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+    const int nhc = lu_nchunk<U>(sk, bi, bj, bk) + bj + bk - 2;
     if (nhc > max_nhc) max_nhc = nhc;
   }
   const dim3 gr((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
@@ -826,14 +893,16 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
         int h1 = 0, nchunk1 = 0, kbase1 = 0;
         for (int b = 0; b < nb; b++) {
           const int *q = br + 6 * b;
-          const int bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
-          const int nchunk = (q[1] - q[0] + U) / U;
+          const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
+          const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+          const int nchunk = lu_nchunk<U>(sk, bi, bj, bk);
           const int nhc = nchunk + bj + bk - 2;
           const int h = pass == 0 ? n : nhc - 1 - n;
           if (h < 0 || h >= nhc) continue;
           int klo = h - (nchunk - 1) - (bj - 1); if (klo < 0) klo = 0;
           const int khi = h < bk - 1 ? h : bk - 1;
-          const unsigned x = (unsigned)((nchunk + wpu - 1) / wpu), y = (unsigned)(khi - klo + 1);
+          int width = (bi + U - 2) / (U + sk.a) + 2; if (width > nchunk) width = nchunk;
+          const unsigned x = (unsigned)((width + wpu - 1) / wpu), y = (unsigned)(khi - klo + 1);
           if (x > gx) gx = x;
           if (y > gy) gy = y;
           h1 = h; nchunk1 = nchunk; kbase1 = q[4] + klo;
@@ -842,13 +911,13 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
         dim3 g(gx, gy, (unsigned)nb);
 #define FS_LO2(F, M1, N)                                                                                               \
   do {                                                                                                                 \
-    if (multi) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, N, U, true>), g, dim3(64), 0, s, z, c, r, 0, n, 0, rop, din, dout, ssor, coe, tab); \
+    if (multi) hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, N, U, true>), g, dim3(64), 0, s, z, c, r, align, n, 0, rop, din, dout, ssor, coe, tab); \
     else hipLaunchKernelGGL((k_ssor_lower_wave<F, M1, N, U, false>), g, dim3(64), 0, s, z, c, r, nchunk1, h1, kbase1, rop, din, dout, ssor, coe, tab); \
   } while (0)
 #define FS_LO(F, M1) do { if (sa) FS_LO2(F, M1, 6); else FS_LO2(F, M1, 5); } while (0)
 #define FS_UPX2(F, L, D, N)                                                                                            \
   do {                                                                                                                 \
-    if (multi) hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, true>), g, dim3(64), 0, s, z, c, r, sdm, 0, n, 0, rop, rop_kn, rop_new, dout, ssor, coe, tab); \
+    if (multi) hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, true>), g, dim3(64), 0, s, z, c, r, sdm, align, n, 0, rop, rop_kn, rop_new, dout, ssor, coe, tab); \
     else hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, false>), g, dim3(64), 0, s, z, c, r, sdm, nchunk1, h1, kbase1, rop, rop_kn, rop_new, dout, ssor, coe, tab); \
   } while (0)
 #define FS_UPX(F, L, D) do { if (sa) FS_UPX2(F, L, D, 6); else FS_UPX2(F, L, D, 5); } while (0)

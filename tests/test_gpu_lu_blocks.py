@@ -40,6 +40,20 @@ CASES = [
     ((12, 22, 21), 'roe', 'NSTurbulent', 0.15, None, 3, 4, 4),
     ((34, 22), 'ausmpred', 'NSLaminar', 0.15, None, 3, 4, 4),          # two-dimensional: cut along j and i
     ((45, 23), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 6, 6),
+    # rows that start on 128-byte lines (padded row length a multiple of 16 cells): units shifted onto the lines
+    ((28, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 3, 4, 4),
+    ((44, 33, 22), 'senseur', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 2, 6, 6),
+    ((28, 24, 22), 'ausmpred', 'NSLaminar', 0., {'imin': 'BCWall', 'imax': 'BCWall'}, 3, 4, 4),
+    ((60, 44), 'roe', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 8, 8),
+    ((28, 24, 22), 'senseur', 'NSLaminar', 0., None, 3, 4, 4, 2),
+    # rows that start 4, 8 or 12 cells into a line, line after line: units shifted by a growing number of cells
+    ((24, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 3, 4, 4),
+    ((32, 24, 22), 'senseur', 'NSLaminar', 0., {'jmin': 'BCWall', 'kmin': 'BCWall', 'imax': 'BCFarfield'}, 3, 4, 4),
+    ((16, 22, 22), 'roe', 'NSLaminar', 0.15, None, 3, 4, 4),
+    ((64, 24, 33), 'ausmpred', 'NSLaminar', 0., {'imin': 'BCWall', 'imax': 'BCWall'}, 2, 6, 6),
+    ((48, 44), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 4, 4),
+    ((24, 24, 22), 'senseur', 'NSLaminar', 0., None, 3, 4, 4, 2),
+    ((32, 24, 22), 'ausmpred', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 4, 4, 2),
     # LU-SSOR relaxations block by block
     ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 3, 4, 4, 2),
     ((40, 33, 47), 'senseur', 'NSLaminar', 0., None, 2, 12, 12, 2),
@@ -50,8 +64,12 @@ CASES = [
 CASES = [c if len(c) == 9 else c + (1,) for c in CASES]
 
 
+@pytest.mark.parametrize("align", [1, 2])
 @pytest.mark.parametrize("n,scheme,model,perturb,bcs,ssit,nthreads,nblocks,nb_relax", CASES)
-def test_block_lusgs_matches_oracle(threads, n, scheme, model, perturb, bcs, ssit, nthreads, nblocks, nb_relax):
+def test_block_lusgs_matches_oracle(threads, monkeypatch, n, scheme, model, perturb, bcs, ssit, nthreads, nblocks, nb_relax, align):
+    """align: 1 = units shifted onto 128-byte lines where the library finds it pays, 2 = wherever the layout allows
+    (the general case, with a shift that grows from line to line)."""
+    monkeypatch.setenv('FASTS_HIP_LU_ALIGN', str(align))
     make = cases.tgv if len(n) == 3 else cases.tgv2d
     t = make(n, scheme, model=model, extra_numz=dict(SINGLE, nb_relax=nb_relax), extra_numb={'ss_iteration': ssit}, bcs=bcs,
              temporal_scheme='implicit', time_step=0.02, perturb=perturb)
