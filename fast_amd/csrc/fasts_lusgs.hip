@@ -506,8 +506,10 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
 // and sweep the neighbour terms are added in the order i, j, k to the increment (din = right-hand side, kept; dout
 // = increments) and to the accumulator ssor (mjr_drodm_IO_ssor.for, mjr_drodm_ssor.for), then the increment is
 // divided by the diagonal (lu_dinv.for).  FIRSTM: first lower sweep, the increment starts from din.  Between two
-// sweeps k_ssor_reset puts din + ssor into dout and zeroes ssor (mjr_ssor.for; the reference does it one plane
-// behind the sweep, when every successor of a cell has read its increment: after the sweep is the same).
+// sweeps the reference puts din + ssor into the increment and zeroes ssor (mjr_ssor.for, one plane behind the sweep,
+// when every successor of a cell has read its increment); a sweep reads the increments of cells it has already
+// visited only, so here the next sweep forms din + ssor when it reaches the cell and starts its accumulator at zero:
+// the same sums, without a pass over the zone between two sweeps (0.6 ms each at 256^3).
 // LAST: last upper sweep, followed by the Newton update of the cells inside sdm (mjr_newton.for).
 // ------------------------------------------------------------------------------------------------------
 template <bool FULL, bool FIRSTM, int NE = 5, int U = 8, bool MULTI = false>
@@ -537,7 +539,9 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
     XAL = coe[l] * 0.5;
     double b[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) { A[e] = FIRSTM ? din[l + e * nd] : dout[l + e * nd]; S[e] = FIRSTM ? 0. : ssor[l + e * nd]; }
+    // later sweeps start from the right-hand side plus what the previous sweep accumulated, with an empty accumulator
+    // (mjr_ssor.for, which the reference applies one plane behind the previous sweep; nothing reads a cell in between)
+    for (int e = 0; e < NE; e++) { A[e] = FIRSTM ? din[l + e * nd] : din[l + e * nd] + ssor[l + e * nd]; S[e] = 0.; }
     if (has_j) { lu_neighbour<FULL, 1, 1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BJ[e] = b[e] * XAL; }
     if (has_k) { lu_neighbour<FULL, 2, 1, NE>(z, c, l, lt, rop, dout, coe, b); for (int e = 0; e < NE; e++) BK[e] = b[e] * XAL; }
     DG = 1. / coe[l + 4 * nd];
@@ -593,8 +597,9 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
 template <bool FULL, bool LAST, bool LUD = false, int NE = 5, int U = 8, bool MULTI = false>
 __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuRange r0, LuRange sdm, int nchunk0, int n, int kbase0,
                                                         const double *__restrict__ rop, const double *rop_kn, double *rop_new,
-                                                        double *__restrict__ dout, double *__restrict__ ssor,
-                                                        const double *__restrict__ coe, const LuRange *__restrict__ tab)
+                                                        const double *__restrict__ din, double *__restrict__ dout,
+                                                        double *__restrict__ ssor, const double *__restrict__ coe,
+                                                        const LuRange *__restrict__ tab)
 {
   LuRange r;
   LuSkew sk;
@@ -619,7 +624,7 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
     XAL = coe[l] * -0.5;
     double b[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) { A[e] = dout[l + e * nd]; S[e] = LUD ? 0. : ssor[l + e * nd]; q[e] = rop[l + e * nd]; }
+    for (int e = 0; e < NE; e++) { A[e] = LUD ? dout[l + e * nd] : din[l + e * nd] + ssor[l + e * nd]; S[e] = 0.; q[e] = rop[l + e * nd]; }
     if (NE == 6) C6 = coe[l + 5 * nd];
     if (LUD) {
       const double c5 = coe[l + 4 * nd];
@@ -690,15 +695,6 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
       }
     }
   }
-}
-
-__global__ void __launch_bounds__(256) k_ssor_reset(FsZone z, LuRange r, const double *__restrict__ din,
-                                                    double *__restrict__ dout, double *__restrict__ ssor)
-{
-  const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x, j = r.j0 + blockIdx.y, k = r.k0 + blockIdx.z;
-  if (i > r.i1) return;
-  const long long l = lcell(z, i, j, k);
-  for (int e = 0; e < z.neq; e++) { dout[l + e * z.nd] = din[l + e * z.nd] + ssor[l + e * z.nd]; ssor[l + e * z.nd] = 0.; }
 }
 
 __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const double *__restrict__ src,
@@ -917,8 +913,8 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
 #define FS_LO(F, M1) do { if (sa) FS_LO2(F, M1, 6); else FS_LO2(F, M1, 5); } while (0)
 #define FS_UPX2(F, L, D, N)                                                                                            \
   do {                                                                                                                 \
-    if (multi) hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, true>), g, dim3(64), 0, s, z, c, r, sdm, align, n, 0, rop, rop_kn, rop_new, dout, ssor, coe, tab); \
-    else hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, false>), g, dim3(64), 0, s, z, c, r, sdm, nchunk1, h1, kbase1, rop, rop_kn, rop_new, dout, ssor, coe, tab); \
+    if (multi) hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, true>), g, dim3(64), 0, s, z, c, r, sdm, align, n, 0, rop, rop_kn, rop_new, din, dout, ssor, coe, tab); \
+    else hipLaunchKernelGGL((k_ssor_upper_wave<F, L, D, N, U, false>), g, dim3(64), 0, s, z, c, r, sdm, nchunk1, h1, kbase1, rop, rop_kn, rop_new, din, dout, ssor, coe, tab); \
   } while (0)
 #define FS_UPX(F, L, D) do { if (sa) FS_UPX2(F, L, D, 6); else FS_UPX2(F, L, D, 5); } while (0)
 #define FS_UP(F, L) FS_UPX(F, L, false)
@@ -940,7 +936,6 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
 #undef FS_UPX
 #undef FS_UPX2
       }
-      if (!overlap && !(last && pass == 1)) hipLaunchKernelGGL(k_ssor_reset, gr, dim3(256), 0, s, z, r, din, dout, ssor);
     }
   }
   if (inplace) hipLaunchKernelGGL(k_copy_range, gr, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
