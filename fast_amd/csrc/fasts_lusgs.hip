@@ -821,14 +821,7 @@ int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks,
   // a launch carries a hyperplane of every block and is bound by memory instead: a unit of 16 cells is a whole
   // 128-byte line of every array where 8 cells use half of each line they touch (256^3 in the blocks of 64 threads:
   // 23.4 ms per step with U = 8, 17.2 ms with U = 16; NACA0012 in 24 blocks 5.6 / 4.1 ms).
-  // FASTS_HIP_LU_UNIT = 8 | 16 overrides the choice (measurements).
-  static int unit = -1;
-  if (unit < 0) {
-    const char *ev = getenv("FASTS_HIP_LU_UNIT");
-    unit = ev ? atoi(ev) : 0;
-  }
-  const int u = unit ? unit : (nblocks > 1 ? 16 : 8);
-  if (u == 16) return lusgs_sweeps<16>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s);
+  if (nblocks > 1) return lusgs_sweeps<16>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s);
   return lusgs_sweeps<8>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s);
 }
 

@@ -5,7 +5,6 @@ set -e
 T=${1:-64}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/lu_trace_T$T
-export FASTS_HIP_LU_UNIT=${UNIT:-0}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/prof -o tr -- python3 $R/bench.py --no-cpu --implicit 3 --steps 2 --warmup 1 --lu-threads $T > $O/bench.json 2> $O/prof.log
