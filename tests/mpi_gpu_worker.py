@@ -5,7 +5,7 @@ the split native calls.  The blocks are dealt to the ranks in consecutive runs (
 per rank: local joins next to messages).  Each rank compares its blocks with a serial run of
 the whole job by the CPU restatement.
 
-    python mpi_gpu_worker.py <bi> <bj> <bk> <n> <nsteps> [explicit|implicit|curvilinear|sa|walls|walls_implicit]
+    python mpi_gpu_worker.py <bi> <bj> <bk> <n> <nsteps> [explicit|implicit|implicit_threads|curvilinear|sa|walls|walls_implicit]
 """
 import os
 import sys
@@ -34,8 +34,12 @@ def main():
     mode = sys.argv[6] if len(sys.argv) > 6 else 'explicit'
     nn = tuple(n * b for b in blocks)
     opts = {'time_step': 0.003 * 32. / max(nn)}
-    if mode == 'implicit':      # BDF + LU-SGS, the Newton iterates cross the rank boundary every sub-iteration
+    threads = 1
+    if mode in ('implicit', 'implicit_threads'):   # BDF + LU-SGS, the Newton iterates cross the rank boundary every sub-iteration
         opts = {'time_step': 0.02, 'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': 3}}
+        if mode == 'implicit_threads':             # LU-SGS solve of every block in the blocks of 4 threads of the reference
+            threads = 4
+            FastC.OMP_NUM_THREADS = threads
     elif mode == 'curvilinear':
         opts['perturb'] = 0.15
     elif mode.startswith('walls'):   # curvilinear blocks between two walls: the i direction must not be split
@@ -57,6 +61,9 @@ def main():
     for zz, m in zip(Internal.getZones(tt), mm):
         p, pr, _ = zone_arrays(zz)
         zs.append(O.OracleZone(p, pr, FastC.level_buffer(zz), m[0], wall_distance(zz) if mode == 'sa' else None))
+        if threads > 1:
+            zs[-1].lu_blocks = FastC.lu_thread_blocks(p, threads)
+            assert len(zs[-1].lu_blocks) == threads
     s = O.OracleSolver(zs, [(br, r, bd, d) for br, bd, r, d in connect.periodic_block_joins(blocks, (n, n, n))])
     s.fill_ghostcells()
     for it in range(nsteps):

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
                                            ((1, 2, 1), 10, 'implicit'), ((1, 1, 2), 10, 'curvilinear'),
                                            ((1, 1, 2), 10, 'sa'),
                                            ((1, 2, 2), 8, 'explicit'), ((1, 2, 2), 8, 'walls'),
-                                           ((1, 2, 2), 8, 'walls_implicit'), ((2, 2, 1), 8, 'implicit')])
+                                           ((1, 2, 2), 8, 'walls_implicit'), ((2, 2, 1), 8, 'implicit'),
+                                           ((1, 2, 1), 24, 'implicit_threads')])
 def test_two_ranks_one_gpu(blocks, n, mode):
     rcs, outs = _run(2, list(blocks) + [n, 3, mode], timeout=300, worker='mpi_gpu_worker.py')
     assert rcs == [0, 0], "\n".join(outs)
