@@ -105,6 +105,31 @@ def test_block_lusgs_matches_oracle(threads, monkeypatch, n, scheme, model, pert
         assert not np.array_equal(one.ro, oz.ro)
 
 
+@pytest.mark.parametrize("align", [1, 2])
+def test_block_lusgs_at_size(threads, monkeypatch, align):
+    """96^3 cells in the 2 x 8 blocks of 16 threads (96 x 48 x 12 cells each: several waves per hyperplane and block,
+    grids of a few thousand workgroups), two time steps of three Newton sub-iterations, bit for bit."""
+    monkeypatch.setenv('FASTS_HIP_LU_ALIGN', str(align))
+    n = (96, 96, 96)
+    t = cases.tgv(n, 'ausmpred', extra_numz=SINGLE, extra_numb={'ss_iteration': 3}, temporal_scheme='implicit',
+                  time_step=0.02)
+    threads(16)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    blocks = FastC.lu_thread_blocks(pint, 16)
+    assert len(blocks) == 16 and tuple(blocks[0]) == (1, 96, 1, 48, 1, 12)
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.lu_blocks = blocks
+    oz.fill_ghostcells()
+    oz.ro_m1[:] = oz.ro; oz.ro_p1[:] = oz.ro
+    for it in range(1, 3):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
+
+
 def test_lu_blocks_are_validated():
     t = cases.tgv((12, 24, 22), 'ausmpred', extra_numz=SINGLE, extra_numb={'ss_iteration': 2},
                   temporal_scheme='implicit', time_step=0.02)
