@@ -215,10 +215,11 @@ FS_DEV void lu_neighbour(const FsZone &z, const LuConst &c, long long l, long lo
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Sweeps over hyperplanes of (8-cell unit of an i-line, j, k): a wave handles 8 units of 8 cells, lane = (unit, cell).
-// The loads and the j/k neighbour terms are done one cell per lane (8 lanes read 64 contiguous bytes of
-// every array); the i recurrence then runs in 8 steps, the increment of cell m-1 reaching cell m through
-// a shuffle inside each group of 8 lanes.
+// Sweeps over hyperplanes of (unit of U consecutive cells of an i-line, j, k): a wave handles 64 / U units, lane =
+// (unit, cell).  The loads and the j/k neighbour terms are done one cell per lane (the U lanes of a unit read U * 8
+// contiguous bytes of every array); the i recurrence then runs in U steps, the increment of cell m-1 reaching cell m
+// through a DPP row shift inside the unit.  U = 8 for one sweep of a zone (launches bound by their latency), 16 when
+// the blocks of the reference's threads are swept side by side (launches bound by memory).
 // ------------------------------------------------------------------------------------------------------
 #ifdef FS_LU_STAMP
 // development aid: time stamps of wave (0,0) of every lower-sweep launch (profiles/lu_stamps.py)
@@ -238,7 +239,7 @@ extern "C" int fs_lu_stamp_fetch(long long *host)
 #endif
 
 // Value of the previous / next lane by a DPP row shift (a VALU move, no trip through the LDS crossbar as
-// __shfl_up / __shfl_down take).  Rows are 16 lanes, units 8: the first (last) lane of a unit receives the value of a
+// __shfl_up / __shfl_down take).  Rows are 16 lanes, units 8 or 16: the first (last) lane of a unit receives the value of a
 // lane of the neighbouring unit or zero, and never uses it.
 FS_DEV double lane_prev(double x)
 {
