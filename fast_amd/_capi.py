@@ -15,7 +15,7 @@ FS_LEVEL_FILTERED = 8      # fs_download only: the filtered state of selective f
 
 SYMBOLS = [
     "fs_version", "fs_create", "fs_destroy", "fs_last_error", "fs_set_stream", "fs_set_verif", "fs_set_first_it",
-    "fs_zone_add", "fs_zone_set_distance", "fs_zone_set_filtered", "fs_zone_set_lu_blocks", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
+    "fs_zone_add", "fs_zone_set_distance", "fs_zone_set_filtered", "fs_zone_set_lu_blocks", "fs_set_lu_threads", "fs_zone_lu_blocks", "fs_join_add", "fs_send_add", "fs_upload", "fs_download", "fs_compute",
     "fs_stage", "fs_stage_part", "fs_set_comm_stream", "fs_halo_count", "fs_halo_pack", "fs_halo_unpack", "fs_local_joins", "fs_bcs",
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_tgv_sums_static", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
@@ -126,6 +126,19 @@ class Context:
         self._chk(lib().fs_zone_set_lu_blocks(self._h, ctypes.c_int(int(zone)), ctypes.c_int(len(b)),
                                               b.ctypes.data_as(ctypes.c_void_p) if len(b) else None),
                   "fs_zone_set_lu_blocks")
+
+    def set_lu_threads(self, nthreads):
+        """LU-SGS / LU-SSOR solve of every zone in the blocks the reference gives that many OpenMP threads."""
+        self._chk(lib().fs_set_lu_threads(self._h, ctypes.c_int(int(nthreads))), "fs_set_lu_threads")
+
+    def zone_lu_blocks(self, zone):
+        """(n, 6) LU ranges of the blocks of a zone as the library holds them (empty: one sweep)."""
+        n = self._chk(lib().fs_zone_lu_blocks(self._h, ctypes.c_int(int(zone)), None, ctypes.c_int(0)), "fs_zone_lu_blocks")
+        out = numpy.zeros((n, 6), dtype=numpy.int32)
+        if n:
+            self._chk(lib().fs_zone_lu_blocks(self._h, ctypes.c_int(int(zone)), out.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_int(n)), "fs_zone_lu_blocks")
+        return out
 
     def set_first_it(self, first_it):
         self._chk(lib().fs_set_first_it(self._h, ctypes.c_int(int(first_it))), "fs_set_first_it")

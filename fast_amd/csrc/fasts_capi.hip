@@ -138,6 +138,111 @@ extern "C" int fs_zone_set_filtered(fs_ctx *ctx, int zone, double *rof, long lon
   return FS_OK;
 }
 
+// Blocks of interior cells that the reference's OpenMP threads take in a zone of iv x jv x kv cells (omp_mode 0: every zone
+// is cut among all the threads, Fast/FastC/FastC/HPC_LAYER/distributeThreads.cpp:90-95 -> indice_boucle_lu.for:94-335):
+// a p x q cut with p a divisor of the thread count not above 8, along k and j where both directions offer enough slices
+// of lmin cells, else along j and i; the pair with the smallest load imbalance wins (an uneven cut along the second
+// direction weighs 2 or 5 times; the imbalance is evaluated in single precision as the reference does); when no pair
+// fits and a cut was possible in principle the first thread takes the zone, and with fewer slices than threads there are
+// as many blocks as slices.  Threads left without cells are dropped.
+static std::vector<int32_t> lu_thread_blocks(int iv, int jv, int kv, int nthreads, int lmin)
+{
+  const int size[3] = {iv, jv, kv};
+  std::vector<int32_t> out;
+  auto whole = [&]() { out = {1, iv, 1, jv, 1, kv}; return out; };
+  const int n = nthreads;
+  if (n <= 1) return whole();
+  int slices[3];
+  for (int d = 0; d < 3; d++) slices[d] = size[d] / lmin > 1 ? size[d] / lmin : 1;
+  if (kv == 1) slices[2] = 1;
+  std::vector<int> divisors = {1};
+  for (int q = 2; q <= 8; q++) if (n % q == 0) divisors.push_back(q);
+  // cost of cutting direction a in ca and direction b in cb
+  auto imbalance = [&](int a, int ca, int b, int cb, double weight) {
+    const float fa = (float)(size[a] % ca) / (float)(size[a] / ca), fb = (float)(size[b] % cb) / (float)(size[b] / cb);
+    return (double)fa + (double)fb * weight;
+  };
+  // best (count along a, count along b); small_first: the pair with the divisor along a is tried first
+  auto best_cut = [&](int a, int b, double weight, bool small_first, int &ca_best, int &cb_best) {
+    double cost_best = 100000.;
+    bool found = false;
+    for (int p1 : divisors) {
+      const int p2 = n / p1;
+      const int pairs[2][2] = {{small_first ? p1 : p2, small_first ? p2 : p1}, {small_first ? p2 : p1, small_first ? p1 : p2}};
+      for (auto &pr : pairs) {
+        if (pr[0] <= slices[a] && pr[1] <= slices[b]) {
+          const double cost = imbalance(a, pr[0], b, pr[1], weight);
+          if (cost < cost_best) { cost_best = cost; ca_best = pr[0]; cb_best = pr[1]; found = true; }
+        }
+      }
+    }
+    return found;
+  };
+  int counts[3] = {0, 0, 0};
+  bool have = false, failed = false;
+  int ca = 0, cb = 0;
+  if (slices[2] * slices[1] >= n) {
+    if (best_cut(2, 1, 2., false, ca, cb)) { counts[0] = 1; counts[1] = cb; counts[2] = ca; have = true; }
+    else failed = true;
+  }
+  if (!have && slices[0] * slices[1] >= n) {
+    if (best_cut(1, 0, 5., true, ca, cb)) { counts[0] = cb; counts[1] = ca; counts[2] = 1; have = true; }
+    else failed = true;
+  }
+  if (!have) {
+    if (failed) return whole();
+    if (slices[0] * slices[1] > slices[1] * slices[2]) { counts[0] = slices[0]; counts[1] = slices[1]; counts[2] = 1; }
+    else { counts[0] = 1; counts[1] = slices[1]; counts[2] = slices[2]; }
+  }
+  auto part = [&](int d, int q, int32_t &lo, int32_t &hi) {   // q-th (from 0) of counts[d] parts of direction d
+    const int c = counts[d], sz = size[d] / c, rest = size[d] % c;
+    if (q < rest) { lo = 1 + (sz + 1) * q; hi = (sz + 1) * (q + 1); }
+    else { lo = 1 + sz * q + rest; hi = sz * (q + 1) + rest; }
+  };
+  if (counts[0] == 1) {
+    const int nb = n < counts[1] * counts[2] ? n : counts[1] * counts[2];
+    for (int t = 0; t < nb; t++) {
+      int32_t b[6] = {1, iv, 0, 0, 0, 0};
+      part(1, t % counts[1], b[2], b[3]); part(2, t / counts[1], b[4], b[5]);
+      out.insert(out.end(), b, b + 6);
+    }
+  } else {
+    const int nb = n < counts[0] * counts[1] ? n : counts[0] * counts[1];
+    for (int t = 0; t < nb; t++) {
+      int32_t b[6] = {0, 0, 0, 0, 1, kv};
+      part(0, t % counts[0], b[0], b[1]); part(1, t / counts[0], b[2], b[3]);
+      out.insert(out.end(), b, b + 6);
+    }
+  }
+  return out;
+}
+
+extern "C" int fs_zone_set_lu_blocks(fs_ctx *ctx, int zone, int nblocks, const int32_t *ind_sdm);
+
+extern "C" int fs_set_lu_threads(fs_ctx *ctx, int nthreads)
+{
+  if (!ctx || nthreads < 1) return ctx ? fail(ctx, FS_ERR_ARG, "fs_set_lu_threads: at least one thread") : FS_ERR_ARG;
+  if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_set_lu_threads: call before fs_upload");
+  if (!ctx->implicit) return fail(ctx, FS_ERR_STATE, "fs_set_lu_threads: the zones do not use the implicit scheme");
+  for (int zi = 0; zi < (int)ctx->zones.size(); zi++) {
+    const Zone &zn = ctx->zones[zi];
+    const std::vector<int32_t> b = lu_thread_blocks(zn.z.iv, zn.z.jv, zn.z.kv, nthreads, 10);
+    const int rc = fs_zone_set_lu_blocks(ctx, zi, (int)(b.size() / 6), b.data());
+    if (rc != FS_OK) return rc;
+  }
+  return FS_OK;
+}
+
+extern "C" int fs_zone_lu_blocks(fs_ctx *ctx, int zone, int32_t *ind_lu, int capacity)
+{
+  if (!ctx || capacity < 0 || (capacity > 0 && !ind_lu)) return ctx ? fail(ctx, FS_ERR_ARG, "fs_zone_lu_blocks: bad argument") : FS_ERR_ARG;
+  if (zone < 0 || zone >= (int)ctx->zones.size()) return fail(ctx, FS_ERR_ARG, "fs_zone_lu_blocks: zone index out of range");
+  const Zone &zn = ctx->zones[zone];
+  const int nb = (int)(zn.lu_blocks.size() / 6);
+  for (int q = 0; q < 6 * nb && q < 6 * capacity; q++) ind_lu[q] = zn.lu_blocks[q];
+  return nb;
+}
+
 extern "C" int fs_zone_set_lu_blocks(fs_ctx *ctx, int zone, int nblocks, const int32_t *ind_sdm)
 {
   if (!ctx || (nblocks > 0 && !ind_sdm)) return ctx ? fail(ctx, FS_ERR_ARG, "fs_zone_set_lu_blocks: null argument") : FS_ERR_ARG;

@@ -127,6 +127,18 @@ int fs_zone_set_filtered(fs_ctx *ctx, int zone, double *rof, long long n_doubles
  * the reference lets the ranges of the threads overlap, BC/BCzone.cpp:129-149).  Call before fs_upload. */
 int fs_zone_set_lu_blocks(fs_ctx *ctx, int zone, int nblocks, const int32_t *ind_sdm);
 
+/* The same for every zone of the context with the blocks the reference gives nthreads OpenMP threads (omp_mode 0:
+ * every zone cut among all the threads, Fast/FastC/FastC/HPC_LAYER/distributeThreads.cpp:90-95, the cut of
+ * indice_boucle_lu.for:94-335 with the 10-cell minimum of the implicit scheme, threads without cells dropped): what
+ * __NUMTHREADS__ / OMP_NUM_THREADS is to the reference's result.  1 = one sweep per zone.  Call after the zones are
+ * registered and before fs_upload. */
+int fs_set_lu_threads(fs_ctx *ctx, int nthreads);
+
+/* LU ranges of the blocks of a zone as the library holds them (6 integers each: the block, with the ghost layer on the
+ * wall faces of the zone it touches), at most `capacity` of them copied to ind_lu; returns the number of blocks (0: one
+ * sweep of the zone).  For checks. */
+int fs_zone_lu_blocks(fs_ctx *ctx, int zone, int32_t *ind_lu, int capacity);
+
 /* Match-join ghost transfer tables (one entry per join "rac"): receiver zone, donor zone and
  * the two index lists (0-based, ghost-inclusive linear cell indices i + j*ni + k*ni*nj), i.e.
  * the PointListDonor / PointList arrays of a 'direct' (type 0) ID join, as hand-built in

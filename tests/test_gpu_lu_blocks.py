@@ -130,6 +130,31 @@ def test_block_lusgs_at_size(threads, monkeypatch, align):
         assert np.array_equal(got, oz.ro), "step %d: max rel err %s" % (it, rel_err(got, oz.ro, int(pint[41])))
 
 
+@pytest.mark.parametrize("n", [(40, 33, 47), (12, 24, 22), (96, 25, 9), (60, 44), (130, 21)])
+def test_native_thread_decomposition(n):
+    """fs_set_lu_threads cuts the zones as FastC.lu_thread_blocks does (itself equal to indice_boucle_lu_ of the compiled
+    reference, test_lu_thread_blocks.py), for every thread count up to 40 and a few larger ones."""
+    from common import prepare
+    make = cases.tgv if len(n) == 3 else cases.tgv2d
+    t = make(n, 'ausmpred', extra_numz=SINGLE, extra_numb={'ss_iteration': 2}, temporal_scheme='implicit', time_step=0.02)
+    metrics = prepare(t)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    lv = [FastC.level_buffer(z, s) for s in ('', '_M1', '_P1')]
+    ctx = _capi.Context(0)
+    ctx.zone_add(pint, preal, lv[0], lv[1], lv[2], metrics[0][0])
+    assert len(ctx.zone_lu_blocks(0)) == 0
+    for nth in list(range(1, 41)) + [48, 64, 96, 128, 200]:
+        ctx.set_lu_threads(nth)
+        want = FastC.lu_thread_blocks(pint, nth)
+        got = ctx.zone_lu_blocks(0)
+        if len(want) == 1:
+            assert len(got) == 0, nth          # one block: the single sweep
+        else:
+            assert np.array_equal(got, want), nth
+    ctx.close()
+
+
 def test_lu_blocks_are_validated():
     t = cases.tgv((12, 24, 22), 'ausmpred', extra_numz=SINGLE, extra_numb={'ss_iteration': 2},
                   temporal_scheme='implicit', time_step=0.02)
