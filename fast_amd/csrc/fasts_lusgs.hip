@@ -264,10 +264,11 @@ FS_DEV double lane_next(double x)
 // hyperplanes: the j - 1 and k - 1 neighbours of the cells of unit cn then sit in units cn - 1 or cn of their lines,
 // never cn + 1.  The price is (p0 + a (nj - 1) + b (nk - 1)) / U more chunk columns, i.e. hyperplanes.  Measured
 // (ms per implicit step, 3 Newton sub-iterations, shift off / on): 252^3 in 64 blocks, a = b = 0, no extra hyperplane:
-// 17.0 / 13.6; 256^3 (a = 4) in 128 blocks, 12 % more hyperplanes: 16.9 / 15.7; in 64 blocks, 17 %: 17.0 / 16.7; in 16
-// blocks, 22 %: 23.5 / 25.4; two-dimensional 1024 x 256 zone (small launches, bound by latency) in 200 blocks, 11 %:
-// 1.44 / 1.65.  So enable = 1 shifts when no hyperplane is added, or at most a tenth on a three-dimensional zone;
-// enable = 2 whenever the stride between variables keeps the alignment (tests of the general case).
+// 17.2 / 13.9; 256^3 (a = 4) in 200 blocks, 14 % more hyperplanes: 14.4 / 13.6; in 128 blocks, 12 %: 14.6 / 13.8; in 64
+// blocks, 17 %: 15.9 / 15.7; in 32 blocks, 20 %: 18.0 / 18.6; two-dimensional 1024 x 256 zone (small launches, bound by
+// latency) in 200 blocks, 11 %: 1.44 / 1.65.  So enable = 1 shifts when no hyperplane is added, or at most 15 % on a
+// three-dimensional zone; enable = 2 whenever the stride between variables keeps the alignment (tests of the
+// general case).
 // All zero: units start at the first cell of the range.
 struct LuSkew { int p0, a, b; };
 // chunk columns of a block with its skew
@@ -284,8 +285,10 @@ __host__ __device__ inline LuSkew lu_skew(const FsZone &z, int i0, int i1, int j
   const int a = (int)(z.incj % U), b = (int)(z.inck % U);
   const int p0 = ((i0 + z.ific - 1) + (j0 + z.ific - 1) * a + (k0 + z.ifick - 1) * b) % U;
   const int nj = j1 - j0 + 1, nk = k1 - k0 + 1;
-  const int extra = lu_nchunk<U>(LuSkew{p0, a, b}, i1 - i0 + 1, nj, nk) - (i1 - i0 + U) / U;
-  if (enable == 1 && extra > 0 && (z.nk == 1 || 10 * extra > (i1 - i0 + U) / U + nj + nk - 2)) return s;
+  const int plain = (i1 - i0 + U) / U;                                       // chunk columns without the shift
+  const int extra = (i1 - i0 + 1 + p0 + a * (nj - 1) + b * (nk - 1) + U - 1) / U - plain;
+  const bool too_many = extra > 0 && (z.nk == 1 || 20 * extra > 3 * (plain + nj + nk - 2));
+  if (enable == 1 && too_many) return s;
   s.p0 = p0; s.a = a; s.b = b;
   return s;
 }
@@ -299,15 +302,27 @@ __host__ __device__ inline LuSkew lu_skew(const FsZone &z, int i0, int i1, int j
 // k-plane: these launches are bound by their latency, and working the three out here costs them 0.6 us each.
 template <int U, bool UPPER, bool MULTI>
 FS_DEV bool lu_block(const FsZone &z, const LuRange &r0, const LuRange *__restrict__ tab, int nchunk0, int n, int kbase0,
-                     LuRange &r, LuSkew &sk, int &nchunk, int &h, int &kbase)
+                     LuRange &r, LuSkew &sk, int &nchunk, int &h, int &kbase, int &bx, int &by)
 {
+  bx = blockIdx.x; by = blockIdx.y;
   if (!MULTI) {
     r = r0; sk.p0 = 0; sk.a = 0; sk.b = 0; nchunk = nchunk0; h = n; kbase = kbase0;
     return true;
   }
-  r = tab[blockIdx.z];
+  // Workgroups go to the 8 XCDs in turn, in the order of their linear index.  All the workgroups of a block are given
+  // to one XCD, the same in every launch: what a launch reads of the previous hyperplane of its block (the increments
+  // just written, the states and coefficients just read) is then in that XCD's L2 where it is still held.
+  int bz = blockIdx.z;
+  if ((gridDim.z & 7) == 0 && !(nchunk0 & 4)) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned slot = lin >> 3, nb8 = gridDim.z >> 3;
+    bz = (int)((slot % nb8) * 8 + (lin & 7));
+    const unsigned w = slot / nb8;
+    bx = (int)(w % gridDim.x); by = (int)(w / gridDim.x);
+  }
+  r = tab[bz];
   const int nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
-  sk = lu_skew<U>(z, r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, nchunk0);   // with a block table the chunk-count argument carries the switch
+  sk = lu_skew<U>(z, r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, nchunk0 & 3);   // with a block table the chunk-count argument carries the switches
   nchunk = lu_nchunk<U>(sk, r.i1 - r.i0 + 1, nj, nk);
   const int nhc = nchunk + nj + nk - 2;
   h = UPPER ? nhc - 1 - n : n;
@@ -321,7 +336,7 @@ FS_DEV bool lu_block(const FsZone &z, const LuRange &r0, const LuRange *__restri
 // of a plane that hold cells of the hyperplane start at cn_min (those before it lie left of the range or past its
 // last line); without, at 0.
 template <int U, bool MULTI>
-FS_DEV void lu_lane(const LuRange &r, const LuSkew &sk, int h, int k, int &cn, int &j, int &i, int &m)
+FS_DEV void lu_lane(const LuRange &r, const LuSkew &sk, int h, int k, int bx, int &cn, int &j, int &i, int &m)
 {
   const int u = threadIdx.x / U;
   m = threadIdx.x % U;
@@ -333,7 +348,7 @@ FS_DEV void lu_lane(const LuRange &r, const LuSkew &sk, int h, int k, int &cn, i
     const int cj = h - kp - (r.j1 - r.j0);                          // cn >= cj: line j <= j1
     if (cj > cn_min) cn_min = cj;
   }
-  cn = cn_min + blockIdx.x * (64 / U) + u;
+  cn = cn_min + bx * (64 / U) + u;
   j = r.j0 + h - cn - kp;
   i = r.i0 - (sk.p0 + sk.a * (j - r.j0) + sk.b * kp) + cn * U + m;
 }
@@ -345,12 +360,12 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
 {
   LuRange r;
   LuSkew sk;
-  int nchunk, h, kbase;
-  if (!lu_block<U, false, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  int nchunk, h, kbase, bx, by;
+  if (!lu_block<U, false, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase, bx, by)) return;
   // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
-  const int k = kbase + blockIdx.y;
+  const int k = kbase + by;
   int cn, j, i, m;
-  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  lu_lane<U, MULTI>(r, sk, h, k, bx, cn, j, i, m);
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
@@ -422,12 +437,12 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
 {
   LuRange r;
   LuSkew sk;
-  int nchunk, h, kbase;
-  if (!lu_block<U, true, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  int nchunk, h, kbase, bx, by;
+  if (!lu_block<U, true, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase, bx, by)) return;
   // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
-  const int k = kbase + blockIdx.y;
+  const int k = kbase + by;
   int cn, j, i, m;
-  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  lu_lane<U, MULTI>(r, sk, h, k, bx, cn, j, i, m);
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
@@ -521,12 +536,12 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
 {
   LuRange r;
   LuSkew sk;
-  int nchunk, h, kbase;
-  if (!lu_block<U, false, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  int nchunk, h, kbase, bx, by;
+  if (!lu_block<U, false, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase, bx, by)) return;
   // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
-  const int k = kbase + blockIdx.y;
+  const int k = kbase + by;
   int cn, j, i, m;
-  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  lu_lane<U, MULTI>(r, sk, h, k, bx, cn, j, i, m);
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
@@ -604,12 +619,12 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
 {
   LuRange r;
   LuSkew sk;
-  int nchunk, h, kbase;
-  if (!lu_block<U, true, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase)) return;
+  int nchunk, h, kbase, bx, by;
+  if (!lu_block<U, true, MULTI>(z, r0, tab, nchunk0, n, kbase0, r, sk, nchunk, h, kbase, bx, by)) return;
   // units of a wave: the same k-plane, consecutive chunks of the hyperplane (so consecutive j-lines, descending)
-  const int k = kbase + blockIdx.y;
+  const int k = kbase + by;
   int cn, j, i, m;
-  lu_lane<U, MULTI>(r, sk, h, k, cn, j, i, m);
+  lu_lane<U, MULTI>(r, sk, h, k, bx, cn, j, i, m);
   const bool active = j >= r.j0 && j <= r.j1 && k <= r.k1 && cn < nchunk && i >= r.i0 && i <= r.i1;
   const long long nd = z.nd;
   const long long l = active ? lcell(z, i, j, k) : lcell(z, r.i0, r.j0, r.k0);
@@ -747,7 +762,10 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
   const double *rop_kn = inplace ? scratch : rop;
   const bool sa = z.neq == 6;
   const int wpu = 64 / U;
-  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");      // 0 off, 1 where it pays (default), 2 wherever possible
+  // units on 128-byte lines: 0 off, 1 where it pays (default), 2 wherever possible; + 4: workgroups in their plain order
+  // instead of every block on one XCD (256^3, ms per implicit step, plain / one XCD per block: 64 blocks 17.3 / 15.9, 128
+  // blocks 16.9 / 14.6, with two LU-SSOR relaxations in 64 blocks 37.9 / 35.5)
+  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");
   const int align = align_env ? atoi(align_env) : 1;
   const bool multi = nblocks > 1 && blocks && blocks_dev;
   const int nb = multi ? nblocks : 1;
@@ -758,7 +776,7 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
     const int *q = br + 6 * b;
     const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
     if (bi < 1 || bj < 1 || bk < 1) return -1;
-    const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+    const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? (align & 3) : 0);
     const int nhc = lu_nchunk<U>(sk, bi, bj, bk) + bj + bk - 2;
     if (nhc > max_nhc) max_nhc = nhc;
   }
@@ -771,7 +789,7 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
       for (int b = 0; b < nb; b++) {
         const int *q = br + 6 * b;
         const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
-        const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+        const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? (align & 3) : 0);
         const int nchunk = lu_nchunk<U>(sk, bi, bj, bk);
         const int nhc = nchunk + bj + bk - 2;
         const int h = pass == 0 ? n : nhc - 1 - n;
@@ -855,7 +873,10 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
   const double *rop_kn = inplace ? scratch : rop;
   double *dout = work, *ssor = work + (size_t)z.neq * z.nd;
   const int wpu = 64 / U;
-  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");      // 0 off, 1 where it pays (default), 2 wherever possible
+  // units on 128-byte lines: 0 off, 1 where it pays (default), 2 wherever possible; + 4: workgroups in their plain order
+  // instead of every block on one XCD (256^3, ms per implicit step, plain / one XCD per block: 64 blocks 17.3 / 15.9, 128
+  // blocks 16.9 / 14.6, with two LU-SSOR relaxations in 64 blocks 37.9 / 35.5)
+  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");
   const int align = align_env ? atoi(align_env) : 1;
   const bool multi = nblocks > 1 && blocks && blocks_dev && !overlap;
   const int nb = multi ? nblocks : 1;
@@ -866,7 +887,7 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
     const int *q = br + 6 * b;
     const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
     if (bi < 1 || bj < 1 || bk < 1) return -1;
-    const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+    const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? (align & 3) : 0);
     const int nhc = lu_nchunk<U>(sk, bi, bj, bk) + bj + bk - 2;
     if (nhc > max_nhc) max_nhc = nhc;
   }
@@ -884,7 +905,7 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
         for (int b = 0; b < nb; b++) {
           const int *q = br + 6 * b;
           const int bi = q[1] - q[0] + 1, bj = q[3] - q[2] + 1, bk = q[5] - q[4] + 1;
-          const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? align : 0);
+          const LuSkew sk = lu_skew<U>(z, q[0], q[1], q[2], q[3], q[4], q[5], multi ? (align & 3) : 0);
           const int nchunk = lu_nchunk<U>(sk, bi, bj, bk);
           const int nhc = nchunk + bj + bk - 2;
           const int h = pass == 0 ? n : nhc - 1 - n;

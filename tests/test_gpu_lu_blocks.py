@@ -54,6 +54,9 @@ CASES = [
     ((48, 44), 'senseur', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 4, 4),
     ((24, 24, 22), 'senseur', 'NSLaminar', 0., None, 3, 4, 4, 2),
     ((32, 24, 22), 'ausmpred', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 3, 4, 4, 2),
+    # long lines, few of them per block: the growing shift adds under 15 % of hyperplanes and is the library's own choice
+    ((128, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 2, 4, 4),
+    ((128, 24, 22), 'senseur', 'NSLaminar', 0., {'jmin': 'BCWall', 'jmax': 'BCWall'}, 2, 4, 4, 2),
     # LU-SSOR relaxations block by block
     ((12, 24, 22), 'ausmpred', 'NSLaminar', 0., None, 3, 4, 4, 2),
     ((40, 33, 47), 'senseur', 'NSLaminar', 0., None, 2, 12, 12, 2),
