@@ -4,10 +4,10 @@
 set -e
 T=${1:-64}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/lu_pmc_T$T
+O=$R/gpurun_out/lu_pmc_T${T}_${CELLS:-256}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --no-cpu --implicit 3 --steps 1 --warmup 1 --lu-threads $T"
+CMD="python3 $R/bench.py --no-cpu --cells ${CELLS:-256} --implicit 3 --steps 1 --warmup 1 --lu-threads $T"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -o f -- $CMD > $O/pmc_fetch.log 2>&1
 python3 $R/profiles/summarise.py pmc $O/prof_fetch $O/pmc_fetch_size.csv
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -o w -- $CMD > $O/pmc_write.log 2>&1

@@ -22,5 +22,5 @@ bash profiles/run_lu_trace.sh 64 > $O/trace_T64.txt 2>&1
 cd $GRAFT_REPO_ROOT
 bash profiles/run_lu_pmc.sh 64 > $O/pmc_T64.txt 2>&1
 cd $GRAFT_REPO_ROOT
-cp gpurun_out/lu_pmc_T64/pmc_*.csv $O/
+cp gpurun_out/lu_pmc_T64_256/pmc_*.csv $O/
 cp gpurun_out/lu_trace_T64/timeline.txt $O/timeline_T64.txt
