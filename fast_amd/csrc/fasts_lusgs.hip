@@ -244,15 +244,15 @@ extern "C" int fs_lu_stamp_fetch(long long *host)
 FS_DEV double lane_prev(double x)
 {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false);   // row_shr:1
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true);   // row_shr:1, lanes without a source read 0
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 FS_DEV double lane_next(double x)
 {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, false);   // row_shl:1
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, true);   // row_shl:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -402,24 +402,28 @@ __global__ void __launch_bounds__(64) k_lu_lower_wave(FsZone z, LuConst c, LuRan
   }
   LUSTAMP(2, true)
   // P of lane m holds: before its step, the increment of cell m-1 (lane 0: preloaded); after, its own
-  for (int st = 0; st < U; st++) {
+  auto cell = [&](const double *pin) {
+    if (has_prev) {
+      double b[NE];
+      lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+#pragma unroll
+      for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
+    }
+#pragma unroll
+    for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+    if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
+  };
+  if (m == 0 && active) {   // first cell of a unit: its predecessor belongs to an earlier hyperplane
     double pin[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-      const double up = lane_prev(P[e]);
-      pin[e] = m == 0 ? P[e] : up;
-    }
-    if (m == st && active) {
-      if (has_prev) {
-        double b[NE];
-        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+    for (int e = 0; e < NE; e++) pin[e] = P[e];
+    cell(pin);
+  }
+  for (int st = 1; st < U; st++) {
+    double pin[NE];
 #pragma unroll
-        for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
-      }
-#pragma unroll
-      for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
-      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
-    }
+    for (int e = 0; e < NE; e++) pin[e] = lane_prev(P[e]);
+    if (m == st && active) cell(pin);
   }
   LUSTAMP(3, false)
   if (active) {
@@ -572,35 +576,39 @@ __global__ void __launch_bounds__(64) k_ssor_lower_wave(FsZone z, LuConst c, LuR
       }
     }
   }
-  for (int st = 0; st < U; st++) {
+  auto cell = [&](const double *pin) {
+    bool any = false;
+    if (has_prev) {
+      double b[NE];
+      lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+#pragma unroll
+      for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = FIRSTM ? t : S[e] + t; }
+      any = true;
+    }
+    if (has_j) {
+#pragma unroll
+      for (int e = 0; e < NE; e++) { A[e] = A[e] + BJ[e]; S[e] = (FIRSTM && !any) ? BJ[e] : S[e] + BJ[e]; }
+      any = true;
+    }
+    if (has_k) {
+#pragma unroll
+      for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = (FIRSTM && !any) ? BK[e] : S[e] + BK[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 5; e++) P[e] = A[e] * DG;
+    if (NE == 6) P[NE - 1] = A[NE - 1] / C6;   // LU/lu_dinv_SA.for
+  };
+  if (m == 0 && active) {   // first cell of a unit: its predecessor belongs to an earlier hyperplane
     double pin[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-      const double up = lane_prev(P[e]);
-      pin[e] = m == 0 ? P[e] : up;
-    }
-    if (m == st && active) {
-      bool any = false;
-      if (has_prev) {
-        double b[NE];
-        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+    for (int e = 0; e < NE; e++) pin[e] = P[e];
+    cell(pin);
+  }
+  for (int st = 1; st < U; st++) {
+    double pin[NE];
 #pragma unroll
-        for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = FIRSTM ? t : S[e] + t; }
-        any = true;
-      }
-      if (has_j) {
-#pragma unroll
-        for (int e = 0; e < NE; e++) { A[e] = A[e] + BJ[e]; S[e] = (FIRSTM && !any) ? BJ[e] : S[e] + BJ[e]; }
-        any = true;
-      }
-      if (has_k) {
-#pragma unroll
-        for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = (FIRSTM && !any) ? BK[e] : S[e] + BK[e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 5; e++) P[e] = A[e] * DG;
-      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;   // LU/lu_dinv_SA.for
-    }
+    for (int e = 0; e < NE; e++) pin[e] = lane_prev(P[e]);
+    if (m == st && active) cell(pin);
   }
   if (active) {
 #pragma unroll
