@@ -477,24 +477,29 @@ __global__ void __launch_bounds__(64) k_lu_upper_wave(FsZone z, LuConst c, LuRan
       }
     }
   }
-  for (int st = U - 1; st >= 0; st--) {
+  // a cell whose successor lies in the next unit has it preloaded in P; the last cell of the range has none
+  auto cell = [&](const double *pin) {
+    if (has_next) {
+      double b[NE];
+      lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+#pragma unroll
+      for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
+    }
+#pragma unroll
+    for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+    if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
+  };
+  if (m == U - 1 && active) {
     double pin[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-      const double dn = lane_next(P[e]);
-      pin[e] = last_of_unit ? P[e] : dn;
-    }
-    if (m == st && active) {
-      if (has_next) {
-        double b[NE];
-        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+    for (int e = 0; e < NE; e++) pin[e] = P[e];
+    cell(pin);
+  }
+  for (int st = U - 2; st >= 0; st--) {
+    double pin[NE];
 #pragma unroll
-        for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
-      }
-#pragma unroll
-      for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
-      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
-    }
+    for (int e = 0; e < NE; e++) pin[e] = lane_next(P[e]);
+    if (m == st && active) cell(pin);
   }
   if (active) {
 #pragma unroll
@@ -669,32 +674,37 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
       }
     }
   }
-  for (int st = U - 1; st >= 0; st--) {
+  // a cell whose successor lies in the next unit has it preloaded in P; the last cell of the range has none
+  auto cell = [&](const double *pin) {
+    if (has_next) {
+      double b[NE];
+      lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+#pragma unroll
+      for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = S[e] + t; }
+    }
+    if (has_j) {
+#pragma unroll
+      for (int e = 0; e < NE; e++) { A[e] = A[e] + BJ[e]; S[e] = S[e] + BJ[e]; }
+    }
+    if (has_k) {
+#pragma unroll
+      for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = S[e] + BK[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 5; e++) P[e] = A[e] * DG;
+    if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
+  };
+  if (m == U - 1 && active) {
     double pin[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-      const double dn = lane_next(P[e]);
-      pin[e] = last_of_unit ? P[e] : dn;
-    }
-    if (m == st && active) {
-      if (has_next) {
-        double b[NE];
-        lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+    for (int e = 0; e < NE; e++) pin[e] = P[e];
+    cell(pin);
+  }
+  for (int st = U - 2; st >= 0; st--) {
+    double pin[NE];
 #pragma unroll
-        for (int e = 0; e < NE; e++) { const double t = b[e] * XAL; A[e] = A[e] + t; S[e] = S[e] + t; }
-      }
-      if (has_j) {
-#pragma unroll
-        for (int e = 0; e < NE; e++) { A[e] = A[e] + BJ[e]; S[e] = S[e] + BJ[e]; }
-      }
-      if (has_k) {
-#pragma unroll
-        for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = S[e] + BK[e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 5; e++) P[e] = A[e] * DG;
-      if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
-    }
+    for (int e = 0; e < NE; e++) pin[e] = lane_next(P[e]);
+    if (m == st && active) cell(pin);
   }
   if (active) {
 #pragma unroll
