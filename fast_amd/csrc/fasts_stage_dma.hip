@@ -39,6 +39,18 @@
 #include <cstdint>
 #include <cstdlib>
 
+#ifndef FS_X_PRIO
+#define FS_X_PRIO 0
+#endif
+#ifdef FS_X_LEGS
+// development aid (timing only, results wrong): bits 8.. of the pace argument switch one leg of the kernel off:
+// 1 the stores of the cell waves, 2 their loads, 4 the plane requests, 8 the face arithmetic
+#define XF(bit) (((pace) >> 8) & (bit))
+#define PACE ((pace) & 0xff)
+#else
+#define XF(bit) 0
+#define PACE (pace)
+#endif
 #ifdef FS_STAMP
 // development aid: per-phase shader-clock stamps of the waves of workgroup 0 (profiles/stamps.py)
 __device__ long long fs_stamp_buf[12 * 40 * 8];
@@ -95,10 +107,51 @@ FS_DEV double from_next_lane(double x)
   return __hiloint2double(hi, lo);
 }
 
+// Loads of the cell waves that are requested one step ahead.  Issued by hand, so that the compiler does not count
+// them: it would place its wait where a branch of the step has issued no younger request, i.e. wait for every
+// outstanding request (vmcnt(0): the requests it has just issued and all the stores of the step before).  The
+// destination registers count as written at the statement, so nothing may touch them before wait_ahead<N>,
+// which names them: N = the requests this wave has issued after them.
+// The destination is declared read-write: the request then goes into the very register the last wait_ahead has
+// released, and the value stays in it until the next wait_ahead (no copy of a register that is still being loaded).
+FS_DEV void ld_ahead(double &dst, const double *base, unsigned boff)
+{
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(boff), "s"(base) : "memory");
+}
+FS_DEV void ld_ahead_byte(unsigned &dst, const unsigned char *base, unsigned off)
+{
+  asm volatile("global_load_ubyte %0, %1, %2" : "+v"(dst) : "v"(off), "s"(base) : "memory");
+}
+// A store of the cell waves placed by hand: after the value dep exists (it is not stored), so that the stores of a
+// step leave one by one between the face fluxes and not in one burst.
+FS_DEV void st_late(double *base, unsigned boff, double v, double dep)
+{
+  asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(boff), "v"(v), "s"(base), "v"(dep));
+}
+
+// nyounger (wave-uniform) = 0, 5 or 10.  One statement, so that the registers have one point of definition: with a
+// statement per count the compiler joins them by copies, which it puts ahead of the waits.
+FS_DEV void wait_ahead(double (&d)[5], unsigned &w, int nyounger)
+{
+  asm volatile("s_cmp_lt_u32 %6, 5\n\t"
+               "s_cbranch_scc1 .Lw0_%=\n\t"
+               "s_cmp_lt_u32 %6, 10\n\t"
+               "s_cbranch_scc1 .Lw5_%=\n\t"
+               "s_waitcnt vmcnt(10)\n\t"
+               "s_branch .Lwe_%=\n"
+               ".Lw5_%=:\n\t"
+               "s_waitcnt vmcnt(5)\n\t"
+               "s_branch .Lwe_%=\n"
+               ".Lw0_%=:\n\t"
+               "s_waitcnt vmcnt(0)\n"
+               ".Lwe_%=:"
+               : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(w) : "s"(nyounger) : "memory", "scc");
+}
+
 // inviscid + viscous flux of an i- or j-face whose right cell is tile cell c of plane k; all
 // operands from LDS (rs = ring slot of rho, T of plane k).  Returns the sensor value used (computed when FIRST).
 template <int KFLU, int IFLOW, int DIR, bool FIRST>
-FS_DEV double face_ij(const FsZone &z, const Smem &sm, int k, int rs, int c, double wg_in, double *flu)
+FS_DEV double face_ij(const FsZone &z, const Smem &sm, int k, int rs, int c, double wg_in, double *flu, int xf = 0)
 {
   static_assert(DIR == 0 || DIR == 1, "in-plane faces only");
   const int sk = slot_of(k), cur = k & 1;
@@ -113,6 +166,13 @@ FS_DEV double face_ij(const FsZone &z, const Smem &sm, int k, int rs, int c, dou
     qm2[e] = p[c - 2 * st]; qm1[e] = p[c - st]; q0[e] = p[c]; qp1[e] = p[c + st];
   }
   double wg = wg_in;
+#ifdef FS_X_LEGS
+  if (xf & 8) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) flu[e] = qm1[e] + q0[e];
+    return wg;
+  }
+#endif
   if (KFLU == 2 && FIRST) {
     auto qs = [&](int e, int o) -> double { return o == -2 ? qm2[e] : (o == -1 ? qm1[e] : (o == 0 ? q0[e] : qp1[e])); };
     wg = fs_wiggle(qs);
@@ -229,8 +289,8 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
     for (int r = 0; r < NDMA; r++) {
       if constexpr (WIDE) {
         char *l = reinterpret_cast<char *>(lds_plane) + (r * NSTGW + (wave - NCELLW)) * 1024;
-        if (dma_act[r]) __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + goff[r]), (lds_ptr_t)(l), 16, 0, 0);
-        if (paced) for (int q = 0; q < pace; q++) __builtin_amdgcn_s_sleep(1);
+        if (dma_act[r] && !XF(4)) __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + goff[r]), (lds_ptr_t)(l), 16, 0, 0);
+        if (paced) for (int q = 0; q < PACE; q++) __builtin_amdgcn_s_sleep(1);
       } else {
         char *l = reinterpret_cast<char *>(lds_plane) + (r * NWAVES + wave) * 256;
         if (dma_act[r]) __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + goff[r]), (lds_ptr_t)(l), 4, 0, 0);
@@ -277,11 +337,30 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
     unsigned wb_n = 0;   // sensor byte of the cell at plane k (requested a step ahead)
     if (KFLU == 2 && !FIRST) wb_n = ldw(k0, ob);
     double part[5] = {0., 0., 0., 0., 0.};   // +Fk- +Fj- +Fi- -Fi+ -Fj+ of cell k-1 (and xi*drodm)
+    // AHEAD: the requests for the previous balance and the sensor byte of the next plane go out by hand (ld_ahead)
+    // and are waited for with a count that leaves the stores of the step in flight
+    // Not with roe: those kernels spill registers, and a spill of a register that is being loaded stores garbage.
+    constexpr bool AHEAD = WIDE && !BDF && !FIRST && KFLU != 5;
+    // LATE: the stores of the new state leave between the face fluxes of the step (st_late) instead of in one burst
+    constexpr bool LATE = AHEAD;
+    const bool row_ok = __builtin_amdgcn_readfirstlane((int)(j <= z.jv)) != 0;   // a row outside the zone stores nothing
+    int nst_prev = 0;   // store instructions of this wave in the step before
     __syncthreads();
 
+#if FS_X_PRIO == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef FS_X_UNROLL
+#pragma unroll FS_X_UNROLL
+#endif
     for (int k = k0; k <= k1 + 1; k++) {
       const bool last = k > k1;          // finishing step: only the k-face k1+1/2 and cell k1
       const int cur = k & 1;
+#if FS_X_PRIO == 2
+      if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#elif FS_X_PRIO == 3
+      if ((wave >= 4) == ((k & 1) != 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
       STAMP(0)
       // the uniform constants of the zone are re-read as scalars in every step: their products (c2*s, c1*s, tc/4 ...)
       // would otherwise be parked in vector registers for the whole loop, which the register budget cannot afford
@@ -291,6 +370,20 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
       double dr_nn[5] = {0., 0., 0., 0., 0.};
       unsigned wb_nn = 0, wb_new = 0;
       const int rs1 = rnext(rs);
+      double xdr[5] = {0., 0., 0., 0., 0.};   // xi * previous balance of cell k
+      if constexpr (AHEAD) {
+        // what was requested in the step before has landed; the stores issued after it need not have
+        wait_ahead(dr_n, wb_n, nst_prev);
+#pragma unroll
+        for (int e = 0; e < 5; e++) xdr[e] = dr_n[e] * coefH;
+        // the products exist before the next requests reuse the registers
+        asm volatile("" : "+v"(xdr[0]), "+v"(xdr[1]), "+v"(xdr[2]), "+v"(xdr[3]), "+v"(xdr[4]));
+      } else if (!FIRST && !BDF) {
+#pragma unroll
+        for (int e = 0; e < 5; e++) xdr[e] = dr_n[e] * coefH;
+      }
+      unsigned wb_c = wb_n;   // sensor byte of the cell at plane k
+      if constexpr (AHEAD) asm volatile("v_mov_b32 %0, %1" : "=v"(wb_c) : "v"(wb_n));
       STAMP(1)
       // ---- own column at k (LDS) and k+1 ------------------------------------------------------------
       double qc[5], qd[5];
@@ -305,7 +398,11 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
       // ---- k-face between planes k-1 and k ----------------------------------------------------------
       double fk[5];
       {
-        double wg = (double)((wb_n >> 2) & 1u);
+        double wg = (double)((wb_c >> 2) & 1u);
+        if (XF(8)) {
+#pragma unroll
+          for (int e = 0; e < 5; e++) fk[e] = qb[e] + qc[e] + qa[e] + qd[e];
+        } else {
         if (KFLU == 2 && FIRST) {
           auto qs = [&](int e, int o) -> double { return o == -2 ? qa[e] : (o == -1 ? qb[e] : (o == 0 ? qc[e] : qd[e])); };
           wg = fs_wiggle(qs);
@@ -322,23 +419,31 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
           };
           fs_flux_viscous<2>(zl, q, mu_b, mu_c, fk);
         }
+        }
       }
       STAMP(2)
       // ---- requests for the next step, ahead of the stores of this one: a wait for these loads then leaves the
       // stores in flight (the memory counter retires in order) ----------------------------------------------------
       if (!last) {
         if (!WIDE) { dma_uvw(k + 2); dma_rt(k + 2, rnext(rs1)); dma_mu(k + 1); }
-        if (!FIRST && !BDF) {
+        if constexpr (AHEAD) {
+          if (!XF(2))
 #pragma unroll
-          for (int e = 0; e < 5; e++) dr_nn[e] = ldg(P(drodm, e, k + 1), ob);
+          for (int e = 0; e < 5; e++) ld_ahead(dr_n[e], P(drodm, e, k + 1), ob);
+          if (KFLU == 2) ld_ahead_byte(wb_n, wig + (long long)(k + 1 + z.ifick - 1) * inck, ob >> 3);
+        } else {
+          if (!FIRST && !BDF) {
+#pragma unroll
+            for (int e = 0; e < 5; e++) dr_nn[e] = ldg(P(drodm, e, k + 1), ob);
+          }
+          if (KFLU == 2 && !FIRST) wb_nn = ldw(k + 1, ob);
         }
-        if (KFLU == 2 && !FIRST) wb_nn = ldw(k + 1, ob);
       }
       // ---- finish cell k-1 --------------------------------------------------------------------------
-      double d[5];
+      double d[5], o[5] = {0., 0., 0., 0., 0.};
 #pragma unroll
       for (int e = 0; e < 5; e++) d[e] = part[e] - fk[e];
-      if (k > k0 && cell_ok) {
+      if (k > k0 && cell_ok && !XF(1)) {
         if (BDF) {
           double qn[5] = {0., 0., 0., 0., 0.}, qn1[5], r[5];
 #pragma unroll
@@ -354,28 +459,35 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
         } else {
           if (keep) {   // the balance of the last Runge-Kutta stage of a step is read by nothing
 #pragma unroll
-            for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, d[e]);
+            for (int e = 0; e < 5; e++) {
+              if constexpr (LATE) st_late(PW_(drodm, e, k - 1), ob, d[e], d[e]);
+              else stg(PW_(drodm, e, k - 1), ob, d[e]);
+            }
           }
-          double o[5];
           fs_rk_update(z, coefW, qb, d, o);
+          if constexpr (!LATE) {
 #pragma unroll
-          for (int e = 0; e < 5; e++) stg(PW_(rop_out, e, k - 1), ob, o[e]);
+            for (int e = 0; e < 5; e++) stg(PW_(rop_out, e, k - 1), ob, o[e]);
+          }
         }
       }
+      nst_prev = (k > k0 && row_ok && !BDF && !XF(1)) ? (keep ? 10 : 5) : 0;
+#if FS_X_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
       STAMP(3)
       // ---- balance of cell k, in the reference's order: xi*drodm + Fk- + Fj- + Fi- ... ----------------
       double acc[5] = {0., 0., 0., 0., 0.}, fin[5] = {0., 0., 0., 0., 0.};
       if (!last) {
 #pragma unroll
         for (int e = 0; e < 5; e++) {
-          double a = (FIRST || BDF) ? 0. : dr_n[e] * coefH;
-          acc[e] = a + fk[e];
+          acc[e] = xdr[e] + fk[e];
         }
         // ---- j-face, then i-face of plane k ----------------------------------------------------------
         {
           double f[5] = {0., 0., 0., 0., 0.};
           if (fj_ok) {
-            double w = face_ij<KFLU, IFLOW, 1, FIRST>(zl, sm, k, rs, ct, (double)((wb_n >> 1) & 1u), f);
+            double w = face_ij<KFLU, IFLOW, 1, FIRST>(zl, sm, k, rs, ct, (double)((wb_c >> 1) & 1u), f, XF(8));
             if (KFLU == 2 && FIRST) wb_new |= w != 0. ? 2u : 0u;
 #pragma unroll
             for (int e = 0; e < 5; e++) sm.fj[e][tj][ti] = f[e];
@@ -383,17 +495,29 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
 #pragma unroll
           for (int e = 0; e < 5; e++) acc[e] = acc[e] + f[e];
         }
+        if (LATE && k > k0 && cell_ok && !XF(1)) {
+          st_late(PW_(rop_out, 0, k - 1), ob, o[0], acc[0]);
+          st_late(PW_(rop_out, 1, k - 1), ob, o[1], acc[1]);
+        }
         STAMP(4)
         {
           double f[5] = {0., 0., 0., 0., 0.};
           if (fi_ok) {
-            double w = face_ij<KFLU, IFLOW, 0, FIRST>(zl, sm, k, rs, ct, (double)(wb_n & 1u), f);
+            double w = face_ij<KFLU, IFLOW, 0, FIRST>(zl, sm, k, rs, ct, (double)(wb_c & 1u), f, XF(8));
             if (KFLU == 2 && FIRST) wb_new |= w != 0. ? 1u : 0u;
           }
           if (KFLU == 2 && FIRST && (fi_ok || fj_ok)) stw(k, ob, wb_new);
 #pragma unroll
           for (int e = 0; e < 5; e++) { acc[e] = acc[e] + f[e]; fin[e] = from_next_lane(f[e]); }
         }
+        if (LATE && k > k0 && cell_ok && !XF(1)) {
+          st_late(PW_(rop_out, 2, k - 1), ob, o[2], acc[2]);
+          st_late(PW_(rop_out, 3, k - 1), ob, o[3], acc[3]);
+          st_late(PW_(rop_out, 4, k - 1), ob, o[4], acc[4]);
+        }
+      } else if (LATE && k > k0 && cell_ok && !XF(1)) {   // finishing step: no faces to wait for
+#pragma unroll
+        for (int e = 0; e < 5; e++) st_late(PW_(rop_out, e, k - 1), ob, o[e], d[e]);
       }
       STAMP(5)
       // flux rows complete: LDS traffic only, the requests of this step stay in flight
@@ -413,9 +537,13 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
       }
       // ---- shift the column window ------------------------------------------------------------------
 #pragma unroll
-      for (int e = 0; e < 5; e++) { qa[e] = qb[e]; qb[e] = qc[e]; dr_n[e] = dr_nn[e]; }
+      for (int e = 0; e < 5; e++) { qa[e] = qb[e]; qb[e] = qc[e]; }
+      if constexpr (!AHEAD) {
+#pragma unroll
+        for (int e = 0; e < 5; e++) dr_n[e] = dr_nn[e];
+        wb_n = wb_nn;
+      }
       mu_b = mu_c;
-      wb_n = wb_nn;
       rs = rs1;
       STAMP(7)
       // flux rows consumed; the staging waves have waited for the arriving planes.  The cell waves' own loads are
@@ -453,12 +581,12 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
         if (act) {
           double f[5];
           if (jedge) {
-            double w = face_ij<KFLU, IFLOW, 1, FIRST>(z, sm, k, rs, ct, (double)wg_n, f);
+            double w = face_ij<KFLU, IFLOW, 1, FIRST>(z, sm, k, rs, ct, (double)wg_n, f, XF(8));
             if (KFLU == 2 && FIRST && ghost) stw(k, ob, w != 0. ? 2u : 0u);
 #pragma unroll
             for (int e = 0; e < 5; e++) sm.fj[e][TJ][ti] = f[e];
           } else {
-            double w = face_ij<KFLU, IFLOW, 0, FIRST>(z, sm, k, rs, ct, (double)wg_n, f);
+            double w = face_ij<KFLU, IFLOW, 0, FIRST>(z, sm, k, rs, ct, (double)wg_n, f, XF(8));
             if (KFLU == 2 && FIRST && ghost) stw(k, ob, w != 0. ? 1u : 0u);
 #pragma unroll
             for (int e = 0; e < 5; e++) sm.fi_extra[e][tj] = f[e];
@@ -542,6 +670,9 @@ FsTiling fsk_stage_dma_tiling(const FsZone &z)
   if (z.kv < t.kchunk) t.kchunk = z.kv;
   t.pace = 1;
   if (const char *ev = getenv("FASTS_HIP_PACE")) t.pace = atoi(ev);   // tuning aid
+#ifdef FS_X_LEGS
+  if (const char *ev = getenv("FASTS_HIP_XLEGS")) t.pace = (t.pace & 0xff) | (atoi(ev) << 8);
+#endif
   t.ntk = (z.kv + t.kchunk - 1) / t.kchunk;
   return t;
 }
