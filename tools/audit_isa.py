@@ -50,31 +50,31 @@ def audit_function(name, lines):
         if 'ASMEND' in ln:
             in_asm = False
     loads = [i for i, ln in enumerate(lines) if asm_flag[i] and re.search(r'global_load_(dwordx2|ubyte) v', ln)]
-    if not loads:
-        return errs
-    loop = tags[loads[0]]
-    if loop is None:
+    if any(tags[i] is None for i in loads):
         return ["%s: hand-issued loads outside a loop" % name]
-    if any(tags[i] != loop for i in loads):
-        errs.append("%s: hand-issued loads in more than one loop" % name)
-    waits = [i for i, ln in enumerate(lines) if asm_flag[i] and tags[i] == loop and 's_waitcnt vmcnt(0)' in ln]
-    if len(waits) != 1:
-        return errs + ["%s: expected one hand-placed wait in loop %s, found %d" % (name, loop, len(waits))]
-    w_end = next(i for i in range(waits[0], len(lines)) if 'ASMEND' in lines[i])
-    dest = set()
-    for i in loads:
-        dest |= regs_of(re.search(r'global_load_\w+ (v\[\d+:\d+\]|v\d+)', lines[i]).group(1))
-    first_load = min(loads)
-    if not w_end < first_load:
-        errs.append("%s: the wait does not precede the loads in the loop's layout" % name)
-    for i, ln in enumerate(lines):
-        if tags[i] != loop or asm_flag[i] or not ln.startswith('\t') or ln.lstrip().startswith(('.', ';')):
+    for loop in sorted(set(tags[i] for i in loads)):
+        lds = [i for i in loads if tags[i] == loop]
+        waits = [i for i, ln in enumerate(lines) if asm_flag[i] and tags[i] == loop and 'wait_ahead' in ln]
+        if len(waits) != 1:
+            errs.append("%s: expected one hand-placed wait in loop %s, found %d" % (name, loop, len(waits)))
             continue
-        if w_end < i < first_load:
-            continue
-        hit = vregs_in(ln) & dest
-        if hit:
-            errs.append("%s: line %d touches v%s while it is being loaded: %s" % (name, i, sorted(hit), ln.strip()))
+        w_end = next(i for i in range(waits[0], len(lines)) if 'ASMEND' in lines[i])
+        dest = set()
+        for i in lds:
+            dest |= regs_of(re.search(r'global_load_\w+ (v\[\d+:\d+\]|v\d+)', lines[i]).group(1))
+        first_load = min(lds)
+        if not w_end < first_load:
+            errs.append("%s: the wait does not precede the loads in the layout of loop %s" % (name, loop))
+        # in layout order the registers may be named between the wait and the first load only: what follows the loads,
+        # up to the end of the loop and from its start to the wait, runs while they are being loaded
+        for i, ln in enumerate(lines):
+            if tags[i] != loop or asm_flag[i] or not ln.startswith('\t') or ln.lstrip().startswith(('.', ';')):
+                continue
+            if w_end < i < first_load:
+                continue
+            hit = vregs_in(ln) & dest
+            if hit:
+                errs.append("%s: line %d touches v%s while it is being loaded: %s" % (name, i, sorted(hit), ln.strip()))
     return errs
 
 
@@ -89,10 +89,11 @@ def main(path):
         m = re.match(r'\s*\.set (_Z\w+)\.private_seg_size, (\d+)', ln)
         if m and name == m.group(1) and start is not None:
             body = text[start:i]
-            if any('ASMSTART' in b for b in body) and any(re.search(r'global_load_dwordx2 v\[\d+:\d+\], v\d+, s\[', b) and
-                                                           'ASM' in ''.join(body[max(0, j - 1):j]) for j, b in enumerate(body)):
+            if any('wait_ahead' in b for b in body):
                 audited += 1
-                if int(m.group(2)) != 0:
+                has_loads = any(re.search(r'global_load_(dwordx2|ubyte) v', b) and 'ASMSTART' in body[j - 1]
+                                for j, b in enumerate(body) if j > 0)
+                if has_loads and int(m.group(2)) != 0:
                     errs.append("%s: %s bytes of scratch in a kernel with hand-issued loads" % (name, m.group(2)))
                 errs += audit_function(name, body)
             start = None
