@@ -107,6 +107,87 @@ def cpu_baseline(scheme, budget_s=10.0):
             "sample": "TGV %d^3 %s RK3, %d steps, C restatement on %d OpenMP threads (k-slabs)" % (n, scheme, it, cores)}
 
 
+def visible_gpus():
+    """GPUs a HIP process started from here would see, counted in a child process: the launcher itself never touches
+    the GPU (it forks)."""
+    import subprocess
+    code = ("import ctypes\n"
+            "n = ctypes.c_int(0)\n"
+            "rc = ctypes.CDLL('libamdhip64.so').hipGetDeviceCount(ctypes.byref(n))\n"
+            "print(n.value if rc == 0 else 0)\n")
+    try:
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def launch_ranks(n, argv, ngpu=None, command=None, timeout=3000.):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh processes of this script, one per GPU (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR / MASTER_PORT and a communicator-id file of their own in the environment), pass on
+    what rank 0 prints, and return 0 only if every rank did.  Fewer than N visible GPUs: an error, never a smaller job.
+    command: what to start instead of this script (the test of the launcher)."""
+    import socket
+    import subprocess
+    import tempfile
+    if ngpu is None:
+        ngpu = visible_gpus()
+    if ngpu < n:
+        print("bench.py: --gpus %d but %d GPU(s) visible" % (n, ngpu), file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    idfile = os.path.join(tempfile.mkdtemp(prefix='fasts_hip_'), 'comm_id')
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), FASTS_HIP_ID_FILE=idfile, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        cmd = (command or [sys.executable, os.path.abspath(__file__)]) + list(argv)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    t0 = time.time()
+    rc, out0 = 0, None
+    try:
+        while True:
+            if out0 is None:
+                try:
+                    out0, _ = procs[0].communicate(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    pass
+            else:
+                time.sleep(0.2)
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:          # one rank down: the others would wait for it for ever
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > timeout:
+                rc = 124
+                break
+    finally:
+        for p in procs:          # the ranks this call started, by their own process ids
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    try:
+        os.remove(idfile)
+    except OSError:
+        pass
+    try:
+        os.rmdir(os.path.dirname(idfile))
+    except OSError:
+        pass
+    if rc == 0:
+        sys.stdout.write(out0 or '')
+        sys.stdout.flush()
+    else:
+        print("bench.py: a rank of the %d-GPU job failed (exit status %s)" % (n, rc), file=sys.stderr)
+    return rc if rc else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -131,10 +212,15 @@ def main():
                     'walls on jmin / jmax, periodic along i and k through match joins; not the headline workload')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: be the launcher (before anything touches the GPU)
+        if split_for(a.gpus) is None:
+            raise SystemExit("bench.py: --gpus must be 1, 2, 4 or 8")
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
 
     os.environ['FASTS_HIP_LAZY_SYNC'] = '1'

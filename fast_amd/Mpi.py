@@ -100,36 +100,44 @@ class HaloPlan:
 
 def comm_id_path():
     """File through which rank 0 hands the communicator identifier to the other ranks of the node:
-    FASTS_HIP_ID_FILE, or a name in /tmp made of what the ranks of one launch share and other jobs
-    do not (the launcher's process id and MASTER_PORT)."""
+    FASTS_HIP_ID_FILE, or a name made only of what every rank of one launch shares whatever process started it
+    (MASTER_ADDR, MASTER_PORT and the launcher's run id if it sets one), in a directory of the user's own."""
     p = os.environ.get('FASTS_HIP_ID_FILE')
     if p:
         return p
-    return '/tmp/fasts_hip_id_%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'))
-
-
-def _launcher_start():
-    try:
-        return os.stat('/proc/%d' % os.getppid()).st_mtime
-    except OSError:
-        return 0.
+    job = '%s_%s_%s' % (os.environ.get('MASTER_ADDR', 'local'), os.environ.get('MASTER_PORT', '0'),
+                        os.environ.get('TORCHELASTIC_RUN_ID', os.environ.get('SLURM_JOB_ID', '0')))
+    job = ''.join(ch if ch.isalnum() or ch in '._-' else '_' for ch in job)
+    d = os.path.join(os.environ.get('XDG_RUNTIME_DIR') or os.environ.get('TMPDIR') or '/tmp', 'fasts_hip_%d' % os.getuid())
+    return os.path.join(d, 'comm_id_' + job)
 
 
 def _share_comm_id(r, timeout=300.):
+    """Rank 0 writes the identifier into a file it creates itself (O_EXCL, mode 0600, in a directory only the user can
+    write: a file left by another job or planted by someone else is never read as this job's); the other ranks wait
+    for a file that is complete and belongs to the user."""
     path = comm_id_path()
+    d = os.path.dirname(path) or '.'
     if r == 0:
+        os.makedirs(d, mode=0o700, exist_ok=True)
         cid = _capi.comm_unique_id()
+        try:
+            os.remove(path)            # the leftover of an earlier job of this name
+        except OSError:
+            pass
         tmp = '%s.%d' % (path, os.getpid())
-        with open(tmp, 'wb') as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, 'wb') as f:
             f.write(cid)
         os.replace(tmp, path)      # appears whole or not at all
         return cid
     t0 = time.time()
-    born = _launcher_start()
     while True:
         try:
-            # a file older than the launcher is the leftover of another job that used the same name
-            if os.stat(path).st_mtime >= born - 1.:
+            st = os.stat(path)
+            # the file must be the user's own, and not older than the launcher of this rank: an older one is the leftover
+            # of an earlier job that used the same name (rank 0 removes it before it writes, and after the ranks have met)
+            if st.st_uid == os.getuid() and st.st_mtime >= _process_start() - 1.:
                 with open(path, 'rb') as f:
                     cid = f.read()
                 if len(cid) == _capi.COMM_ID_BYTES:
@@ -137,8 +145,24 @@ def _share_comm_id(r, timeout=300.):
         except OSError:
             pass
         if time.time() - t0 > timeout:
-            raise _capi.FastsHipError("fast_amd.Mpi: rank %d waited %.0f s for the communicator id in %s" % (r, timeout, path))
+            raise _capi.FastsHipError("fast_amd.Mpi: rank %d waited %.0f s for the communicator id in %s "
+                                      "(set FASTS_HIP_ID_FILE to a path every rank can reach)" % (r, timeout, path))
         time.sleep(0.02)
+
+
+_T_IMPORT = time.time()
+
+
+def _process_start():
+    """Start of the launcher of this rank (its parent), which comes before the ranks of the job exist; this process's
+    own start where that cannot be read."""
+    best = _T_IMPORT
+    for pid in (os.getpid(), os.getppid()):
+        try:
+            best = min(best, os.stat('/proc/%d' % pid).st_mtime)
+        except OSError:
+            pass
+    return best
 
 
 class _Rccl:

@@ -1056,6 +1056,9 @@ extern "C" int fs_stage_part(fs_ctx *ctx, int nitrun, int nstep, int part)
 extern "C" int fs_set_comm_stream(fs_ctx *ctx, void *hip_stream)
 {
   if (!ctx) return FS_ERR_ARG;
+  // with the library's own transport the pack, the messages and the unpack share the communicator's stream: another
+  // stream here would let a message leave before its buffer is packed
+  if (ctx->comm) return fail(ctx, FS_ERR_STATE, "fs_set_comm_stream: the context has a communicator (fs_comm_init), its stream is fixed");
   ctx->comm_stream = (hipStream_t)hip_stream;
   return FS_OK;
 }
@@ -1491,6 +1494,9 @@ extern "C" int fs_joins_set(fs_ctx *ctx, const int32_t *pint_tc, int n_int, cons
       if (nrcv <= 0 || pdon < 0 || prcv < 0 || ptyp < 0 || (long long)pdon + nrcv > n_int || (long long)prcv + nrcv > n_int)
         return fail(ctx, FS_ERR_ARG, "fs_joins_set: point lists outside the array");
       if (nod < 0 || nod >= nz) return fail(ctx, FS_ERR_ARG, "fs_joins_set: donor zone index outside the zones of the context");
+      if (nvars != ctx->zones[nod].z.neq)
+        return fail(ctx, FS_ERR_ARG, "fs_joins_set: a rac carries " + std::to_string(nvars) + " variables per point, its donor zone has " +
+                                         std::to_string(ctx->zones[nod].z.neq) + " equations");
       // interpolation types: [ntype, points per type..., type of every point]; a match join copies one donor
       int ntype;
       if (!at(ptyp, ntype) || ntype < 1 || (long long)ptyp + 1 + ntype + nrcv > n_int)

@@ -85,6 +85,30 @@ struct Comm {
 
 Comm *comm_of(const fs_ctx *ctx) { return (Comm *)ctx->comm; }
 
+// Inside ncclGroupStart / ncclGroupEnd the first error is kept and the group is always closed: a return from the
+// middle would leave every later call of this thread queued in a group that never ends.
+struct Group {
+  ncclResult_t first = ncclSuccess;
+  const char *what = "";
+  Group() { note(g_rccl.GroupStart(), "ncclGroupStart"); }
+  void note(ncclResult_t r, const char *w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; } }
+  // closes the group; 0 or FS_ERR_HIP with the text of the first error
+  int end(fs_ctx *ctx)
+  {
+    note(g_rccl.GroupEnd(), "ncclGroupEnd");
+    if (first == ncclSuccess) return FS_OK;
+    ctx->err = std::string(what) + ": " + g_rccl.GetErrorString(first);
+    return FS_ERR_HIP;
+  }
+};
+
+// device buffers of one call, freed on every way out
+struct DevInts {
+  std::vector<int32_t *> p;
+  ~DevInts() { for (int32_t *q : p) (void)hipFree(q); }
+  hipError_t get(int32_t **out, size_t n) { hipError_t e = hipMalloc(out, sizeof(int32_t) * n); if (e == hipSuccess) p.push_back(*out); return e; }
+};
+
 }  // namespace
 
 bool fs_comm_active(const fs_ctx *ctx) { return ctx->comm && comm_of(ctx)->ready; }
@@ -144,8 +168,10 @@ extern "C" int fs_comm_init(fs_ctx *ctx, int rank, int world, const void *id, in
 }
 
 // Handshake, once: every rank tells every peer which ghost cells its messages fill.  Wire format per message, int32:
-// [nrac | (receiver zone global id, npts, receiver cells[npts]) x nrac], the integer part of the reference's message
-// (setInterpTransfersFast.cpp:1185-1206: nrac, then per join NoR and the receiver list).
+// [nrac | (receiver zone global id, npts, variables per point, receiver cells[npts]) x nrac], the integer part of the
+// reference's message (setInterpTransfersFast.cpp:1185-1206: nrac, then per join NoR, the number of variables and the
+// receiver list).  Every rank takes part in every collective of the call whatever it finds wrong on the way, and the
+// ranks agree on the outcome at the end (one all-reduce): a rank that returned early would leave the others waiting.
 extern "C" int fs_comm_setup(fs_ctx *ctx)
 {
   int rc = fs_ensure_ready(ctx, "fs_comm_setup");
@@ -154,79 +180,97 @@ extern "C" int fs_comm_setup(fs_ctx *ctx)
   if (!c) return fail(ctx, FS_ERR_STATE, "fs_comm_setup: call fs_comm_init first");
   if (c->ready) return fail(ctx, FS_ERR_STATE, "fs_comm_setup: already done");
   const int W = c->world;
+  int bad = FS_OK;                 // first local problem; reported after the collectives
+  std::string bad_text;
+  auto problem = [&](int code, const std::string &text) { if (!bad) { bad = code; bad_text = text; } };
   std::map<int, int> gid_zone;
   for (size_t nz = 0; nz < ctx->zones.size(); nz++)
     if (ctx->zones[nz].gid >= 0) gid_zone[ctx->zones[nz].gid] = (int)nz;
-  // outgoing metadata per destination
+  // outgoing metadata per destination (a send that cannot be described is left out and fails the call below)
   std::vector<std::vector<int32_t>> meta(W);
   for (auto &s : ctx->sends) {
-    if (s.peer_tag >= W) return fail(ctx, FS_ERR_ARG, "fs_comm_setup: a send names a rank outside the job");
-    if (s.rcv_gid < 0) return fail(ctx, FS_ERR_STATE, "fs_comm_setup: sends must be registered with fs_send_add_remote");
+    if (s.peer_tag < 0 || s.peer_tag >= W) { problem(FS_ERR_ARG, "fs_comm_setup: a send names a rank outside the job"); continue; }
+    if (s.rcv_gid < 0) { problem(FS_ERR_STATE, "fs_comm_setup: sends must be registered with fs_send_add_remote"); continue; }
     auto &m = meta[s.peer_tag];
     if (m.empty()) m.push_back(0);
     m[0]++;
-    m.push_back(s.rcv_gid); m.push_back(s.npts);
+    m.push_back(s.rcv_gid); m.push_back(s.npts); m.push_back(ctx->zones[s.donor_zone].z.neq);
     m.insert(m.end(), s.rcv_host.begin(), s.rcv_host.end());
   }
   // sizes: row r of the matrix = int32 counts rank r sends to every rank
   std::vector<int32_t> mine(W), all((size_t)W * W);
   for (int p = 0; p < W; p++) mine[p] = (int32_t)meta[p].size();
+  DevInts tmp;
   int32_t *d_mine = nullptr, *d_all = nullptr;
-  HIPCHK(ctx, hipMalloc(&d_mine, sizeof(int32_t) * W));
-  HIPCHK(ctx, hipMalloc(&d_all, sizeof(int32_t) * W * W));
+  HIPCHK(ctx, tmp.get(&d_mine, W));
+  HIPCHK(ctx, tmp.get(&d_all, (size_t)W * W));
   HIPCHK(ctx, hipMemcpyAsync(d_mine, mine.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice, c->stream));
   NCCLCHK(ctx, g_rccl.AllGather(d_mine, d_all, W, ncclInt32, c->comm, c->stream));
   HIPCHK(ctx, hipMemcpyAsync(all.data(), d_all, sizeof(int32_t) * W * W, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(ctx, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_mine); (void)hipFree(d_all);
   // metadata messages
   std::vector<int32_t *> d_out(W, nullptr), d_in(W, nullptr);
   std::vector<std::vector<int32_t>> in(W);
   for (int p = 0; p < W; p++) {
     if (mine[p] > 0) {
-      HIPCHK(ctx, hipMalloc(&d_out[p], sizeof(int32_t) * mine[p]));
+      HIPCHK(ctx, tmp.get(&d_out[p], mine[p]));
       HIPCHK(ctx, hipMemcpyAsync(d_out[p], meta[p].data(), sizeof(int32_t) * mine[p], hipMemcpyHostToDevice, c->stream));
     }
     const int32_t nin = all[(size_t)p * W + c->rank];
-    if (nin > 0) { HIPCHK(ctx, hipMalloc(&d_in[p], sizeof(int32_t) * nin)); in[p].resize(nin); }
+    if (nin > 0) { HIPCHK(ctx, tmp.get(&d_in[p], nin)); in[p].resize(nin); }
   }
-  NCCLCHK(ctx, g_rccl.GroupStart());
-  for (int p = 0; p < W; p++) {
-    if (d_out[p]) NCCLCHK(ctx, g_rccl.Send(d_out[p], mine[p], ncclInt32, p, c->comm, c->stream));
-    if (d_in[p]) NCCLCHK(ctx, g_rccl.Recv(d_in[p], in[p].size(), ncclInt32, p, c->comm, c->stream));
+  {
+    Group g;
+    for (int p = 0; p < W; p++) {
+      if (d_out[p]) g.note(g_rccl.Send(d_out[p], mine[p], ncclInt32, p, c->comm, c->stream), "ncclSend");
+      if (d_in[p]) g.note(g_rccl.Recv(d_in[p], in[p].size(), ncclInt32, p, c->comm, c->stream), "ncclRecv");
+    }
+    rc = g.end(ctx);
+    if (rc) return rc;
   }
-  NCCLCHK(ctx, g_rccl.GroupEnd());
   for (int p = 0; p < W; p++)
     if (d_in[p]) HIPCHK(ctx, hipMemcpyAsync(in[p].data(), d_in[p], sizeof(int32_t) * in[p].size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(ctx, hipStreamSynchronize(c->stream));
-  for (int p = 0; p < W; p++) { (void)hipFree(d_out[p]); (void)hipFree(d_in[p]); }
   // receive side: ghost-cell joins in the order the peer packs them
-  for (int p = 0; p < W; p++) {
+  for (int p = 0; p < W && !bad; p++) {
     if (in[p].empty()) continue;
     const std::vector<int32_t> &m = in[p];
     size_t pos = 1;
-    for (int q = 0; q < m[0]; q++) {
-      if (pos + 2 > m.size()) return fail(ctx, FS_ERR_ARG, "fs_comm_setup: truncated join table from a peer");
-      const int gid = m[pos], npts = m[pos + 1];
-      pos += 2;
-      if (npts <= 0 || pos + (size_t)npts > m.size()) return fail(ctx, FS_ERR_ARG, "fs_comm_setup: truncated join table from a peer");
+    for (int q = 0; q < m[0] && !bad; q++) {
+      if (pos + 3 > m.size()) { problem(FS_ERR_ARG, "fs_comm_setup: truncated join table from a peer"); break; }
+      const int gid = m[pos], npts = m[pos + 1], nvars = m[pos + 2];
+      pos += 3;
+      if (npts <= 0 || pos + (size_t)npts > m.size()) { problem(FS_ERR_ARG, "fs_comm_setup: truncated join table from a peer"); break; }
       auto it = gid_zone.find(gid);
-      if (it == gid_zone.end()) return fail(ctx, FS_ERR_ARG, "fs_comm_setup: a peer sends ghost values for a zone that is not on this rank");
+      if (it == gid_zone.end()) { problem(FS_ERR_ARG, "fs_comm_setup: a peer sends ghost values for a zone that is not on this rank"); break; }
+      if (nvars != ctx->zones[it->second].z.neq) {
+        problem(FS_ERR_ARG, "fs_comm_setup: a peer sends " + std::to_string(nvars) + " variables per point to a zone with " +
+                                std::to_string(ctx->zones[it->second].z.neq) + " equations");
+        break;
+      }
       rc = fs_join_add(ctx, it->second, -p - 1, m.data() + pos, nullptr, npts);
-      if (rc) return rc;
+      if (rc) { problem(rc, ctx->err); break; }
       pos += npts;
     }
   }
   // message buffers
-  for (int p = 0; p < W; p++) {
+  for (int p = 0; p < W && !bad; p++) {
     Peer pr;
     pr.rank = p;
     pr.nsend = fs_halo_count(ctx, p, 1); pr.nrecv = fs_halo_count(ctx, p, 0);
     if (!pr.nsend && !pr.nrecv) continue;
-    if (pr.nsend) HIPCHK(ctx, hipMalloc(&pr.sbuf, sizeof(double) * pr.nsend));
-    if (pr.nrecv) HIPCHK(ctx, hipMalloc(&pr.rbuf, sizeof(double) * pr.nrecv));
-    c->peers.push_back(pr);
+    if (pr.nsend && hipMalloc(&pr.sbuf, sizeof(double) * pr.nsend) != hipSuccess) problem(FS_ERR_HIP, "fs_comm_setup: no memory for a send buffer");
+    if (pr.nrecv && hipMalloc(&pr.rbuf, sizeof(double) * pr.nrecv) != hipSuccess) problem(FS_ERR_HIP, "fs_comm_setup: no memory for a receive buffer");
+    c->peers.push_back(pr);      // released by fs_comm_release also when the call fails
   }
+  // the ranks agree: one failure fails the call everywhere
+  double worst = bad ? 1. : 0.;
+  HIPCHK(ctx, hipMemcpyAsync(c->red, &worst, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(ctx, g_rccl.AllReduce(c->red, c->red, 1, ncclDouble, ncclMax, c->comm, c->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&worst, c->red, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(ctx, hipStreamSynchronize(c->stream));
+  if (bad) return fail(ctx, bad, bad_text);
+  if (worst != 0.) return fail(ctx, FS_ERR_STATE, "fs_comm_setup: another rank of the job failed in this call");
   // zones with remote ghost cells: scheduling of split stages
   for (auto &j : ctx->joins) if (j.donor_zone < 0) ctx->zones[j.rcv_zone].has_recvs = true;
   c->ready = true;
@@ -241,12 +285,15 @@ int fs_comm_exchange_begin(fs_ctx *ctx, int nstep)
   HIPCHK(ctx, hipStreamWaitEvent(c->stream, c->ev_go, 0));
   for (auto &p : c->peers)
     if (p.nsend) { int rc = fs_halo_pack(ctx, nstep, p.rank, p.sbuf, (int)p.nsend); if (rc) return rc; }
-  NCCLCHK(ctx, g_rccl.GroupStart());
-  for (auto &p : c->peers) {
-    if (p.nsend) NCCLCHK(ctx, g_rccl.Send(p.sbuf, (size_t)p.nsend, ncclDouble, p.rank, c->comm, c->stream));
-    if (p.nrecv) NCCLCHK(ctx, g_rccl.Recv(p.rbuf, (size_t)p.nrecv, ncclDouble, p.rank, c->comm, c->stream));
+  {
+    Group g;
+    for (auto &p : c->peers) {
+      if (p.nsend) g.note(g_rccl.Send(p.sbuf, (size_t)p.nsend, ncclDouble, p.rank, c->comm, c->stream), "ncclSend");
+      if (p.nrecv) g.note(g_rccl.Recv(p.rbuf, (size_t)p.nrecv, ncclDouble, p.rank, c->comm, c->stream), "ncclRecv");
+    }
+    const int grc = g.end(ctx);
+    if (grc) return grc;
   }
-  NCCLCHK(ctx, g_rccl.GroupEnd());
   for (auto &p : c->peers)
     if (p.nrecv) { int rc = fs_halo_unpack(ctx, nstep, p.rank, p.rbuf, (int)p.nrecv); if (rc) return rc; }
   HIPCHK(ctx, hipEventRecord(c->ev_done, c->stream));

@@ -272,6 +272,15 @@ FS_DEV double lane_next(double x)
 // All zero: units start at the first cell of the range.
 struct LuSkew { int p0, a, b; };
 // chunk columns of a block with its skew
+// FASTS_HIP_LU_ALIGN: 0, 1 (default) or 2, + 4 for the plain workgroup order; anything else is the default.  Read at
+// every solve (a tuning aid that the tests switch between cases); two getenv calls per solve are not measurable.
+static int lu_align_setting()
+{
+  const char *e = getenv("FASTS_HIP_LU_ALIGN");
+  const int a = e ? atoi(e) : 1;
+  return (a < 0 || a > 7 || (a & 3) == 3) ? 1 : a;
+}
+
 template <int U>
 __host__ __device__ inline int lu_nchunk(const LuSkew &s, int ni, int nj, int nk)
 {
@@ -783,8 +792,7 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
   // units on 128-byte lines: 0 off, 1 where it pays (default), 2 wherever possible; + 4: workgroups in their plain order
   // instead of every block on one XCD (256^3, ms per implicit step, plain / one XCD per block: 64 blocks 17.3 / 15.9, 128
   // blocks 16.9 / 14.6, with two LU-SSOR relaxations in 64 blocks 37.9 / 35.5)
-  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");
-  const int align = align_env ? atoi(align_env) : 1;
+  const int align = lu_align_setting();
   const bool multi = nblocks > 1 && blocks && blocks_dev;
   const int nb = multi ? nblocks : 1;
   const int *br = multi ? blocks : range;
@@ -894,8 +902,7 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
   // units on 128-byte lines: 0 off, 1 where it pays (default), 2 wherever possible; + 4: workgroups in their plain order
   // instead of every block on one XCD (256^3, ms per implicit step, plain / one XCD per block: 64 blocks 17.3 / 15.9, 128
   // blocks 16.9 / 14.6, with two LU-SSOR relaxations in 64 blocks 37.9 / 35.5)
-  const char *align_env = getenv("FASTS_HIP_LU_ALIGN");
-  const int align = align_env ? atoi(align_env) : 1;
+  const int align = lu_align_setting();
   const bool multi = nblocks > 1 && blocks && blocks_dev && !overlap;
   const int nb = multi ? nblocks : 1;
   const int *br = multi ? blocks : range;
