@@ -1069,6 +1069,11 @@ def zone_vars(z):
     return v
 
 
+# Allocator of the compacted level buffers: None = numpy.  fast_amd.PyTree.warmup sets it to page-locked memory of
+# the HIP runtime (n float64 -> array, or None where there is none), which the host link copies in place.
+LEVEL_ALLOC = None
+
+
 def _createPrimVars(t):
     """Primitive variables + the _M1/_P1 time levels, then compaction of each level into one
     contiguous buffer with stride NDIMDX (Fast/FastC/FastC/PyTree.py:443-520,2230-2271).
@@ -1116,7 +1121,9 @@ def _createPrimVars(t):
             # (Fast/FastC/FastC/PyTree.py:357-361,678-687)
             levels = ('', '_M1', '_P1') + (('_f',) if int(pint[62]) == 1 else ())
             for suffix in levels:
-                buf = numpy.empty(len(vars_) * ndimdx, dtype=numpy.float64)
+                buf = LEVEL_ALLOC(len(vars_) * ndimdx) if LEVEL_ALLOC is not None else None
+                if buf is None:
+                    buf = numpy.empty(len(vars_) * ndimdx, dtype=numpy.float64)
                 for c, v in enumerate(vars_):
                     src = Internal.getNodeFromName1(sol, v + suffix)
                     zero = False

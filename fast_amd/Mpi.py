@@ -222,7 +222,7 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     tr = transport if transport is not None else _Rccl(rank(), size(), comm_id)
     r, n = tr.rank, tr.world
     procDict = graph['procDict'] if graph is not None else None
-    zones, metrics, dtloc = FastS._warmup_host(t, tc, Padding)
+    zones, metrics, dtloc = FastS._warmup_host(t, tc, Padding, device)
     ctx, names = FastS._new_context(zones, metrics, dtloc, device)
     ctx.set_first_it(FastC.FIRST_IT)
     native = getattr(tr, 'native', False)

@@ -82,8 +82,11 @@ def flat_tc(tc):
     return (pi[1], pr[1])
 
 
-def _warmup_host(t, tc, Padding=None):
-    """Host part of warmup: solver data, metrics, BC table, three compacted time levels."""
+def _warmup_host(t, tc, Padding=None, device=None):
+    """Host part of warmup: solver data, metrics, BC table, three compacted time levels (in page-locked memory of the
+    HIP runtime when a device is named and has some to give: the default refresh of the host copy after every
+    _compute then runs at the rate of the host link)."""
+    FastC.LEVEL_ALLOC = None if device is None else (lambda n: _capi.pinned_empty(n, device))
     FastC._reorder(t, tc)
     FastC._buildOwnData(t, Padding)
     own = Internal.getNodeFromName1(t, '.Solver#ownData')
@@ -139,7 +142,7 @@ def warmup(t, tc, graph=None, infos_ale=None, Adjoint=False, tmy=None, list_grap
     the HIP device index)."""
     if infos_ale is not None or Adjoint or tmy is not None:
         raise ValueError("fast_amd.warmup: ALE, adjoint and running statistics are not supported")
-    zones, metrics, dtloc = _warmup_host(t, tc, Padding)
+    zones, metrics, dtloc = _warmup_host(t, tc, Padding, device)
     ctx, names = _new_context(zones, metrics, dtloc, device)
     ctx.set_first_it(FastC.FIRST_IT)     # 1 when the tree carries stored _M1 levels (restart): BDF2 from the first step
     flat = flat_tc(tc)
@@ -274,6 +277,41 @@ def _log10_floor(v):
     return numpy.log10(numpy.maximum(v, 1.e-30))
 
 
+def residual_table_lines(zname, nitrun, nssiter, implicit, hl2, hloo, lft=1, iverb=0):
+    """The lines dpssiter.for prints for one zone (Fast/FastS/FastS/DISPLAY/dpssiter.for:60-245): hl2 / hloo =
+    (L2, Loo)[sub-iteration][equation].  log10 of the first sub-iteration, of every sub-iteration when iverb > 1 or
+    when the largest residual grew between the first and the last (:32-36), then the drop from the first to the
+    last and a warning where it is a rise.  lft 0: long format (f14.9), 1 or 2: short (f7.2)."""
+    last = hl2.shape[0]
+    l2log, loolog = _log10_floor(hl2), _log10_floor(hloo)
+    fmt = '%14.9f' if lft == 0 else '%7.2f'
+    every = iverb > 1 or bool(numpy.any(hloo[last - 1] > hloo[0]))
+    lines = []
+    for i in range(last):
+        if i == 0 or every:       # formats 3010-4311
+            it_real = i + 1 if i + 1 < last or not implicit else nssiter
+            lines.append(" Res_L2 (zone=%s, ssiter=%3d %3d)" % (zname, it_real, i + 1) + ''.join('  ' + fmt % v for v in l2log[i]))
+            lines.append(" Res_Loo(zone=%s, ssiter=%3d %3d)" % (zname, it_real, i + 1) + ''.join('  ' + fmt % v for v in loolog[i]))
+    if last > 1 or implicit:      # formats 3020-4321 (the reference prints them at i = last_it, whatever last_it is)
+        d2, doo = l2log[last - 1] - l2log[0], loolog[last - 1] - loolog[0]
+        lines.append(" Res_L2 (zone=%s, Diff Ssi 1-%3d)" % (zname, last) + ''.join('  ' + fmt % v for v in d2))
+        lines.append(" Res_Loo(zone=%s, Diff Ssi 1-%3d)" % (zname, last) + ''.join('  ' + fmt % v for v in doo))
+        for nm, d in (('L2 ', d2), ('Loo', doo)):
+            if d.max() > 0:
+                # the literal of dpssiter.for:176-178 runs over a continuation line: its leading blanks are part of the text
+                lines.append("Warning convergence" + 19 * ' ' + "%s Newton: dom=%s Pas de temps=%6d divergence=%12.5f"
+                             % (nm, zname, nitrun, d.max()))
+    return lines
+
+
+def convergence_record(hl2, hloo):
+    """What dpssiter.for:229-237 hands to conv2pytree.for:60-72 for one verification step: log10 of the norms of the
+    first sub-iteration and their drop to the last, (L2, Loo, L2 drop, Loo drop)[equation]."""
+    last = hl2.shape[0]
+    l2log, loolog = _log10_floor(hl2), _log10_floor(hloo)
+    return l2log[0], loolog[0], l2log[last - 1] - l2log[0], loolog[last - 1] - loolog[0]
+
+
 def display_temporal_criteria(t, metrics, nitrun, format=None, gmres=None, verbose='firstlast',
                               stopAtNan=True):
     """CFL and convergence information of the last verification step (Fast/FastS/FastS/PyTree.py:2030-2066 ->
@@ -316,23 +354,9 @@ def display_temporal_criteria(t, metrics, nitrun, format=None, gmres=None, verbo
         if lft < 3:
             # display_ss_iteration.cpp:104
             print("CFL_MOY_MAX_MIN(Zone= %32.32s, nitrun=%d) %f    %f    %f " % (z[0], nitrun, cfl[2], cfl[0], cfl[1]))
-        last = hl2.shape[0]
-        l2log, loolog = _log10_floor(hl2), _log10_floor(hloo)
         if lft < 3:
-            fmt = '%14.9f' if lft == 0 else '%7.2f'
-            every = iverb > 1 or bool(numpy.any(hloo[last - 1] > hloo[0]))     # dpssiter.for:32-36
-            for i in range(last):
-                if i == 0 or every:       # dpssiter.for:3010-4311
-                    print(" Res_L2 (zone=%s, ssiter=%3d %3d)" % (z[0], i + 1 if i + 1 < last or not implicit else nssiter, i + 1)
-                          + ''.join('  ' + fmt % v for v in l2log[i]))
-                    print(" Res_Loo(zone=%s, ssiter=%3d %3d)" % (z[0], i + 1 if i + 1 < last or not implicit else nssiter, i + 1)
-                          + ''.join('  ' + fmt % v for v in loolog[i]))
-            if last > 1:                  # dpssiter.for:3020-4321
-                print(" Res_L2 (zone=%s, Diff Ssi 1-%3d)" % (z[0], last) + ''.join('  ' + fmt % v for v in l2log[last - 1] - l2log[0]))
-                print(" Res_Loo(zone=%s, Diff Ssi 1-%3d)" % (z[0], last) + ''.join('  ' + fmt % v for v in loolog[last - 1] - loolog[0]))
-                for nm, d in (('L2 ', l2log[last - 1] - l2log[0]), ('Loo', loolog[last - 1] - loolog[0])):
-                    if d.max() > 0:
-                        print("Warning convergence %s Newton: dom=%s Pas de temps=%6d divergence=%12.5f" % (nm, z[0], nitrun, d.max()))
+            for ln in residual_table_lines(z[0], nitrun, nssiter, implicit, hl2, hloo, lft, iverb):
+                print(ln)
         # conv2pytree.for:60-72: one record per call: log10 of the first sub-iteration and the drop to the last
         zch = Internal.getNodeFromName1(z, 'ZoneConvergenceHistory')
         if zch is not None:
@@ -341,10 +365,11 @@ def display_temporal_criteria(t, metrics, nitrun, format=None, gmres=None, verbo
             if rec < itn.size:
                 itn[rec] = nitrun
                 sl = slice(rec * neq, (rec + 1) * neq)
-                Internal.getNodeFromName1(zch, 'RSD_L2')[1][sl] = l2log[0]
-                Internal.getNodeFromName1(zch, 'RSD_oo')[1][sl] = loolog[0]
-                Internal.getNodeFromName1(zch, 'RSD_L2_diff')[1][sl] = l2log[last - 1] - l2log[0]
-                Internal.getNodeFromName1(zch, 'RSD_oo_diff')[1][sl] = loolog[last - 1] - loolog[0]
+                r = convergence_record(hl2, hloo)
+                Internal.getNodeFromName1(zch, 'RSD_L2')[1][sl] = r[0]
+                Internal.getNodeFromName1(zch, 'RSD_oo')[1][sl] = r[1]
+                Internal.getNodeFromName1(zch, 'RSD_L2_diff')[1][sl] = r[2]
+                Internal.getNodeFromName1(zch, 'RSD_oo_diff')[1][sl] = r[3]
                 numpy.asarray(zch[1]).ravel()[0] = rec + 1
         if stopAtNan and not numpy.all(numpy.isfinite(hl2)):
             raise FloatingPointError("NaN in the residual of zone %s at iteration %d" % (z[0], nitrun))

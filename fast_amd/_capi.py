@@ -20,7 +20,7 @@ SYMBOLS = [
     "fs_rotate", "fs_fill_ghostcells", "fs_apply_bc", "fs_residuals", "fs_residual_history", "fs_cfl", "fs_tgv_sums", "fs_tgv_sums_static", "fs_sync",
     "fs_stage_kernel_ms", "fs_debug_fetch",
     "fs_comm_unique_id", "fs_comm_init", "fs_zone_set_global_id", "fs_send_add_remote", "fs_comm_setup", "fs_halo_exchange",
-    "fs_comm_allreduce", "fs_joins_set", "fs_stream_triad",
+    "fs_comm_allreduce", "fs_joins_set", "fs_stream_triad", "fs_host_alloc", "fs_host_free",
 ]
 
 COMM_ID_BYTES = 128
@@ -52,6 +52,28 @@ def lib():
                 f.restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+def pinned_empty(n, device=0):
+    """n float64 of page-locked host memory as a numpy array (fs_host_alloc), released when the array and its views
+    are gone; None where the runtime has none to give (no GPU: the caller allocates ordinary memory).
+    FASTS_HIP_PIN=0: never."""
+    import weakref
+    import numpy
+    if os.environ.get('FASTS_HIP_PIN', '1') == '0' or n <= 0:
+        return None
+    try:
+        L = lib()
+    except (FastsHipError, OSError):
+        return None
+    p = ctypes.c_void_p()
+    L.fs_host_alloc.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    L.fs_host_free.argtypes = [ctypes.c_void_p]
+    if L.fs_host_alloc(ctypes.c_int(int(device)), ctypes.byref(p), ctypes.c_size_t(8 * int(n))) != 0 or not p.value:
+        return None
+    raw = (ctypes.c_double * int(n)).from_address(p.value)
+    weakref.finalize(raw, L.fs_host_free, ctypes.c_void_p(p.value))
+    return numpy.frombuffer(raw, dtype=numpy.float64)
 
 
 def _pi(a):

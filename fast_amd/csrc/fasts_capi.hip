@@ -83,6 +83,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &zn : ctx->zones) {
     for (int r = 0; r < 3; r++) (void)hipFree(zn.dev[r]);
+    for (int r = 0; r < 3; r++) if (zn.pinned[r]) { if (hipHostUnregister(zn.pinned[r]) != hipSuccess) (void)hipGetLastError(); }
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
@@ -99,6 +100,24 @@ extern "C" void fs_destroy(fs_ctx *ctx)
   for (auto &p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+}
+
+// Host memory for the caller's level buffers that the host link copies in place (page-locked, known to the
+// runtime): fs_upload / fs_download then run at the rate of the link instead of through a pageable staging copy.
+extern "C" int fs_host_alloc(int device, void **ptr, size_t nbytes)
+{
+  if (!ptr || nbytes == 0) return FS_ERR_ARG;
+  *ptr = nullptr;
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return FS_ERR_HIP; }
+  if (hipHostMalloc(ptr, nbytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *ptr = nullptr; return FS_ERR_HIP; }
+  return FS_OK;
+}
+
+extern "C" int fs_host_free(void *ptr)
+{
+  if (!ptr) return FS_OK;
+  if (hipHostFree(ptr) != hipSuccess) { (void)hipGetLastError(); return FS_ERR_HIP; }
+  return FS_OK;
 }
 
 extern "C" int fs_set_stream(fs_ctx *ctx, void *hip_stream)
@@ -746,6 +765,21 @@ extern "C" int fs_upload(fs_ctx *ctx)
       if (!zn.rhs_bc.empty()) {
         HIPCHK(ctx, hipMalloc(&zn.rhs_bc_dev, sizeof(FsBcWin) * zn.rhs_bc.size()));
         HIPCHK(ctx, hipMemcpy(zn.rhs_bc_dev, zn.rhs_bc.data(), sizeof(FsBcWin) * zn.rhs_bc.size(), hipMemcpyHostToDevice));
+      }
+    }
+    // The level buffers belong to the caller (numpy arrays of the pyTree: pageable memory, copied through a staging
+    // buffer at a third of the link's rate).  Registered once, they are copied in place.  FASTS_HIP_PIN=0: leave them;
+    // a refusal of the runtime (locked-memory limit) is not an error either.
+    {
+      static const bool pin = !(getenv("FASTS_HIP_PIN") && atoi(getenv("FASTS_HIP_PIN")) == 0);
+      for (int r = 0; r < 3 && pin; r++) {
+        bool have = false;
+        for (int q = 0; q < 3; q++) have = have || zn.pinned[q] == (void *)zn.host[r];
+        if (have) continue;
+        if (hipHostRegister(zn.host[r], nb, hipHostRegisterDefault) == hipSuccess) {
+          for (int q = 0; q < 3; q++) if (!zn.pinned[q]) { zn.pinned[q] = zn.host[r]; break; }
+        } else
+          (void)hipGetLastError();
       }
     }
     for (int r = 0; r < 3; r++)

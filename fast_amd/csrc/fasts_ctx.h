@@ -12,6 +12,8 @@ struct Zone {
   std::vector<int32_t> pint;
   std::vector<double> preal;
   double *host[3] = {nullptr, nullptr, nullptr};  // roles: 0 = N, 1 = M1, 2 = P1
+  void *pinned[3] = {nullptr, nullptr, nullptr};  // host level buffers registered with the runtime (fs_upload), so that
+                                                  // fs_upload / fs_download move them at the rate of the host link
   double *dev[3] = {nullptr, nullptr, nullptr};
   double *drodm = nullptr, *xmut = nullptr, *wig = nullptr;
   double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]

@@ -574,6 +574,53 @@ class RefSolver:
         from .oracle import assemble_rdm
         return [assemble_rdm(zn.pint, zn.preal, zn.rdm, int(zn.pint[NSSITER]), zn.it_bloc) for zn in self.zones]
 
+    def display_reference(self, nitrun, names, history, lft=1, iverb=0, record=True):
+        """dpssiter_ and conv2pytree_ of the compiled reference for every zone, driven as
+        Fast/FastS/FastS/DISPLAY/display_ss_iteration.cpp:107-175 drives them after a verification step: the norms
+        assembled from the cprdu3s1 table go to dpssiter_ as rdm(it_bloc, neq, 2), which prints the table of the
+        sub-iterations and fills cvg(4 neq); conv2pytree_ appends the record to the zone's convergence history.
+        history[nd] = dict(last=int32[1], itnum=int32[nrec], l2, oo, l2_diff, oo_diff = float64[neq * nrec]), the
+        arrays of the ZoneConvergenceHistory node (Fast/FastS/FastS/PyTree.py:1955-1990), updated in place.
+        record = False: dpssiter_ only (nothing is appended).  Returns what the reference printed (a string)."""
+        import tempfile
+        L = lib()
+        L._FortranAioBeginFlush.restype = ctypes.c_void_p
+        L._FortranAioBeginFlush.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L._FortranAioEndIoStatement.argtypes = [ctypes.c_void_p]
+
+        def flush6():
+            L._FortranAioEndIoStatement(L._FortranAioBeginFlush(6, None, 0))
+
+        from .oracle import assemble_rdm
+        with tempfile.TemporaryFile() as tmp:
+            flush6()
+            saved = os.dup(1)
+            os.dup2(tmp.fileno(), 1)
+            try:
+                for nd, zn in enumerate(self.zones):
+                    neq, nssiter = zn.neq, int(zn.pint[NSSITER])
+                    l2, loo = assemble_rdm(zn.pint, zn.preal, zn.rdm, nssiter, zn.it_bloc)
+                    glob = np.zeros(2 * neq * zn.it_bloc)
+                    for ne in range(neq):       # display_ss_iteration.cpp:137-141
+                        glob[zn.it_bloc * ne:zn.it_bloc * (ne + 1)] = l2[:, ne]
+                        glob[zn.it_bloc * (ne + neq):zn.it_bloc * (ne + neq + 1)] = loo[:, ne]
+                    cvg = np.zeros(4 * neq)
+                    name = names[nd].encode()
+                    L.dpssiter_(_i(nitrun), _i(neq), _i(zn.it_bloc), _i(nssiter), _p(zn.pint), _i(lft), _i(iverb),
+                                ctypes.c_char_p(name), _i(len(name)), _p(glob), _p(cvg))
+                    if not record:
+                        continue
+                    h = history[nd]
+                    L.conv2pytree_(_p(cvg), _i(nitrun), _i(neq), _p(h['last']), ctypes.c_char_p(name), _i(len(name)),
+                                   _i(lft), _i(h['itnum'].size), _i(nd), _p(h['itnum']), _p(h['l2']), _p(h['oo']),
+                                   _p(h['l2_diff']), _p(h['oo_diff']))
+                flush6()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+            tmp.seek(0)
+            return tmp.read().decode()
+
     def tgv_sums(self):
         """Per zone [enstrophy sum, kinetic-energy sum, volume] of the current state: post_ of the compiled reference
         (POST/post.for: velocity gradient of cp_gradu with the 4-point face average c1 = 7/12, c2 = 1/12, then

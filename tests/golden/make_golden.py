@@ -9,7 +9,9 @@ Each file holds the inputs (Parameter_int, Parameter_real, metrics, initial fiel
 ghost fill, join tables) and the reference's outputs (field after 1, 3 and `nit` time steps and
 the per-step residual norms of the first sub-iteration; for the implicit scheme `reshist` holds the norms of
 every Newton sub-iteration of every step, out of the reference's own cprdu3s1 with every step treated as a
-verification step).  Cases marked 'single' run the
+verification step, `disp_text` what the reference's dpssiter_ prints after each step, `disp_text_long_all` the long
+format with every sub-iteration after the last step, and `zch_*` the ZoneConvergenceHistory arrays that its
+conv2pytree_ has filled by then).  Cases marked 'single' run the
 reference with one cache block per zone (cache_blocking_I/J/K larger than the zone), the
 configuration in which its floating-point operation order is reproducible by a plain loop nest;
 'default' keeps the reference's default cache blocking (2048,2,7), whose results differ from
@@ -171,8 +173,18 @@ def main():
         res = np.zeros((nit, nb, 2, 5))
         nssiter = int(rz[0].pint[58]); neq = rz[0].neq
         hist = np.zeros((nit, nb, nssiter, 2, neq))
+        # convergence history and printed table of the reference's own display routines (dpssiter_, conv2pytree_)
+        nrec = nit + 2
+        zch = [dict(last=np.zeros(1, dtype=np.int32), itnum=np.zeros(nrec, dtype=np.int32), l2=np.zeros(neq * nrec),
+                    oo=np.zeros(neq * nrec), l2_diff=np.zeros(neq * nrec), oo_diff=np.zeros(neq * nrec)) for _ in range(nb)]
+        disp = []
+        znames = [z[0] for z in zones]
         for it in range(1, nit + 1):
             s.step(it)
+            if implicit:
+                disp.append(s.display_reference(it, znames, zch, lft=1, iverb=0))
+                if it == nit:
+                    out['disp_text_long_all'] = np.array(s.display_reference(it, znames, zch, lft=0, iverb=2, record=False))
             if implicit:     # norms of every Newton sub-iteration, from cprdu3s1_ of the compiled reference
                 for b, (l2, loo) in enumerate(s.residual_history()):
                     hist[it - 1, b, :, 0] = l2; hist[it - 1, b, :, 1] = loo
@@ -189,6 +201,11 @@ def main():
             out['tgvsums'] = np.array(s.tgv_sums())
         if implicit:
             out['reshist'] = hist
+            out['disp_text'] = np.array(disp)
+            out['zone_names'] = np.array(znames)
+            for b in range(nb):
+                for key in ('last', 'itnum', 'l2', 'oo', 'l2_diff', 'oo_diff'):
+                    out['zch_%s_%d' % (key, b)] = zch[b][key]
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **out)
         print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024.))

@@ -42,6 +42,27 @@ def test_many_steps_bit_exact(n, scheme, nit):
         os.environ.pop('FASTS_HIP_LAZY_SYNC', None)
 
 
+def test_config1_vortex_64_roe_hundred_steps_bit_exact():
+    """The first benchmark configuration as it is named: single Cartesian block of 64^3 cells, inviscid isentropic
+    vortex, explicit RK3 + roe (o3 slopes), six periodic faces, 100 time steps: the field after every tenth step
+    equals the CPU restatement's bit for bit."""
+    os.environ['FASTS_HIP_LAZY_SYNC'] = '1'
+    try:
+        t, metrics, z, oz = _pair(cases.vortex(64, 'roe', extra_numz=SINGLE))
+        p = zone_arrays(z)[0]
+        assert (int(p[20]), int(p[21]), int(p[22])) == (64, 64, 64) and int(p[33]) == 5 and int(p[27]) == 1 and int(p[64]) == 2
+        for it in range(1, 101):
+            FastS._compute(t, metrics, it, None)
+            oz.step()
+            if it % 10 == 0:
+                FastS.sync_to_host(t)
+                got = FastC.level_buffer(z)
+                assert np.array_equal(got, oz.ro), "step %d: max abs diff %g" % (it, np.abs(got - oz.ro).max())
+        assert np.isfinite(got).all()
+    finally:
+        os.environ.pop('FASTS_HIP_LAZY_SYNC', None)
+
+
 @pytest.mark.parametrize("scheme,bcs", [('senseur', None), ('roe_min', {'jmin': 'BCWall', 'jmax': 'BCOutflow'})])
 def test_curvilinear_hundred_steps_bit_exact(scheme, bcs):
     """100 steps on a curvilinear 48 x 40 x 36 zone (several patches and k chunks of the stage kernel that keeps the state
@@ -72,6 +93,7 @@ def test_sa_hundred_steps():
         FastS._compute(t, metrics, it, None)
         oz.step()
     e = rel_err(FastC.level_buffer(z), oz.ro, nd, neq=6)
+    print("SA, 100 steps: largest relative error per equation %s; margin to 1e-11: x%.0f" % (e, 1e-11 / max(e.max(), 1e-300)))
     assert e.max() < 1e-11, e
 
 
