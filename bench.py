@@ -321,11 +321,13 @@ def main():
     if rank == 0:
         # HBM bytes per launch from the PMC passes of this same command (collected in runs of their
         # own by profiles/run_profiles.sh; counters cannot be read inside a timed run)
-        traffic = None
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic_%s_%d%s.json' % (a.scheme, a.n, '_curvilinear' if a.perturb else ''))
-        if os.path.exists(tf) and not a.naca:
+        if os.path.exists(tf) and not a.naca and world == 1 and not a.implicit and not a.channel:
             with open(tf) as fh:
                 traffic = json.load(fh).get('traffic_bytes_per_launch')
+            traffic_source = ("not measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this "
+                              "command, recorded in profiles/%s" % os.path.basename(tf))
         # algorithmic bytes per launch; per-cell metrics (9 surface-vector components + volume) are read once per stage
         bpl = (BYTES_PER_CELL_STEP[a.scheme] + (240.0 if (a.perturb or a.naca) else 0.)) / 3.0 * (ncell_total // world // nblk)
         ach = bpl / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.
@@ -354,7 +356,7 @@ def main():
                                       (", LU-SGS in the blocks of %d threads" % a.lu_threads if a.lu_threads > 1 else "")
                                       if a.implicit else "explicit RK3"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": bpl, "avg_launch_ms": k_ms, "launches": k_n,
                          # what a plain streaming kernel reaches on this device, measured in this run (3 x 1 GiB triad)
                          "stream_triad": triad, "frac_of_stream_triad": ach / triad if triad else None},
