@@ -860,9 +860,12 @@ static int build_shell_lists(fs_ctx *ctx)
     const FsZone &z = zn.z;
     for (auto &s : ctx->sends) if (s.donor_zone == (int)nz) zn.has_sends = true;
     for (auto &j : ctx->joins) if (j.donor_zone < 0 && j.rcv_zone == (int)nz) zn.has_recvs = true;
-    if (z.ityp == 0 || ctx->implicit || z.iflow == 3 || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1) continue;   // these zones run their stage in one piece
+    // implicit zones, roe + walls and the local time step run their stage in one piece (later kernels of the stage read
+    // the whole balance); so do Spalart-Allmaras zones on Cartesian meshes (their stage kernel takes no tile list)
+    if (ctx->implicit || (z.iflow == 3 && z.ityp != 0) || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1) continue;
     zn.z.split = zn.has_sends ? 1 : 0;
-    const FsTiling t = fsk_stage_dma_tiling(z);
+    // tiles of the Cartesian stage kernel, patches (owned cells) of the curvilinear one
+    const FsTiling t = z.ityp == 0 ? fsk_stage_full_tiling(zn.z) : fsk_stage_dma_tiling(zn.z);
     const int nblk = t.nti * t.ntj * t.ntk;
     std::vector<char> mark((size_t)nblk, 0);
     bool any = false;
@@ -967,10 +970,13 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     if (z.iflow == 3 && z.ityp != 0)
       krc = fsk_stage_sa(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut, zn.dist,
                          (unsigned char *)zn.wig, kbdf, keep, ctx->stream);
-    else if (z.ityp == 0)
-      krc = fsk_stage_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
-                           (unsigned char *)zn.wig, kbdf, zn.dist, keep, ctx->stream);
-    else {
+    else if (z.ityp == 0) {
+      const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
+      const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
+      if (!split || nlist > 0)
+        krc = fsk_stage_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
+                             (unsigned char *)zn.wig, kbdf, zn.dist, keep, blist, nlist, ctx->stream);
+    } else {
       const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
       const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
       if (!split || nlist > 0)

@@ -48,9 +48,12 @@ int fsk_stage_dma(const FsZone &z, double coefH, double coefW, int first, const 
                   double *drodm, const double *xmut, unsigned char *wig, const int *blist, int nlist, const FsBdf *bdf,
                   int keep_balance, hipStream_t s);
 // stage kernel of curvilinear zones (zone type 0, fasts_stage_full.hip); sensors stored as bytes
+// blist / nlist: a subset of the patches (numbered px + nti * (py + ntj * pz) in the grid of fsk_stage_full_tiling);
+// NULL = all of them
+FsTiling fsk_stage_full_tiling(const FsZone &z);
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                    double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, const double *dist,
-                   int keep_balance, hipStream_t s);
+                   int keep_balance, const int *blist, int nlist, hipStream_t s);
 void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
 // Spalart-Allmaras on Cartesian zones (fasts_stage_sa.hip): total viscosity on the whole zone, stage kernel
 void fsk_vispalart(const FsZone &z, const double *rop, double *xmut, hipStream_t s);

@@ -206,7 +206,8 @@ template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO = fals
 __global__ void __launch_bounds__(256)
 k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
-             unsigned char *__restrict__ wig, FsBdf bdf, const double *__restrict__ dlng)
+             unsigned char *__restrict__ wig, FsBdf bdf, const double *__restrict__ dlng,
+             const int *__restrict__ blist, int npx, int npy, int npz)
 {
   constexpr int NQ = IFLOW == 3 ? 6 : 5;   // Spalart-Allmaras: 6th variable nu_tilde
   __shared__ double sfj[2][NQ][TJ][TI];
@@ -218,13 +219,16 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
   // patches overlap by their halo (36 x 12 cells staged for 31 x 7 owned) and read the same metrics at their borders,
   // and now mostly meet in one L2 (256^3: the Euler variants 1.55 -> 1.50 ms per stage; the laminar ones, which are not
   // bound by memory, unchanged at 2.18 ms).
+  // blist: a subset of the patches (a one-dimensional grid over the list; patch number = px + npx * (py + npy * pz)):
+  // the stage of a zone whose cells feed halo messages runs in two launches, those patches first.
   int pbx, pby, pbz;
   {
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
     unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const unsigned q8 = total / 8, r8 = total % 8, x = lin % 8;
     lin = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + lin / 8;
-    pbx = (int)(lin % gridDim.x); pby = (int)((lin / gridDim.x) % gridDim.y); pbz = (int)(lin / (gridDim.x * gridDim.y));
+    if (blist) lin = (unsigned)blist[lin];
+    pbx = (int)(lin % (unsigned)npx); pby = (int)((lin / (unsigned)npx) % (unsigned)npy); pbz = (int)(lin / (unsigned)(npx * npy));
   }
   const int i = 1 + pbx * OI + ti, j = 1 + pby * OJ + tj;
   const int k0 = 1 + pbz * kchunk;
@@ -426,10 +430,12 @@ void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, do
 template <int K, int F, bool FIRST_, bool BDF_>
 static void launch_full(const FsZone &z, dim3 g, hipStream_t s, double coefH, double coefW, int kchunk, int keep_balance,
                         const double *rop, double *rop_out, double *drodm, const double *xmut, unsigned char *wig,
-                        const FsBdf &b, const double *dist)
+                        const FsBdf &b, const double *dist, const int *blist, int nlist)
 {
+  const int npx = (int)g.x, npy = (int)g.y, npz = (int)g.z;
+  if (blist) g = dim3((unsigned)nlist, 1, 1);
 #define FS_L(...) hipLaunchKernelGGL((k_stage_full<__VA_ARGS__>), g, dim3(256), 0, s, z, coefH, coefW, kchunk, keep_balance, rop, \
-                                     rop_out, drodm, xmut, wig, b, dist)
+                                     rop_out, drodm, xmut, wig, b, dist, blist, npx, npy, npz)
   if (z.twod) { FS_L(K, F, FIRST_, BDF_, true); return; }
   if constexpr (F == 2) {
     if (z.homo) FS_L(K, F, FIRST_, BDF_, false, true, true);
@@ -443,22 +449,33 @@ static void launch_full(const FsZone &z, dim3 g, hipStream_t s, double coefH, do
 #undef FS_L
 }
 
+FsTiling fsk_stage_full_tiling(const FsZone &z)
+{
+  FsTiling t;
+  t.ti = OI; t.tj = OJ; t.pace = 0;
+  t.kchunk = 16;   // 256^3 senseur laminar: 2.18 ms per stage; 8: 2.21, 32: 2.26, 64: 2.47 (workgroups in flight per CU)
+  if (const char *ev = getenv("FASTS_HIP_KCHUNK_FULL")) {
+    int v = atoi(ev);
+    if (v >= 1) t.kchunk = v;
+  }
+  if (t.kchunk > z.kv) t.kchunk = z.kv;
+  t.nti = (z.iv + OI - 1) / OI; t.ntj = (z.jv + OJ - 1) / OJ; t.ntk = (z.kv + t.kchunk - 1) / t.kchunk;
+  return t;
+}
+
 int fsk_stage_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                    double *drodm, const double *xmut, unsigned char *wig, const FsBdf *bdf, const double *dist,
-                   int keep_balance, hipStream_t s)
+                   int keep_balance, const int *blist, int nlist, hipStream_t s)
 {
   if (z.ityp != 0 || !z.vol || !z.mt[0] || !z.mt[1] || !z.mt[2]) return -1;
   if (z.iflow == 3 && (z.neq != 6 || !dist)) return -1;
-  int kchunk = 16;   // 256^3 senseur laminar: 2.18 ms per stage; 8: 2.21, 32: 2.26, 64: 2.47 (workgroups in flight per CU)
-  if (const char *ev = getenv("FASTS_HIP_KCHUNK_FULL")) {
-    int v = atoi(ev);
-    if (v >= 1) kchunk = v;
-  }
-  if (kchunk > z.kv) kchunk = z.kv;
-  dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
+  if (blist && nlist <= 0) return 0;
+  const FsTiling t = fsk_stage_full_tiling(z);
+  const int kchunk = t.kchunk;
+  dim3 g(t.nti, t.ntj, t.ntk);
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
-#define FS_GO(K, F, FIRST_, BDF_) launch_full<K, F, FIRST_, BDF_>(z, g, s, coefH, coefW, kchunk, keep_balance, rop, rop_out, drodm, xmut, wig, b, dist)
+#define FS_GO(K, F, FIRST_, BDF_) launch_full<K, F, FIRST_, BDF_>(z, g, s, coefH, coefW, kchunk, keep_balance, rop, rop_out, drodm, xmut, wig, b, dist, blist, nlist)
 #define FS_CASE(K, F)                                                                                         \
   if (z.kflu == K && z.iflow == F) {                                                                          \
     if (bdf) { if (first) FS_GO(K, F, true, true); else FS_GO(K, F, false, true); }                           \

@@ -28,6 +28,8 @@ def _run(n, blocks, model, loopback, nsteps, opts, flat=False):
     ((2, 1, 2), 70, 'Euler', {}),                         # blocks wider than one tile: several tiles feed a message
     ((1, 2, 1), 10, 'NSLaminar', {'time_step': 0.02, 'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': 3}}),
     ((1, 1, 2), 10, 'NSTurbulent', {}),                   # 6 variables per cell in the messages
+    ((1, 2, 1), 40, 'NSLaminar', {'perturb': 0.15}),      # curvilinear, several patches: donors' patches run first
+    ((2, 1, 1), 36, 'NSTurbulent', {'perturb': 0.1}),
 ])
 def test_self_send_matches_local_joins(blocks, n, model, opts):
     _, first_l, last_l = _run(n, blocks, model, False, 3, opts)
