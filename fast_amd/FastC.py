@@ -160,7 +160,8 @@ def _buildOwnData(t, Padding=None):
     temporal_scheme = _get(d, 'temporal_scheme', 'implicit')
     ss_iteration = int(_get(d, 'ss_iteration', 30))
     rk = int(_get(d, 'rk', 3))
-    modulo_verif = int(_get(d, 'modulo_verif', 200))
+    # 'implicit_local' changes the default period of the verification steps (Fast/FastC/FastC/PyTree.py:1134)
+    modulo_verif = int(_get(d, 'modulo_verif', 7 if temporal_scheme == 'implicit_local' else 200))
     restart_fields = int(_get(d, 'restart_fields', 1))
     ompmode = int(_get(d, 'omp_mode', OMP_MODE))
     exploc = 0
@@ -279,7 +280,13 @@ def _buildOwnData(t, Padding=None):
                 raise ValueError("fast_amd: motion '%s' is not supported (none only)." % motion)
             lale = 0
             itypcp = 2 if temporal_scheme == 'explicit' else 1
+            # blocks of the Newton residual; with 'implicit_local' also the grain of the sub-zones
+            # (Fast/FastC/FastC/PyTree.py:1305,1678-1694)
             size_ssdom = [100, 10, 10]
+            if temporal_scheme == 'implicit_local':
+                size_ssdom = [int(v) for v in numpy.asarray(_get(dz, 'ssdom_IJK', [240, 20, 900])).reshape(-1)[:3]]
+                if len(size_ssdom) != 3 or min(size_ssdom) < 1:
+                    raise ValueError("fast_amd: ssdom_IJK must hold three positive block sizes.")
             islope = {'o1': 1, 'o2': 4, 'o3': 2, 'o5': 5, 'minmod': 3, 'o3sc': 6, 'o5sc': 7}.get(slope, 2)
             if scheme == 'ausmpred': kfludom = 1
             elif scheme == 'senseur': kfludom = 2

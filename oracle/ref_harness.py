@@ -196,6 +196,11 @@ class RefSolver:
         self.stage1_rhs = None
         # OpenMP threads of the RHS + update (oracle/ref_mt.c drives the reference's own thread decomposition and locks)
         self.threads = 1
+        # 'implicit_local' (lssiter_loc = 1): Newton sub-iterations on the sub-zones that have not converged; kmod =
+        # modulo_verif, the period of the verification steps that re-evaluate them
+        self.local = False
+        self.kmod = 1
+        self._sz_ready = False
 
     # -- one sub-iteration of one zone: RHS + update -------------------------------------
     def _navier_stokes(self, nd, zn, nitrun, nstep, ro_ssiter):
@@ -411,12 +416,14 @@ class RefSolver:
         p = zn.pint
         pt_bcs = int(p[PT_BC]); nb_bc = int(p[pt_bcs])
         lskip = [1] * 6
+        itest = [1, zn.iv, 1, zn.jv, 1, zn.kv]
         for ndf in range(nb_bc):
             pt_bc = int(p[pt_bcs + 1 + ndf]); bt = int(p[pt_bc]); ipara = int(p[pt_bc + 1]) - 1
             if (3 <= bt <= 7) or bt in (12, 18, 30):
                 if bt in (12, 18, 30) or (bt == 4 and p[IFLOW] == 1 and False):
                     raise NotImplementedError("ref_harness: implicit treatment of BC tag %d" % bt)
-                lskip[ipara] = 0
+                if zn.ind_dm[ipara] == itest[ipara]:      # BCzone.cpp:101: the range of the thread reaches the face
+                    lskip[ipara] = 0
         shift = zn.ind_dm.copy()
         for d in range(3):
             shift[2 * d] -= (1 - lskip[2 * d]); shift[2 * d + 1] += (1 - lskip[2 * d + 1])
@@ -689,12 +696,172 @@ class RefSolver:
         for zn in self.zones:
             zn.ro_m1, zn.ro, zn.ro_p1 = zn.ro, zn.ro_p1, zn.ro_m1
 
+    # -- 'implicit_local': Newton sub-iterations on sub-zones ----------------------------------------------------
+    def _sz_setup(self):
+        """ind_dm / it_lu_ssdom arrays of every zone, sized and filled as
+        Fast/FastS/FastS/Metric/allocate_metric.cpp:398-471 does, the table of skip_lu, and the calls of
+        souszones_list that warmup makes (Fast/FastS/FastS/PyTree.py:391-394: nitrun = 1, every sub-iteration, both
+        passes because no list exists yet)."""
+        z0 = self.zones[0]
+        nssiter = int(z0.pint[NSSITER])
+        self.iskip_lu = np.zeros(2 * nssiter, dtype=np.int32)
+        self.dtloc = np.zeros(16, dtype=np.int32)
+        for zn in self.zones:
+            p = zn.pint
+            ijkv = p[IJKV:IJKV + 3]; ss = p[SIZE_SSDOM:SIZE_SSDOM + 3]
+            zn.ijkv_lu = np.array([max(1, int(ijkv[d]) // int(ss[d])) for d in range(3)], dtype=np.int32)
+            n = int(np.prod(zn.ijkv_lu)); mx = int(p[MXSSDOM_LU])
+            assert mx >= n
+            zn.sz_n = n; zn.sz_mx = mx
+            zn.ind_dm_tab = np.zeros(6 * mx * nssiter + 2 * nssiter + 1, dtype=np.int32)
+            zn.it_tab = np.zeros(5 * mx, dtype=np.int32)
+            zn.it_tab[0:2 * mx] = nssiter
+            zn.it_tab[4 * mx:5 * mx] = np.arange(1, mx + 1)
+            zn.rdm = np.zeros(nssiter * zn.neq * 2 * n)
+        for nstep in range(1, nssiter + 1):
+            self._souszones_c(1, nstep, 1)
+            self._souszones_c(0, nstep, 0)
+        self._sz_ready = True
+
+    def _sz_views(self, zn):
+        nssiter = int(zn.pint[NSSITER]); mx = zn.sz_mx
+        t = zn.ind_dm_tab; q = 6 * mx * nssiter
+        return dict(ind_dm=t[0:q], nisdom_residu=t[q:q + nssiter], nidom_loc=t[q + nssiter:q + 2 * nssiter],
+                    it_bloc=t[q + 2 * nssiter:], it_lu=zn.it_tab[0:mx], it_target=zn.it_tab[mx:2 * mx],
+                    it_target_old=zn.it_tab[2 * mx:3 * mx], it_temp=zn.it_tab[3 * mx:4 * mx], no_lu=zn.it_tab[4 * mx:])
+
+    def _souszones_c(self, nitrun, nstep, flag_res):
+        """souszones_list_c for every zone (Fast/FastC/FastC/Compute/souszones_list.cpp:45-79): init_ssiter_bloc_ of the
+        compiled reference on the arrays of the zone."""
+        L = lib()
+        for nd, zn in enumerate(self.zones):
+            p = zn.pint
+            v = self._sz_views(zn)
+            nssiter = int(p[NSSITER])
+            ijk_lu = np.zeros(3 * zn.sz_mx, dtype=np.int32)
+            L.init_ssiter_bloc_(_i(nd), _i(nstep), _i(nssiter), _i(nitrun), _i(1), _i(p[ITYPCP]), _i(flag_res),
+                                _p(np.ascontiguousarray(p[IJKV:IJKV + 3])), _p(zn.ijkv_lu), _p(ijk_lu),
+                                _p(np.ascontiguousarray(p[SIZE_SSDOM:SIZE_SSDOM + 3])), _i(zn.sz_mx), _p(self.iskip_lu),
+                                _p(self.dtloc), _p(v['ind_dm']), _p(v['nidom_loc']), _p(v['it_bloc']),
+                                _p(v['nisdom_residu']), _p(v['it_lu']), _p(v['it_target']), _p(v['it_target_old']),
+                                _p(v['no_lu']), _p(p))
+
+    def _souszones(self, nitrun, nstep):
+        """souszones_list as Fast/FastS/FastS/PyTree.py:122 calls it before every sub-iteration
+        (Fast/FastC/FastC/Compute/souszones_list.cpp:161-196 with lssiter_loc = 1): returns (lexit_lu, lssiter_verif)."""
+        nssiter = int(self.zones[0].pint[NSSITER])
+        kmod = self.kmod
+        lexit_lu = lssiter_verif = 0
+        init_exit = 0
+        if nitrun % kmod == 0:
+            init_exit = 1
+            self._souszones_c(nitrun, nstep, 1)
+            lssiter_verif = 1
+            lexit_lu = 1 if nstep == nssiter else 0
+        if (nitrun - 1) % kmod == 0:
+            self._souszones_c(nitrun - 1, nstep, 0)
+            lssiter_verif = 1
+            lexit_lu = 1 if nstep == nssiter else 0
+            if init_exit == 0:
+                lexit_lu = lssiter_verif = 0
+                init_exit = 2
+            if kmod == 1:
+                lssiter_verif = 1
+                lexit_lu = 1 if nstep == nssiter else 0
+        if init_exit == 0:
+            lexit_lu = lssiter_verif = 0
+        return lexit_lu, lssiter_verif
+
+    def sub_zones(self, nd, nstep):
+        """Boxes (i1, i2, j1, j2, k1, k2) of zone nd at sub-iteration nstep."""
+        zn = self.zones[nd]
+        v = self._sz_views(zn)
+        nb = int(v['nidom_loc'][nstep - 1])
+        q = (nstep - 1) * 6 * zn.sz_mx
+        return [v['ind_dm'][q + 6 * s:q + 6 * s + 6].copy() for s in range(nb)]
+
+    def step_implicit_local(self, nitrun):
+        """One time step of 'implicit_local': as step_implicit, every zone cut at every sub-iteration into the boxes of
+        init_ssiter_bloc / ssdom_lu_ijk (one task per box: Fast/FastS/FastS/Compute/rhs.cpp:9-58, lhs.cpp:18-161,
+        bcs.cpp:14-41), the residual of cprdu3s1 per block of SIZE_SSDOM cells feeding the targets of the next
+        evaluation.  The joins move every point whatever the boxes (gsdr3.cpp:343-349)."""
+        L = lib()
+        if not self._sz_ready:
+            self._sz_setup()
+        z0 = self.zones[0]
+        nssiter = int(z0.pint[NSSITER])
+        assert z0.pint[ITYPCP] == 1
+        self.last_boxes = []
+        for nstep in range(1, nssiter + 1):
+            lexit_lu, verif = self._souszones(nitrun, nstep)
+            if verif == 0 and nstep == nssiter:
+                break
+            boxes = [self.sub_zones(nd, nstep) for nd in range(len(self.zones))]
+            self.last_boxes.append(boxes)
+            whole = [zn.ind_dm for zn in self.zones]
+            shifts = [[] for _ in self.zones]
+            try:
+                for nd, zn in enumerate(self.zones):
+                    ssiter = zn.ro if nstep == 1 else zn.ro_p1
+                    for box in boxes[nd]:
+                        zn.ind_dm = box
+                        self._navier_stokes(nd, zn, nitrun, nstep, ssiter)
+                    if nstep == 1:
+                        zn.stage1_rhs = zn.drodm.copy()
+                for nd, zn in enumerate(self.zones):
+                    p = zn.pint
+                    v = self._sz_views(zn)
+                    for s, box in enumerate(boxes[nd]):
+                        zn.ind_dm = box
+                        shifts[nd].append(self._bczone_rhs(nd, zn, nstep))
+                        if verif and s == 0:
+                            v['it_bloc'][0] += 1      # Compute/ssor.cpp:14-20
+                            zn.it_bloc = int(v['it_bloc'][0])
+                            L.cprdu3s1_(_i(nd), _i(nstep), _i(nssiter), _i(zn.neq), _i(zn.ndimdx), _i(zn.sz_n), _i(nitrun),
+                                        _i(p[IFLOW]), _i(p[ILES]), _i(1), _i(1), _i(0),
+                                        _i(zn.sz_mx), _i(zn.it_bloc), _d(zn.preal[EPSI_NEWTON]),
+                                        _p(np.ascontiguousarray(p[SIZE_SSDOM:SIZE_SSDOM + 3])), _p(v['nisdom_residu']),
+                                        _p(np.ascontiguousarray(p[NIJK:NIJK + 5])),
+                                        _p(np.ascontiguousarray(p[IJKV:IJKV + 3])), _p(zn.ijkv_lu), _p(box),
+                                        _p(v['it_lu']), _p(v['it_target']), _p(v['it_target_old']), _p(v['it_temp']),
+                                        _p(v['no_lu']), _p(zn.drodm), _p(zn.rdm))
+                sfd_now = nstep == (nssiter if verif else nssiter - 1)
+                if lexit_lu:
+                    for nd, zn in enumerate(self.zones):
+                        for box in boxes[nd]:
+                            zn.ind_dm = box
+                            self._sfd(zn, nitrun)
+                    continue
+                for nd, zn in enumerate(self.zones):
+                    ssiter = zn.ro if nstep == 1 else zn.ro_p1
+                    dummy = np.zeros(8)
+                    for box, shift in zip(boxes[nd], shifts[nd]):
+                        L.invlu_(_i(nd), _i(nstep), _i(nitrun), _p(zn.pint), _p(zn.preal), _p(shift), _p(box), _i(1),
+                                 _p(zn.ro_p1), _p(ssiter), _p(zn.drodm), _p(zn.drodm),
+                                 _p(zn.ti), _p(zn.tj), _p(zn.tk), _p(zn.ro), _p(zn.ro), _p(zn.ro),
+                                 _p(zn.coe), _p(dummy), _i(1))
+                        if sfd_now:
+                            zn.ind_dm = box
+                            self._sfd(zn, nitrun)
+                cl = [zn.ro_p1 for zn in self.zones]
+                self._transfers(cl)
+                for nd, zn in enumerate(self.zones):
+                    for box in boxes[nd]:
+                        zn.ind_dm = box
+                        self._bczone(nd, zn, nstep, cl[nd])
+            finally:
+                for zn, w in zip(self.zones, whole):
+                    zn.ind_dm = w
+        self.first_it = 1
+        for zn in self.zones:
+            zn.ro_m1, zn.ro, zn.ro_p1 = zn.ro, zn.ro_p1, zn.ro_m1
+
     def step(self, nitrun):
         """One time step = nssiter sub-iterations, then M1 <- N <- P1 rotation."""
         z0 = self.zones[0]
         nssiter = int(z0.pint[NSSITER])
         if z0.pint[ITYPCP] == 1:
-            return self.step_implicit(nitrun)
+            return self.step_implicit_local(nitrun) if self.local else self.step_implicit(nitrun)
         assert z0.pint[ITYPCP] == 2, "RefSolver.step: explicit and implicit (LU-SGS) schemes only"
         for nstep in range(1, nssiter + 1):
             cl = []
