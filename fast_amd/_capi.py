@@ -21,6 +21,7 @@ SYMBOLS = [
     "fs_stage_kernel_ms", "fs_debug_fetch",
     "fs_comm_unique_id", "fs_comm_init", "fs_zone_set_global_id", "fs_send_add_remote", "fs_comm_setup", "fs_halo_exchange",
     "fs_comm_allreduce", "fs_joins_set", "fs_stream_triad", "fs_host_alloc", "fs_host_free",
+    "fs_subzone_skip_lu", "fs_subzone_boxes", "fs_subzone_residual",
 ]
 
 COMM_ID_BYTES = 128

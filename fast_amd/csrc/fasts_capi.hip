@@ -305,6 +305,55 @@ extern "C" int fs_zone_set_lu_blocks(fs_ctx *ctx, int zone, int nblocks, const i
   return FS_OK;
 }
 
+// ---- sub-zones of 'implicit_local': the host logic on plain arrays (fasts_subzones.hip) ----------------------------
+extern "C" int fs_subzone_skip_lu(int nitmax, int mx_ssiter, int32_t *iskip_lu)
+{
+  if (!iskip_lu || mx_ssiter < 1 || nitmax > mx_ssiter) return FS_ERR_ARG;
+  fsz_skip_lu(nitmax, mx_ssiter, iskip_lu);
+  return FS_OK;
+}
+
+extern "C" int fs_subzone_boxes(const int32_t *ijkv, const int32_t *size_ssdom, int iseuil, const int32_t *it_target,
+                                int32_t *no_lu, int32_t *count, int32_t *ind_dm, int max_boxes)
+{
+  if (!ijkv || !size_ssdom || !it_target || !no_lu || !count || !ind_dm || max_boxes < 0) return FS_ERR_ARG;
+  int nblk[3], size[3], iv[3];
+  for (int d = 0; d < 3; d++) {
+    if (ijkv[d] < 1 || size_ssdom[d] < 1) return FS_ERR_ARG;
+    iv[d] = ijkv[d]; size[d] = size_ssdom[d];
+    nblk[d] = ijkv[d] / size_ssdom[d] > 1 ? ijkv[d] / size_ssdom[d] : 1;
+  }
+  std::vector<int32_t> boxes;
+  const int nb = fsz_boxes(nblk, size, iv, iseuil, it_target, no_lu, count, boxes);
+  if (nb > max_boxes) return FS_ERR_ARG;
+  memcpy(ind_dm, boxes.data(), sizeof(int32_t) * boxes.size());
+  return nb;
+}
+
+extern "C" int fs_subzone_residual(const int32_t *ijkv, const int32_t *size_ssdom, int nssiter, int neq, int threed,
+                                   int nstep, int it_bloc, double epsi, const double *norms, const int32_t *no_lu,
+                                   int nis, int32_t *it_lu, int32_t *it_target, int32_t *it_target_old, int32_t *it_temp,
+                                   double *rdm)
+{
+  if (!ijkv || !size_ssdom || !norms || !no_lu || !it_lu || !it_target || !it_target_old || !it_temp || !rdm ||
+      nssiter < 1 || neq < 5 || neq > 6 || nstep < 1 || nstep > nssiter || it_bloc < 1 || it_bloc > nssiter)
+    return FS_ERR_ARG;
+  FsSubZones s;
+  int iv[3] = {ijkv[0], ijkv[1], ijkv[2]}, sz[3] = {size_ssdom[0], size_ssdom[1], size_ssdom[2]};
+  for (int d = 0; d < 3; d++) if (iv[d] < 1 || sz[d] < 1) return FS_ERR_ARG;
+  fsz_init(s, iv, sz, nssiter, neq, threed != 0);
+  const size_t n = (size_t)s.n;
+  s.it_lu.assign(it_lu, it_lu + n); s.it_target.assign(it_target, it_target + n);
+  s.it_target_old.assign(it_target_old, it_target_old + n); s.it_temp.assign(it_temp, it_temp + n);
+  s.rdm.assign(rdm, rdm + s.rdm.size());
+  s.it_bloc = it_bloc;
+  fsz_residual(s, nstep, epsi, norms, no_lu, nis);
+  memcpy(it_lu, s.it_lu.data(), sizeof(int32_t) * n); memcpy(it_target, s.it_target.data(), sizeof(int32_t) * n);
+  memcpy(it_target_old, s.it_target_old.data(), sizeof(int32_t) * n); memcpy(it_temp, s.it_temp.data(), sizeof(int32_t) * n);
+  memcpy(rdm, s.rdm.data(), sizeof(double) * s.rdm.size());
+  return FS_OK;
+}
+
 extern "C" int fs_set_first_it(fs_ctx *ctx, int first_it)
 {
   if (!ctx || (first_it != 0 && first_it != 1)) return FS_ERR_ARG;

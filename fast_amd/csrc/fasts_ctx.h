@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/fasts_hip.h"
 #include "fasts_kernels.h"
+#include "fasts_subzones.h"
 
 #include <string>
 #include <vector>

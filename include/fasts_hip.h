@@ -75,6 +75,37 @@ int fs_set_verif(fs_ctx *ctx, int modulo_verif);
  * M1 level sets 1 here. */
 int fs_set_first_it(fs_ctx *ctx, int first_it);
 
+/* 'implicit_local' (lssiter_loc = 1 in the reference's work dictionary, Fast/FastC/FastC/PyTree.py:2074-2076,2205, read by
+ * Fast/FastS/FastS/Compute/computePT.cpp:125-127): every Newton sub-iteration works on the sub-zones -- boxes of blocks
+ * of SIZE_SSDOM cells (Parameter_int[30..32]) -- whose residual had not dropped by EPSI_NEWTON at the last verification
+ * step (Fast/FastC/FastC/Compute/souszones_list.cpp:31-90, init_ssiter_bloc.for, ssdom_lu_ijk.for;
+ * Fast/FastS/FastS/Compute/cprdu3s1_incl.for:166-197).  0 (default) = every sub-iteration on the whole zones.  Implicit
+ * zones only, before fs_upload; not with LU thread blocks, nb_relax > 1, lu_match = 1 or roe with walls. */
+int fs_set_local_newton(fs_ctx *ctx, int lssiter_loc);
+
+/* The boxes (i1, i2, j1, j2, k1, k2; at most max_boxes) that zone `zone` works on at sub-iteration nstep, as last
+ * evaluated (ind_dm(6, :, nstep) and nidom_loc(nstep) of the reference's metrics[5] array,
+ * Fast/FastS/FastS/Metric/allocate_metric.cpp:398-440).  Returns their number. */
+int fs_subzone_list(fs_ctx *ctx, int zone, int nstep, int32_t *boxes, int max_boxes);
+/* it_target_ssdom of zone `zone` (one entry per block, metrics[6] of the reference); returns the number of blocks. */
+int fs_subzone_targets(fs_ctx *ctx, int zone, int32_t *it_target, int max_blocks);
+
+/* The host logic of the sub-zones on plain arrays, no context and no device: the routines of the reference they
+ * restate are called on the same inputs by the tests.
+ * fs_subzone_skip_lu   = skip_lu (Fast/FastC/FastC/Compute/skip_lu.for): iskip_lu(mx_ssiter, 2)
+ * fs_subzone_boxes     = ssdom_lu_ijk (Fast/FastC/FastC/Compute/ssdom_lu_ijk.for): the boxes (6 integers each, at most
+ *                        max_boxes) of the blocks with it_target >= iseuil; no_lu / *count = the blocks they hold;
+ *                        returns the number of boxes
+ * fs_subzone_residual  = cprdu3s1 (Fast/FastS/FastS/Compute/cprdu3s1.for, cprdu3s1_incl.for) on block norms the caller
+ *                        has reduced: norms = 12 doubles per block (sums of squares of 6 equations, their largest
+ *                        magnitudes); rdm = rdm_sdm(nssiter, neq, 2, nblocks) */
+int fs_subzone_skip_lu(int nitmax, int mx_ssiter, int32_t *iskip_lu);
+int fs_subzone_boxes(const int32_t *ijkv, const int32_t *size_ssdom, int iseuil, const int32_t *it_target,
+                     int32_t *no_lu, int32_t *count, int32_t *ind_dm, int max_boxes);
+int fs_subzone_residual(const int32_t *ijkv, const int32_t *size_ssdom, int nssiter, int neq, int threed, int nstep,
+                        int it_bloc, double epsi, const double *norms, const int32_t *no_lu, int nis, int32_t *it_lu,
+                        int32_t *it_target, int32_t *it_target_old, int32_t *it_temp, double *rdm);
+
 /* Register one zone.  Returns the zone index (>= 0) or an error code.
  * Replaces the per-zone pointer gathering of K_FASTS::_computePT
  * (Fast/FastS/FastS/Compute/computePT.cpp:225-369) and the metric list produced by
