@@ -149,6 +149,13 @@ def _get(d, key, default):
     return Internal.getValue(a)
 
 
+def lssiter_loc(zones):
+    """lssiter_loc of the reference's work dictionary (Fast/FastC/FastC/PyTree.py:2062-2076, read on the first zone):
+    1 = 'implicit_local', Newton sub-iterations on the sub-zones that have not converged; 0 otherwise."""
+    a = Internal.getNodeFromName2(zones[0], 'temporal_scheme') if zones else None
+    return 1 if a is not None and Internal.getValue(a) == 'implicit_local' else 0
+
+
 # ======================================================================================
 def _buildOwnData(t, Padding=None):
     """Create .Solver#ownData (Parameter_int / Parameter_real) on every zone and

@@ -106,6 +106,8 @@ def _new_context(zones, metrics, dtloc, device):
         FastC.HOOK['ctx'].close()
     ctx = _capi.Context(device)
     ctx.set_verif(int(dtloc[1]))
+    ctx.lssiter_loc = FastC.lssiter_loc(zones)
+    ctx.set_local_newton(ctx.lssiter_loc)
     names = {}
     for nd, (z, m) in enumerate(zip(zones, metrics)):
         o = Internal.getNodeFromName1(z, '.Solver#ownData')
@@ -132,7 +134,7 @@ def _set_hook(ctx, dtloc, names, mpi=0):
     FastC.HOOK = {'ctx': ctx, 'dtloc': dtloc, 'FIRST_IT': FastC.FIRST_IT, 'param_int_tc': None,
                   'param_real_tc': None, 'mpi': mpi, 'zone_index': names,
                   'MX_SSZONE': FastC.MX_SSZONE, 'MX_SYNCHRO': FastC.MX_SYNCHRO,
-                  'MX_OMP_SIZE_INT': FastC.MX_OMP_SIZE_INT, 'lssiter_loc': 0, 'neq_max': 5}
+                  'MX_OMP_SIZE_INT': FastC.MX_OMP_SIZE_INT, 'lssiter_loc': getattr(ctx, 'lssiter_loc', 0), 'neq_max': 5}
     return FastC.HOOK
 
 

@@ -21,7 +21,8 @@ SYMBOLS = [
     "fs_stage_kernel_ms", "fs_debug_fetch",
     "fs_comm_unique_id", "fs_comm_init", "fs_zone_set_global_id", "fs_send_add_remote", "fs_comm_setup", "fs_halo_exchange",
     "fs_comm_allreduce", "fs_joins_set", "fs_stream_triad", "fs_host_alloc", "fs_host_free",
-    "fs_subzone_skip_lu", "fs_subzone_boxes", "fs_subzone_residual",
+    "fs_subzone_skip_lu", "fs_subzone_boxes", "fs_subzone_residual", "fs_set_local_newton", "fs_subzone_list",
+    "fs_subzone_targets",
 ]
 
 COMM_ID_BYTES = 128
@@ -126,6 +127,24 @@ class Context:
 
     def set_verif(self, modulo_verif):
         self._chk(lib().fs_set_verif(self._h, ctypes.c_int(int(modulo_verif))), "fs_set_verif")
+
+    def set_local_newton(self, lssiter_loc):
+        """1: Newton sub-iterations on the sub-zones that have not converged ('implicit_local'); before upload()."""
+        self._chk(lib().fs_set_local_newton(self._h, ctypes.c_int(int(lssiter_loc))), "fs_set_local_newton")
+
+    def subzone_list(self, zone, nstep, max_boxes=4096):
+        """Boxes (i1, i2, j1, j2, k1, k2) zone `zone` works on at sub-iteration nstep: int32[nbox, 6]."""
+        out = numpy.zeros(6 * max_boxes, dtype=numpy.int32)
+        n = self._chk(lib().fs_subzone_list(self._h, ctypes.c_int(int(zone)), ctypes.c_int(int(nstep)),
+                                            out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(max_boxes)), "fs_subzone_list")
+        return out[:6 * n].reshape(n, 6)
+
+    def subzone_targets(self, zone, max_blocks=1 << 20):
+        """Sub-iterations the blocks of zone `zone` are given at the next evaluation of the sub-zones."""
+        out = numpy.zeros(max_blocks, dtype=numpy.int32)
+        n = self._chk(lib().fs_subzone_targets(self._h, ctypes.c_int(int(zone)), out.ctypes.data_as(ctypes.c_void_p),
+                                               ctypes.c_int(max_blocks)), "fs_subzone_targets")
+        return out[:n].copy()
 
     def zone_set_distance(self, zone, dist):
         d = numpy.ascontiguousarray(numpy.asarray(dist).reshape(-1, order='F'), dtype=numpy.float64)

@@ -2,6 +2,7 @@
 // Declarations and the reference interfaces they replace: include/fasts_hip.h.
 #include "fasts_ctx.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,9 +15,9 @@ namespace {
 // Parameter_int / Parameter_real slots (Fast/FastS/FastS/param_solver.h:77-306)
 enum { NIJK = 0, NIJK_MTR = 5, IJKV = 20, ITYPZONE = 25, IFLOW = 27, ITYPCP = 29, KFLUDOM = 33, LALE = 34, NEQ = 36,
        NEQ_IJ = 37, NEQ_K = 38, NDIMDX = 41, NDIMDX_MTR = 43, DTLOC = 46, RK = 52, EXPLOC = 54, NSSITER = 58,
-       SLOPE = 64, PT_BC = 70, SA_LOW_RE = 130, SA_ROT_CORR = 131, SA_DIST = 132, SFD = 62, SFD_INIT_IT = 63, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
+       SLOPE = 64, PT_BC = 70, SIZE_SSDOM = 30, SA_LOW_RE = 130, SA_ROT_CORR = 131, SA_DIST = 132, SFD = 62, SFD_INIT_IT = 63, NB_RELAX = 71, IMPLICITSOLVER = 74, LU_MATCH = 75, SENSORTYPE = 85 };
 enum { DTC = 0, GAMMA = 1, CVINF = 2, ROINF = 3, PINF = 4, VINF = 5, PRANDT = 10, XMUL0 = 11, TEMP0 = 12, CS = 13,
-       RONUTILDEINF = 8, CFL = 15, SA_RATIOM_R = 18, PRANDT_TUR = 38, VXINF = 19, VYINF = 20, VZINF = 21,
+       RONUTILDEINF = 8, EPSI_NEWTON = 14, CFL = 15, SA_RATIOM_R = 18, PRANDT_TUR = 38, VXINF = 19, VYINF = 20, VZINF = 21,
        PSIROE = 34 };
 
 }  // namespace
@@ -86,6 +87,8 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     for (int r = 0; r < 3; r++) if (zn.pinned[r]) { if (hipHostUnregister(zn.pinned[r]) != hipSuccess) (void)hipGetLastError(); }
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
+    (void)hipFree(zn.blk_res);
+    for (auto &bb : zn.box_bcs) (void)hipFree(bb.dev);
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
@@ -351,6 +354,14 @@ extern "C" int fs_subzone_residual(const int32_t *ijkv, const int32_t *size_ssdo
   memcpy(it_lu, s.it_lu.data(), sizeof(int32_t) * n); memcpy(it_target, s.it_target.data(), sizeof(int32_t) * n);
   memcpy(it_target_old, s.it_target_old.data(), sizeof(int32_t) * n); memcpy(it_temp, s.it_temp.data(), sizeof(int32_t) * n);
   memcpy(rdm, s.rdm.data(), sizeof(double) * s.rdm.size());
+  return FS_OK;
+}
+
+extern "C" int fs_set_local_newton(fs_ctx *ctx, int lssiter_loc)
+{
+  if (!ctx || (lssiter_loc != 0 && lssiter_loc != 1)) return FS_ERR_ARG;
+  if (ctx->uploaded) return fail(ctx, FS_ERR_STATE, "fs_set_local_newton: must be called before fs_upload");
+  ctx->local_newton = lssiter_loc;
   return FS_OK;
 }
 
@@ -743,6 +754,7 @@ extern "C" int fs_send_add(fs_ctx *ctx, int donor_zone, int peer_tag, const int3
 }
 
 static int build_shell_lists(fs_ctx *ctx);
+static int local_setup(fs_ctx *ctx);
 
 extern "C" int fs_upload(fs_ctx *ctx)
 {
@@ -757,6 +769,14 @@ extern "C" int fs_upload(fs_ctx *ctx)
     for (auto &zn : ctx->zones)
       if (zn.pint[SFD] == 1 && !zn.rof_host)
         return fail(ctx, FS_ERR_STATE, "fs_upload: a zone with selective frequency damping needs fs_zone_set_filtered first");
+  if (!ctx->uploaded && ctx->local_newton) {
+    if (!ctx->implicit) return fail(ctx, FS_ERR_STATE, "fs_upload: local Newton sub-iterations need the implicit scheme");
+    for (auto &zn : ctx->zones)
+      if (!zn.lu_blocks.empty() || zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0 || !zn.roe_walls.empty() ||
+          zn.pint[SIZE_SSDOM] < 1 || zn.pint[SIZE_SSDOM + 1] < 1 || zn.pint[SIZE_SSDOM + 2] < 1)
+        return fail(ctx, FS_ERR_UNSUPPORTED, "fs_upload: local Newton sub-iterations are implemented with one LU-SGS sweep "
+                    "per sub-zone (no thread blocks, nb_relax = 1, lu_match = 0, no roe scheme with walls)");
+  }
   for (auto &zn : ctx->zones) {
     const size_t nb = sizeof(double) * (size_t)zn.z.neq * (size_t)zn.z.nd;
     if (!ctx->uploaded) {
@@ -843,6 +863,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
   if (!ctx->uploaded) {
     int rc = build_shell_lists(ctx);
     if (rc) return rc;
+    if (ctx->local_newton) {
+      rc = local_setup(ctx);
+      if (rc) return rc;
+    }
   }
   ctx->uploaded = true;
   return FS_OK;
@@ -946,6 +970,133 @@ static int build_shell_lists(fs_ctx *ctx)
   return FS_OK;
 }
 
+// ---- 'implicit_local': sub-zones --------------------------------------------------------------------------------------
+// BC windows of sub-iteration nstep cut to its boxes: a window is applied where a box reaches its face, over the cells
+// of the box (Fast/FastC/FastC/BC/indice_cl_sdm.for:46-99 with the box as ind_sdm; Fast/FastS/FastS/Compute/bcs.cpp:14-41)
+static int local_bc_tables(fs_ctx *ctx, Zone &zn, int nstep)
+{
+  const FsZone &z = zn.z;
+  const std::vector<int32_t> &bx = zn.sub.boxes[(size_t)nstep - 1];
+  const int ends[6] = {1, z.iv, 1, z.jv, 1, z.kv};
+  std::vector<FsBcWin> wins;
+  long long max_cells = 0;
+  for (size_t b = 0; b + 6 <= bx.size(); b += 6)
+    for (const FsBcWin &w0 : zn.bc) {
+      const int f = w0.idir - 1, d = f / 2;
+      if (bx[b + f] != ends[f]) continue;
+      FsBcWin w = w0;
+      bool empty = false;
+      for (int t = 0; t < 3; t++) {
+        if (t == d) continue;
+        w.lo[t] = std::max(w0.lo[t], (int)bx[b + 2 * t]);
+        w.hi[t] = std::min(w0.hi[t], (int)bx[b + 2 * t + 1]);
+        if (w.lo[t] > w.hi[t]) empty = true;
+      }
+      if (empty) continue;
+      const long long cells = (long long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
+      if (cells > max_cells) max_cells = cells;
+      wins.push_back(w);
+    }
+  Zone::BoxBcs &bb = zn.box_bcs[(size_t)nstep - 1];
+  bb.n = (int)wins.size(); bb.kinds = bc_kinds(wins); bb.max_cells = max_cells;
+  if (wins.size() > bb.cap) {
+    (void)hipFree(bb.dev);
+    bb.dev = nullptr; bb.cap = 0;
+    HIPCHK(ctx, hipMalloc(&bb.dev, sizeof(FsBcWin) * wins.size()));
+    bb.cap = wins.size();
+  }
+  if (!wins.empty()) HIPCHK(ctx, hipMemcpy(bb.dev, wins.data(), sizeof(FsBcWin) * wins.size(), hipMemcpyHostToDevice));
+  return FS_OK;
+}
+
+// State of the sub-zones as the reference's warmup leaves it (Fast/FastS/FastS/PyTree.py:391-394: souszones_list for
+// every sub-iteration with no list yet: counters reset, then the boxes of the initial targets)
+static int local_setup(fs_ctx *ctx)
+{
+  const int nssiter = ctx->zones[0].z.nssiter;
+  ctx->iskip_lu.assign(2 * (size_t)nssiter, 0);
+  fsz_skip_lu(nssiter, nssiter, ctx->iskip_lu.data());       // init_ssiter_bloc.for:50-53
+  fsz_skip_lu(nssiter - 1, nssiter, ctx->iskip_lu.data());
+  for (auto &zn : ctx->zones) {
+    const FsZone &z = zn.z;
+    const int ijkv[3] = {z.iv, z.jv, z.kv};
+    const int ss[3] = {zn.pint[SIZE_SSDOM], zn.pint[SIZE_SSDOM + 1], zn.pint[SIZE_SSDOM + 2]};
+    fsz_init(zn.sub, ijkv, ss, nssiter, z.neq, z.ifick != 0);
+    fsz_reset(zn.sub);
+    zn.box_bcs.assign((size_t)nssiter, Zone::BoxBcs());
+    HIPCHK(ctx, hipMalloc(&zn.blk_res, sizeof(double) * 12 * (size_t)zn.sub.n * nssiter));
+    for (int nstep = 1; nstep <= nssiter; nstep++) {
+      fsz_evaluate(zn.sub, nstep, ctx->iskip_lu.data());
+      int rc = local_bc_tables(ctx, zn, nstep);
+      if (rc) return rc;
+    }
+  }
+  return FS_OK;
+}
+
+// The block norms of the sub-iterations of a finished verification step come back from the device and go through the
+// bookkeeping of cprdu3s1, in the order the sub-iterations ran (residus_navier.h:12-43; it_bloc: Compute/ssor.cpp:14-20)
+static int local_finalize(fs_ctx *ctx)
+{
+  bool any = false;
+  for (auto &zn : ctx->zones) any = any || !zn.pending.empty();
+  if (!any) return FS_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &zn : ctx->zones) {
+    if (zn.pending.empty()) continue;
+    const size_t per = 12 * (size_t)zn.sub.n;
+    std::vector<double> norms(per * zn.pending.size());
+    HIPCHK(ctx, hipMemcpy(norms.data(), zn.blk_res, sizeof(double) * norms.size(), hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < zn.pending.size(); q++) {
+      const Zone::PendingNorms &pn = zn.pending[q];
+      zn.sub.it_bloc += 1;
+      fsz_residual(zn.sub, pn.nstep, zn.preal[EPSI_NEWTON], norms.data() + per * q, pn.no_lu.data(), pn.nis);
+    }
+    zn.pending.clear();
+    // norms of the zone per slot: the blocks added up in their order (DISPLAY/display_ss_iteration.cpp:112-136)
+    const int nss = zn.sub.nssiter, neq = zn.sub.neq;
+    zn.res_host.assign(12 * (size_t)zn.sub.it_bloc, 0.);
+    for (int it = 0; it < zn.sub.it_bloc; it++)
+      for (int ne = 0; ne < neq; ne++)
+        for (int b = 0; b < zn.sub.n; b++) {
+          const size_t base = (size_t)it + (size_t)nss * ((size_t)ne + (size_t)neq * (2 * (size_t)b));
+          zn.res_host[12 * (size_t)it + ne] += zn.sub.rdm[base];
+          zn.res_host[12 * (size_t)it + 6 + ne] = std::max(zn.res_host[12 * (size_t)it + 6 + ne], zn.sub.rdm[base + (size_t)nss * neq]);
+        }
+    zn.res_slots = zn.sub.it_bloc;
+    zn.have_res = zn.sub.it_bloc > 0;
+  }
+  return FS_OK;
+}
+
+// souszones_list before sub-iteration nstep of time step nitrun (Fast/FastC/FastC/Compute/souszones_list.cpp:161-196 with
+// lssiter_loc = 1, Fast/FastS/FastS/Compute/computePT.cpp:551-577): on a verification step the counters restart at the
+// first sub-iteration; on the step after one (and on the first step) the boxes of this sub-iteration are evaluated
+// again from the targets.  Once per (nitrun, nstep).
+static int local_prepare(fs_ctx *ctx, int nitrun, int nstep)
+{
+  if (ctx->local_nitrun == nitrun && ctx->local_nstep == nstep) return FS_OK;
+  ctx->local_nitrun = nitrun; ctx->local_nstep = nstep;
+  const int kmod = ctx->modulo_verif;
+  const bool verif = nitrun % kmod == 0, eval = (nitrun - 1) % kmod == 0;
+  if (nstep == 1 && (verif || eval)) {
+    int rc = local_finalize(ctx);
+    if (rc) return rc;
+  }
+  if (verif && nstep == 1)
+    for (auto &zn : ctx->zones) fsz_reset(zn.sub);
+  if (eval) {
+    // the tables of this sub-iteration may still be read by the step before
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &zn : ctx->zones) {
+      fsz_evaluate(zn.sub, nstep, ctx->iskip_lu.data());
+      int rc = local_bc_tables(ctx, zn, nstep);
+      if (rc) return rc;
+    }
+  }
+  return FS_OK;
+}
+
 // part < 0: the whole stage.  part 0: viscosity + the shell tiles.  part 1: the remaining tiles
 // (+ residual norms).  Zones that are not split (no joins to other contexts, curvilinear zones, implicit
 // scheme) run in one piece: in part 0 if other contexts wait for their cells, else in part 1.
@@ -955,15 +1106,34 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
   if (rc) return rc;
   std::vector<hipEvent_t> lu_joins;
   int n_lu = 0;
+  if (nstep < 1 || nstep > ctx->zones[0].z.nssiter) return fail(ctx, FS_ERR_ARG, std::string(who) + ": sub-iteration out of range");
+  if (ctx->local_newton) {
+    rc = local_prepare(ctx, nitrun, nstep);
+    if (rc) return rc;
+  }
   for (auto &zn : ctx->zones) {
     const FsZone &z = zn.z;
     if (nstep < 1 || nstep > z.nssiter) return fail(ctx, FS_ERR_ARG, std::string(who) + ": sub-iteration out of range");
     // the last slot of an implicit step is the reference's verification pass: skipped on ordinary steps
     // (Fast/FastS/FastS/Compute/computePT.cpp:579-585); on a verification step it evaluates the Newton residual of
     // the final iterate and its norms, and advances nothing (lexit_lu, Fast/FastC/FastC/Compute/souszones_list.cpp:81-83)
-    const bool verif = nitrun % ctx->modulo_verif == 0 || nitrun == 1 || ctx->modulo_verif == 1;
+    // with local Newton sub-iterations the first time step is no verification step of its own
+    // (souszones_list.cpp:166-196: the second pass alone runs, and leaves lssiter_verif = 0)
+    const bool verif = ctx->local_newton ? nitrun % ctx->modulo_verif == 0
+                                         : (nitrun % ctx->modulo_verif == 0 || nitrun == 1 || ctx->modulo_verif == 1);
     const bool slot = ctx->implicit && nstep == z.nssiter;
     if (slot && !verif) continue;
+    // the boxes this zone works on at this sub-iteration (one task per box, rhs.cpp:9-58); none: the zone sits it out
+    const int whole_box[6] = {1, z.iv, 1, z.jv, 1, z.kv};
+    const int32_t *boxes = nullptr;
+    int nbox = 1;
+    if (ctx->local_newton) {
+      boxes = zn.sub.boxes[(size_t)nstep - 1].data();
+      nbox = (int)(zn.sub.boxes[(size_t)nstep - 1].size() / 6);
+      if (nbox == 0) continue;
+      if (nstep == 1 && (nbox != 1 || memcmp(boxes, whole_box, sizeof whole_box) != 0))
+        return fail(ctx, FS_ERR_STATE, std::string(who) + ": the first sub-iteration must cover the whole zone");
+    }
     int in, out;
     stage_roles(ctx, nstep, in, out);
     double coefH, coefW;
@@ -978,7 +1148,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     const bool opens = part <= 0 || !split;      // this call starts the stage of this zone
     const bool closes = part != 0 || !split;     // this call ends it
     const bool dtloc = zn.pint[DTLOC] == 1;
-    FsBdf bdf = {zn.dev[0], zn.dev[1], -1.5, 2., -0.5, nstep == 1, dtloc ? zn.coe : nullptr};
+    FsBdf bdf = {zn.dev[0], zn.dev[1], -1.5, 2., -0.5, nstep == 1, dtloc ? zn.coe : nullptr, {1, z.iv, 1, z.jv, 1, z.kv}};
     if (ctx->first_it == 0 || dtloc) { bdf.c1 = -1.; bdf.c2 = 1.; bdf.c3 = 0.; }   // core3as2.for:37-45
     const FsBdf *pbdf = ctx->implicit ? &bdf : nullptr;
     if (opens && nstep == 1) {
@@ -1016,6 +1186,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     // are those of the first stage; kept when a later kernel of this stage reads it (wall-flux correction, local
     // time step) and for a one-stage scheme, whose only stage is also the first
     const int keep = ctx->implicit || deferred || dtloc || nstep < z.nssiter || nstep == 1;
+    for (int b = 0; b < nbox && !krc; b++) {
+    if (boxes) for (int q = 0; q < 6; q++) bdf.box[q] = boxes[6 * b + q];   // cells outside the box keep their residual
     if (z.iflow == 3 && z.ityp != 0)
       krc = fsk_stage_sa(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut, zn.dist,
                          (unsigned char *)zn.wig, kbdf, keep, ctx->stream);
@@ -1031,6 +1203,19 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       if (!split || nlist > 0)
         krc = fsk_stage_dma(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
                             (unsigned char *)zn.wig, blist, nlist, kbdf, keep, ctx->stream);
+    }
+    if (boxes && verif && !krc && memcmp(boxes + 6 * b, whole_box, sizeof whole_box) != 0) {
+      // What the reference's loops leave in the balance of the cells around the box: the source of the 6th equation,
+      // then the fluxes of the faces of the box.  Only the norms of a verification step ever read those cells.
+      const int box[6] = {boxes[6 * b], boxes[6 * b + 1], boxes[6 * b + 2], boxes[6 * b + 3], boxes[6 * b + 4], boxes[6 * b + 5]};
+      if (z.iflow == 3) {
+        if (z.ityp == 0) fsk_sa_ring_source_full(z, box, zn.dev[in], zn.dist, zn.drodm, ctx->stream);
+        else fsk_sa_ring_source(z, box, zn.dev[in], zn.dist, zn.drodm, ctx->stream);
+      }
+      if (z.ityp == 0) fsk_box_faces_full(z, box, zn.dev[in], zn.xmut, (unsigned char *)zn.wig, zn.drodm, ctx->stream);
+      else if (z.iflow == 3) fsk_box_faces_sa(z, box, zn.dev[in], zn.xmut, (unsigned char *)zn.wig, zn.drodm, ctx->stream);
+      else fsk_box_faces_cart(z, box, zn.dev[in], zn.xmut, (const unsigned char *)zn.wig, zn.drodm, ctx->stream);
+    }
     }
     if (krc)
       return fail(ctx, FS_ERR_UNSUPPORTED, std::string(who) + ": no kernel for this scheme / model");
@@ -1059,7 +1244,13 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     }
     // residual norms (cprdu3s1.for): every Newton sub-iteration of a verification step; explicit scheme: the
     // first-stage increment
-    if (verif && (ctx->implicit || nstep == 1)) {
+    if (verif && ctx->local_newton) {
+      // norms per block; the bookkeeping of cprdu3s1 follows on the host once the step is over, with the block list
+      // as it stands now
+      fsk_residual_blocks(z, zn.sub.nblk, zn.sub.size, zn.drodm, zn.blk_res + 12 * (size_t)zn.sub.n * zn.pending.size(),
+                          ctx->stream);
+      zn.pending.push_back({nstep, zn.sub.nisdom_residu[(size_t)nstep - 1], zn.sub.no_lu});
+    } else if (verif && (ctx->implicit || nstep == 1)) {
       fsk_residual(z, ctx->implicit ? 0 : 1, zn.drodm, zn.res_part, zn.res_out + 12 * (nstep - 1), ctx->stream,
                    (!ctx->implicit && dtloc) ? zn.coe : nullptr);
       zn.have_res = true;
@@ -1107,17 +1298,29 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
         HIPCHK(ctx, hipEventRecord(zn.ev_lu_fork, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ls, zn.ev_lu_fork, 0));
       }
+      int lrc = 0;
+      if (ctx->local_newton) {
+        // one sweep pair per box; its range takes the ghost layer of a wall face where the box reaches it
+        // (BC/BCzone.cpp:99-127), neighbour terms across the other borders of the box are left out (LU/invlu_l.for:90-215)
+        for (int b = 0; b < nbox && !lrc; b++) {
+          int range[6];
+          for (int q = 0; q < 6; q++) range[q] = boxes[6 * b + q] == whole_box[q] ? zn.lu[q] : boxes[6 * b + q];
+          lrc = fsk_lusgs(z, range, 0, nullptr, nullptr, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm,
+                          zn.coe, ls);
+        }
+      } else {
       const int sdm[6] = {1, z.iv, 1, z.jv, 1, z.kv};
       // lu_match = 1: the sweeps of invlu_overlap_{l,u}.for (with nb_relax > 1, 5 equations: the LU-SSOR sweeps whatever
       // lu_match is, LU/invlu.for:195-340).  The reference also copies the Newton residual into the
       // ghost cells of match joins first (lhs.cpp:1-15); no sweep reads them (the range grows into ghost cells only
       // over walls, whose BC then overwrites them, and between the thread blocks of a zone): nothing to do here
-      const int lrc = (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
+      lrc = (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
                           ? fsk_lussor(z, zn.lu, sdm, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.pint[NB_RELAX],
                                        zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
                                        zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
                           : fsk_lusgs(z, zn.lu, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.preal[GAMMA], zn.dev[in],
                                       zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
+      }
       if (sfd && !verif && nstep == z.nssiter - 1)
         fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, zn.coe, ls);
       if (ctx->lu_nstreams > 0) {
@@ -1192,9 +1395,21 @@ extern "C" int fs_local_joins(fs_ctx *ctx, int nstep)
   return FS_OK;
 }
 
-static void bcs_on_role(fs_ctx *ctx, int role)
+// nstep >= 1 with local Newton sub-iterations: the BCs of the boxes of that sub-iteration (bcs.cpp:14-41), their edges
+// and corners box by box (correct_coins with the range of the task)
+static void bcs_on_role(fs_ctx *ctx, int role, int nstep = 0)
 {
   for (auto &zn : ctx->zones) {
+    if (ctx->local_newton && nstep >= 1) {
+      const Zone::BoxBcs &bb = zn.box_bcs[(size_t)nstep - 1];
+      fsk_bc_windows(zn.z, bb.n, bb.dev, bb.kinds, bb.max_cells, zn.dev[role], ctx->stream);
+      const std::vector<int32_t> &bx = zn.sub.boxes[(size_t)nstep - 1];
+      for (size_t b = 0; b + 6 <= bx.size(); b += 6) {
+        const int box[6] = {bx[b], bx[b + 1], bx[b + 2], bx[b + 3], bx[b + 4], bx[b + 5]};
+        fsk_bc_edges(zn.z, zn.dev[role], ctx->stream, box);
+      }
+      continue;
+    }
     fsk_bc_windows(zn.z, (int)zn.bc.size(), zn.bc_dev, bc_kinds(zn.bc), zn.bc_max_cells, zn.dev[role], ctx->stream);
     fsk_bc_edges(zn.z, zn.dev[role], ctx->stream);
   }
@@ -1206,7 +1421,7 @@ extern "C" int fs_bcs(fs_ctx *ctx, int nstep)
   if (rc) return rc;
   int in, out;
   stage_roles(ctx, nstep, in, out);
-  bcs_on_role(ctx, out);
+  bcs_on_role(ctx, out, nstep);
   HIPCHK(ctx, hipGetLastError());
   return FS_OK;
 }
@@ -1318,7 +1533,7 @@ extern "C" int fs_compute(fs_ctx *ctx, int nitrun, int nstep_deb, int nstep_fin,
       local_joins_on(ctx, role_from_nstep, &a);
       int in, out;
       stage_roles(ctx, nstep, in, out);
-      bcs_on_role(ctx, out);
+      bcs_on_role(ctx, out, nstep);
     }
     // explicit: the result of the last sub-iteration sits in P1 only when their number is odd
     // (Fast/FastS/FastS/PyTree.py:233: switchPointers__(zones, case, nitmax%2+2)); implicit: always (:232)
@@ -1382,10 +1597,17 @@ extern "C" int fs_residuals(fs_ctx *ctx, int zone, double *l2, double *loo, int 
   if (rc) return rc;
   if (zone < 0 || zone >= (int)ctx->zones.size() || !l2 || !loo || neq < 5 || neq > 6) return fail(ctx, FS_ERR_ARG, "fs_residuals: bad argument");
   Zone &zn = ctx->zones[zone];
+  if (ctx->local_newton) {
+    rc = local_finalize(ctx);
+    if (rc) return rc;
+  }
   if (!zn.have_res) return fail(ctx, FS_ERR_STATE, "fs_residuals: no verification sub-iteration has run yet");
   double out[12];
-  HIPCHK(ctx, hipMemcpyAsync(out, zn.res_out, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->local_newton) memcpy(out, zn.res_host.data(), sizeof out);
+  else {
+    HIPCHK(ctx, hipMemcpyAsync(out, zn.res_out, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   residual_norms(zn, out, neq, l2, loo);
   return FS_OK;
 }
@@ -1397,11 +1619,18 @@ extern "C" int fs_residual_history(fs_ctx *ctx, int zone, double *l2, double *lo
   if (zone < 0 || zone >= (int)ctx->zones.size() || !l2 || !loo || neq < 5 || neq > 6 || nslot < 1)
     return fail(ctx, FS_ERR_ARG, "fs_residual_history: bad argument");
   Zone &zn = ctx->zones[zone];
+  if (ctx->local_newton) {
+    rc = local_finalize(ctx);
+    if (rc) return rc;
+  }
   if (!zn.have_res) return fail(ctx, FS_ERR_STATE, "fs_residual_history: no verification step has run yet");
   const int n = zn.res_slots < nslot ? zn.res_slots : nslot;
   std::vector<double> out(12 * (size_t)n);
-  HIPCHK(ctx, hipMemcpyAsync(out.data(), zn.res_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->local_newton) memcpy(out.data(), zn.res_host.data(), sizeof(double) * out.size());
+  else {
+    HIPCHK(ctx, hipMemcpyAsync(out.data(), zn.res_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   for (int i = 0; i < n; i++) residual_norms(zn, out.data() + 12 * i, neq, l2 + (size_t)i * neq, loo + (size_t)i * neq);
   return n;
 }
@@ -1443,6 +1672,34 @@ extern "C" int fs_tgv_sums_static(fs_ctx *ctx, int level, double *dev_sums)
   double *scratch = ctx->device < FS_MAX_DEVICES ? g_static_scratch[ctx->device] : nullptr;
   if (!scratch) return fail(ctx, FS_ERR_STATE, "fs_tgv_sums_static: no static scratch buffer on this device");
   return tgv_sums_on(ctx, role, dev_sums, scratch, FS_STATIC_ROWS, "fs_tgv_sums_static");
+}
+
+extern "C" int fs_subzone_list(fs_ctx *ctx, int zone, int nstep, int32_t *boxes, int max_boxes)
+{
+  int rc = ensure_ready(ctx, "fs_subzone_list");
+  if (rc) return rc;
+  if (!ctx->local_newton) return fail(ctx, FS_ERR_STATE, "fs_subzone_list: the context runs no local Newton sub-iterations");
+  if (zone < 0 || zone >= (int)ctx->zones.size() || !boxes || nstep < 1 || nstep > ctx->zones[zone].z.nssiter)
+    return fail(ctx, FS_ERR_ARG, "fs_subzone_list: bad argument");
+  const std::vector<int32_t> &bx = ctx->zones[zone].sub.boxes[(size_t)nstep - 1];
+  const int nb = (int)(bx.size() / 6);
+  if (nb > max_boxes) return fail(ctx, FS_ERR_ARG, "fs_subzone_list: more boxes than the caller has room for");
+  if (nb) memcpy(boxes, bx.data(), sizeof(int32_t) * bx.size());
+  return nb;
+}
+
+extern "C" int fs_subzone_targets(fs_ctx *ctx, int zone, int32_t *it_target, int max_blocks)
+{
+  int rc = ensure_ready(ctx, "fs_subzone_targets");
+  if (rc) return rc;
+  if (!ctx->local_newton) return fail(ctx, FS_ERR_STATE, "fs_subzone_targets: the context runs no local Newton sub-iterations");
+  if (zone < 0 || zone >= (int)ctx->zones.size() || !it_target || ctx->zones[zone].sub.n > max_blocks)
+    return fail(ctx, FS_ERR_ARG, "fs_subzone_targets: bad argument");
+  rc = local_finalize(ctx);
+  if (rc) return rc;
+  const FsSubZones &sz = ctx->zones[zone].sub;
+  memcpy(it_target, sz.it_target.data(), sizeof(int32_t) * (size_t)sz.n);
+  return sz.n;
 }
 
 extern "C" int fs_sync(fs_ctx *ctx)

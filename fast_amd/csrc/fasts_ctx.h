@@ -54,6 +54,15 @@ struct Zone {
   struct RoeWall { int tag, idir, lo[3], hi[3]; };
   std::vector<RoeWall> roe_walls;
   hipEvent_t ev_part = nullptr;   // start of a split stage (timing)
+  // 'implicit_local': blocks, targets and boxes; norms of the blocks at the sub-iterations of a verification step (on the
+  // device until the step is over, then folded into sub.rdm on the host); BC windows cut to the boxes, per sub-iteration
+  FsSubZones sub;
+  double *blk_res = nullptr;
+  struct PendingNorms { int nstep, nis; std::vector<int32_t> no_lu; };
+  std::vector<PendingNorms> pending;
+  struct BoxBcs { FsBcWin *dev = nullptr; size_t cap = 0; int n = 0, kinds = 0; long long max_cells = 0; };
+  std::vector<BoxBcs> box_bcs;
+  std::vector<double> res_host;   // 12 norms per slot of the last verification step, summed over the blocks
 };
 
 struct Join {
@@ -86,6 +95,9 @@ struct fs_ctx {
   int lu_nstreams = -1;    // -1: not decided yet (FASTS_HIP_LU_STREAMS, default 4; 0 or 1 = everything on one stream)
   bool implicit = false;      // ITYPCP 1: BDF + LU-SGS Newton sub-iterations (all zones of a context agree)
   int first_it = 0;           // FIRST_IT of the reference: 0 until one time step is complete (BDF1, xid = 1)
+  int local_newton = 0;       // lssiter_loc = 1 ('implicit_local'): Newton sub-iterations on sub-zones
+  std::vector<int32_t> iskip_lu;            // schedule of the sub-iterations, iskip_lu(nssiter, 2)
+  int local_nitrun = -1, local_nstep = -1;  // the sub-iteration the sub-zone lists were last prepared for
   std::string err;
   // stage-kernel timing
   bool timing = false;

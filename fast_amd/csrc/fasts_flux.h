@@ -535,7 +535,33 @@ struct FsBdf {
   double c1, c2, c3;            // BDF1: -1, 1, 0   BDF2: -1.5, 2, -0.5
   int nit1;                     // 1 at the first Newton sub-iteration
   const double *coe1;           // local time step: dt of every cell (coe(:,1)); NULL = global dt/vol
+  int box[6];                   // i1, i2, j1, j2, k1, k2: the cells whose residual is written (a sub-zone of the zone)
 };
+
+// Thread t of side `side` (0..5 = imin, imax, jmin, jmax, kmin, kmax) of the box: the cell whose lower face along the
+// normal is the face of the box (the first cell of the box on a min side, the cell past the box on a max side).  False
+// when the cell the flux lands on lies outside the interior of the zone, or t past the face.
+template <class BoxT>
+FS_DEV bool box_face_cell(const FsZone &z, const BoxT &box, int side, long long t, int &i, int &j, int &k)
+{
+  const int d = side >> 1, high = side & 1;
+  const int a = d == 0 ? 1 : 0, b = d == 2 ? 1 : 2;
+  const int na = box.b[2 * a + 1] - box.b[2 * a] + 1, nb = box.b[2 * b + 1] - box.b[2 * b] + 1;
+  if (t >= (long long)na * nb) return false;
+  int c[3];
+  c[a] = box.b[2 * a] + (int)(t % na);
+  c[b] = box.b[2 * b] + (int)(t / na);
+  c[d] = high ? box.b[2 * d + 1] + 1 : box.b[2 * d];
+  const int ends[3] = {z.iv, z.jv, z.kv};
+  if (high ? c[d] > ends[d] : c[d] - 1 < 1) return false;
+  i = c[0]; j = c[1]; k = c[2];
+  return true;
+}
+
+FS_DEV bool fs_in_box(const FsBdf &b, int i, int j, int k)
+{
+  return i >= b.box[0] && i <= b.box[1] && j >= b.box[2] && j <= b.box[3] && k >= b.box[4] && k <= b.box[5];
+}
 
 FS_DEV void fs_bdf_residual(const FsZone &z, const FsBdf &b, double coe, const double *q, const double *qn,
                             const double *qn1, const double *d, double *r)

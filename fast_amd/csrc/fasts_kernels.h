@@ -62,11 +62,33 @@ int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const d
                  int keep_balance, hipStream_t s);
 // coe(:,6), diagonal of the nu_tilde equation, interior + one ghost layer; needs coe(:,1) and coe(:,5)
 void fsk_sa_coe6(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
+// Sub-zones: the source term of the nu_tilde equation is evaluated on the box and the layer of cells around it
+// (ind_ssa of Fast/FastC/FastC/HPC_LAYER/indice_boucle_ssdom.for:105-160; SA/spsource_SA.for adds it to drodm(:,6)
+// there), the balance is started from zero on the box alone: the interior cells of that layer keep what they held of
+// the 6th equation plus the source.  box = i1, i2, j1, j2, k1, k2.  _full: curvilinear, k-homogeneous and 2-D zones.
+struct FsBox { int b[6]; };
+// Sub-zones: the flux loops of the reference add the flux of a face to the cell on its upper side and take it from the
+// cell on its lower side, the cells just outside the range included (Compute/template_FluxAndBalance.for:192-271,
+// assemble_drodm_plus_vec1.for, flu_send_scater_vec1.for).  For a box inside a zone the interior cells that touch it
+// therefore see what they held of the balance change by the flux of the face they share with the box -- nothing the
+// solution depends on, but the norms cprdu3s1 takes of blocks it counts as computed do.  One launch, after the stage
+// kernel of the box: - F on the lower neighbours, + F on the upper ones.  _cart: Cartesian zones with 5 equations;
+// _sa: Cartesian zones with the Spalart-Allmaras model; _full: the other zone types.
+void fsk_box_faces_cart(const FsZone &z, const int *box, const double *rop, const double *xmut, const unsigned char *wig,
+                        double *drodm, hipStream_t s);
+void fsk_box_faces_sa(const FsZone &z, const int *box, const double *rop, const double *xmut, unsigned char *wig,
+                      double *drodm, hipStream_t s);
+void fsk_box_faces_full(const FsZone &z, const int *box, const double *rop, const double *xmut, unsigned char *wig,
+                        double *drodm, hipStream_t s);
+void fsk_sa_ring_source(const FsZone &z, const int *box, const double *rop, const double *dist, double *drodm, hipStream_t s);
+void fsk_sa_ring_source_full(const FsZone &z, const int *box, const double *rop, const double *dist, double *drodm,
+                             hipStream_t s);
 // kinds: bit 0 = the table holds periodic / extrapolation windows (copy kernel), bit 1 = walls / far field.
 // The windows of one table must not overlap: the two kernels are not ordered cell by cell.
 void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, int kinds, long long max_cells, double *rop,
                     hipStream_t s);
-void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s);
+// box != NULL: i1, i2, j1, j2, k1, k2 of the interior cells the fix is made for (a sub-zone); NULL = the zone
+void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s, const int *box = nullptr);
 void fsk_join_copy(int npts, int neq, long long nd_r, long long nd_d, const int *rcv, const int *dnr,
                    double *rop_r, const double *rop_d, hipStream_t s);
 void fsk_halo_pack(int npts, int neq, long long nd, const int *pts, const double *rop, double *buf, hipStream_t s);
@@ -76,6 +98,9 @@ void fsk_halo_unpack(int npts, int neq, long long nd, const int *pts, double *ro
 // out[0..5] = sums of squares, out[6..11] = largest magnitudes (5 or 6 equations)
 void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *part, double *out, hipStream_t s,
                   const double *coe1 = nullptr);
+// norms of drodm per block of size[] cells (nblk[] blocks per direction): 12 doubles per block, as `out` above
+void fsk_residual_blocks(const FsZone &z, const int nblk[3], const int size[3], const double *drodm, double *out,
+                         hipStream_t s);
 // out[3] = largest, smallest and mean local CFL number of the interior cells (cpcfl3.for); part = 3 doubles per
 // (j,k) row of scratch; gam1 = gamma / Prandtl, gam2 = gamma * R
 void fsk_cfl(const FsZone &z, double gam1, double gam2, const double *rop, const double *xmut, double *part, double *out,

@@ -424,8 +424,10 @@ __global__ void __launch_bounds__(256) k_bc_windows(FsZone z, int nwin, const Fs
 }
 
 // 12 edges (mean of two face ghosts) and 8 corners (mean of three), correct_coins.for:23-420.
-// blockIdx.y = edge/corner id 0..19.
-__global__ void __launch_bounds__(256) k_bc_edges(FsZone z, double *__restrict__ rop)
+// blockIdx.y = edge/corner id 0..19.  box = the range of interior cells the fix is made for (correct_coins.for:16-21):
+// an edge is treated where the box reaches both of its faces, along the cells of the box; a corner where it reaches
+// the three.
+__global__ void __launch_bounds__(256) k_bc_edges(FsZone z, FsBox box, double *__restrict__ rop)
 {
   const int id = blockIdx.y;
   const int f = z.ific, fk = z.ifick;
@@ -438,12 +440,14 @@ __global__ void __launch_bounds__(256) k_bc_edges(FsZone z, double *__restrict__
     const int da = fam == 2 ? 1 : 0;            // first ghost direction
     const int db = fam == 0 ? 1 : 2;            // second ghost direction
     const int dc = fam == 0 ? 2 : (fam == 1 ? 1 : 0);  // interior direction
-    const int na = nfic[da], nb = nfic[db], nc = ends[dc][1];
+    if (box.b[2 * da + s0] != ends[da][s0] || box.b[2 * db + s1] != ends[db][s1]) return;
+    const int c_lo = box.b[2 * dc];
+    const int na = nfic[da], nb = nfic[db], nc = box.b[2 * dc + 1] - c_lo + 1;
     const long long n = (long long)na * nb * nc;
     const int sa = s0 ? 1 : -1, sb = s1 ? 1 : -1;
     const int a0 = ends[da][s0], b0 = ends[db][s1];
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-      int c = 1 + (int)(t % nc);
+      int c = c_lo + (int)(t % nc);
       int a = 1 + (int)((t / nc) % na);
       int b = 1 + (int)(t / ((long long)nc * na));
       int a1 = a + 1 < na ? a + 1 : na, b1 = b + 1 < nb ? b + 1 : nb;
@@ -467,6 +471,7 @@ __global__ void __launch_bounds__(256) k_bc_edges(FsZone z, double *__restrict__
     const int c = id - 12;
     const int si = (c & 1) ? 1 : -1, sj = (c & 2) ? 1 : -1, sk = (c & 4) ? 1 : -1;
     const int i0 = ends[0][c & 1], j0 = ends[1][(c >> 1) & 1], k0 = ends[2][(c >> 2) & 1];
+    if (box.b[c & 1] != i0 || box.b[2 + ((c >> 1) & 1)] != j0 || box.b[4 + ((c >> 2) & 1)] != k0) return;
     const long long n = (long long)f * f * fk;
     const double c3 = 1. / 3.;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
@@ -558,6 +563,47 @@ __global__ void __launch_bounds__(256) k_residual_partial(FsZone z, int use_coe,
     long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
     for (int e = 0; e < 6; e++) { part[b * 12 + e] = ssum[e][0]; part[b * 12 + 6 + e] = smax[e][0]; }
   }
+}
+
+// Norms of the Newton residual per block of SIZE_SSDOM cells (the last block of a direction takes the remainder):
+// one workgroup per block, 12 doubles each as in k_residual_partial (cprdu3s1_incl.for:15-140).
+__global__ void __launch_bounds__(256) k_residual_blocks(FsZone z, FsBox nb, const double *__restrict__ drodm,
+                                                         double *__restrict__ out)
+{
+  __shared__ double ssum[6][256];
+  __shared__ double smax[6][256];
+  const int nbi = nb.b[0], nbj = nb.b[1], nbk = nb.b[2];
+  const int b = blockIdx.x;
+  const int bi = b % nbi, bj = (b / nbi) % nbj, bk = b / (nbi * nbj);
+  const int i0 = 1 + bi * nb.b[3], j0 = 1 + bj * nb.b[4], k0 = 1 + bk * nb.b[5];
+  const int i1 = bi == nbi - 1 ? z.iv : (bi + 1) * nb.b[3];
+  const int j1 = bj == nbj - 1 ? z.jv : (bj + 1) * nb.b[4];
+  const int k1 = bk == nbk - 1 ? z.kv : (bk + 1) * nb.b[5];
+  const int ni = i1 - i0 + 1, nj = j1 - j0 + 1;
+  const long long n = (long long)ni * nj * (k1 - k0 + 1);
+  const int neq = z.neq;
+  double s[6] = {0, 0, 0, 0, 0, 0}, m[6] = {0, 0, 0, 0, 0, 0};
+  for (long long t = threadIdx.x; t < n; t += blockDim.x) {
+    const int i = i0 + (int)(t % ni), j = j0 + (int)((t / ni) % nj), k = k0 + (int)(t / ((long long)ni * nj));
+    const long long l = fs_inddm(z, i, j, k);
+    for (int e = 0; e < neq; e++) {
+      const double r = drodm[e * z.nd + l];
+      s[e] = s[e] + r * r;
+      m[e] = fs_max(m[e], fabs(r));
+    }
+  }
+  for (int e = 0; e < 6; e++) { ssum[e][threadIdx.x] = s[e]; smax[e][threadIdx.x] = m[e]; }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+      for (int e = 0; e < 6; e++) {
+        ssum[e][threadIdx.x] = ssum[e][threadIdx.x] + ssum[e][threadIdx.x + w];
+        smax[e][threadIdx.x] = fs_max(smax[e][threadIdx.x], smax[e][threadIdx.x + w]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int e = 0; e < 6; e++) { out[(long long)b * 12 + e] = ssum[e][0]; out[(long long)b * 12 + 6 + e] = smax[e][0]; }
 }
 
 __global__ void __launch_bounds__(256) k_residual_final(long long nblk, const double *__restrict__ part,
@@ -776,12 +822,14 @@ void fsk_bc_windows(const FsZone &z, int nwin, const FsBcWin *dev_wins, int kind
   if (kinds & 2) hipLaunchKernelGGL(k_bc_windows, dim3(gx, nwin), dim3(256), 0, s, z, nwin, dev_wins, rop);
 }
 
-void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s)
+void fsk_bc_edges(const FsZone &z, double *rop, hipStream_t s, const int *box)
 {
   int m = z.iv > z.jv ? z.iv : z.jv;
   if (z.kv > m) m = z.kv;
   unsigned gx = cdiv((long long)m * z.ific * z.ific, 256);
-  hipLaunchKernelGGL(k_bc_edges, dim3(gx, 20), dim3(256), 0, s, z, rop);
+  FsBox b = {{1, z.iv, 1, z.jv, 1, z.kv}};
+  if (box) for (int q = 0; q < 6; q++) b.b[q] = box[q];
+  hipLaunchKernelGGL(k_bc_edges, dim3(gx, 20), dim3(256), 0, s, z, b, rop);
 }
 
 void fsk_join_copy(int npts, int neq, long long nd_r, long long nd_d, const int *rcv, const int *dnr,
@@ -822,6 +870,13 @@ void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *par
 {
   hipLaunchKernelGGL(k_residual_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, use_coe, drodm, part, coe1);
   hipLaunchKernelGGL(k_residual_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv, part, out);
+}
+
+void fsk_residual_blocks(const FsZone &z, const int nblk[3], const int size[3], const double *drodm, double *out,
+                         hipStream_t s)
+{
+  FsBox nb = {{nblk[0], nblk[1], nblk[2], size[0], size[1], size[2]}};
+  hipLaunchKernelGGL(k_residual_blocks, dim3((unsigned)(nblk[0] * nblk[1] * nblk[2])), dim3(256), 0, s, z, nb, drodm, out);
 }
 
 void fsk_tgv_sums(const FsZone &z, const double *rop, double *part, double *out, hipStream_t s)

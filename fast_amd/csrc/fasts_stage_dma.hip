@@ -445,6 +445,7 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
       for (int e = 0; e < 5; e++) d[e] = part[e] - fk[e];
       if (k > k0 && cell_ok && !XF(1)) {
         if (BDF) {
+          if (fs_in_box(bdf, i, j, k - 1)) {
           double qn[5] = {0., 0., 0., 0., 0.}, qn1[5], r[5];
 #pragma unroll
           for (int e = 0; e < 5; e++) qn1[e] = ldg(P(bdf.ro_n1, e, k - 1), ob);
@@ -456,6 +457,7 @@ k_stage_dma(FsZone z, double coefH, double coefW, int kchunk, int ntile_i, int n
           fs_bdf_residual(z, bdf, coe1, qb, qn, qn1, d, r);
 #pragma unroll
           for (int e = 0; e < 5; e++) stg(PW_(drodm, e, k - 1), ob, r[e]);
+          }
         } else {
           if (keep) {   // the balance of the last Runge-Kutta stage of a step is read by nothing
 #pragma unroll

@@ -281,10 +281,11 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
     const RdGlobal rdg = {rop, nd, l, z.incj, TWOD ? 0 : z.inck};
     double fk[NQ] = {};
     // finish: the balance of a cell is complete (3-D: cell k-1 once its k+1/2 face is known; 2-D: the cell itself)
-    auto finish = [&](long long lb, long long ltb, const double *qcell, const double *d) {
+    auto finish = [&](long long lb, long long ltb, const double *qcell, const double *d, int kb) {
         double o[NQ];
         const double coe = z.dt / z.vol[ltb];
         if (BDF) {
+          if (!fs_in_box(bdf, i, j, kb)) return;   // a sub-zone: the other cells keep their residual
           double qn[NQ] = {}, qn1[NQ];
 #pragma unroll
           for (int e = 0; e < NQ; e++) qn1[e] = bdf.ro_n1[e * nd + lb];
@@ -333,7 +334,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
         double d[NQ];
 #pragma unroll
         for (int e = 0; e < NQ; e++) d[e] = part[e] - fk[e];
-        finish(l - z.inck, lt - z.minck, qb, d);
+        finish(l - z.inck, lt - z.minck, qb, d, k - 1);
       }
     }
     if (!last) {
@@ -382,7 +383,7 @@ k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const d
           if (NQ == 6 && e == 5) dr = dr + src;
           part[e] = dr + fk[e] + fjm[e] + fim[e] - fip[e] - sfj[buf][e][tj + 1][ti];
         }
-        if (TWOD) finish(l, lt, qc, part);
+        if (TWOD) finish(l, lt, qc, part, k);
       }
     }
 #pragma unroll
@@ -413,7 +414,98 @@ __global__ void __launch_bounds__(256) k_sa_coe6_full(FsZone z, const double *__
   coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
 }
 
+template <int KFLU, int IFLOW, bool TWOD, bool HOMO>
+__global__ void __launch_bounds__(128) k_box_faces_full(FsZone z, FsBox box, const double *__restrict__ rop,
+                                                        const double *__restrict__ xmut, unsigned char *__restrict__ wig,
+                                                        double *__restrict__ drodm)
+{
+  constexpr int NQ = IFLOW == 3 ? 6 : 5;
+  const int side = blockIdx.y;
+  if (TWOD && side >= 4) return;
+  int i, j, k;
+  if (!box_face_cell(z, box, side, (long long)blockIdx.x * blockDim.x + threadIdx.x, i, j, k)) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  const long long lt = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck;
+  const int d = side >> 1;
+  const long long st = d == 0 ? 1 : (d == 1 ? z.incj : z.inck);
+  double qm2[NQ], qm1[NQ], q0[NQ], qp1[NQ], f[NQ];
+#pragma unroll
+  for (int e = 0; e < NQ; e++) {
+    qm2[e] = rop[e * nd + l - 2 * st]; qm1[e] = rop[e * nd + l - st]; q0[e] = rop[e * nd + l]; qp1[e] = rop[e * nd + l + st];
+  }
+  const RdGlobal rdg = {rop, nd, l, z.incj, TWOD ? 0 : z.inck};
+  if (d == 0) face_full<KFLU, IFLOW, 0, false, TWOD, HOMO>(z, rdg, xmut, wig, l, lt, qm2, qm1, q0, qp1, f);
+  else if (d == 1) face_full<KFLU, IFLOW, 1, false, TWOD, HOMO>(z, rdg, xmut, wig, l, lt, qm2, qm1, q0, qp1, f);
+  else if (!TWOD) face_full<KFLU, IFLOW, 2, false, TWOD, HOMO>(z, rdg, xmut, wig, l, lt, qm2, qm1, q0, qp1, f);
+  if (side & 1) {
+    // the cell past the box takes the flux of the five mean-flow equations only (SA/flu_send_scater_vec1.for gives the
+    // 6th to the cell inside alone)
+#pragma unroll
+    for (int e = 0; e < 5; e++) drodm[e * nd + l] = drodm[e * nd + l] + f[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < NQ; e++) drodm[e * nd + l - st] = drodm[e * nd + l - st] - f[e];
+  }
+}
+
+// cells of the layer around the box that are interior cells of the zone: drodm(:,6) += vol * source (no layer along k
+// on a two-dimensional zone)
+template <bool TWOD, bool HOMO = false>
+__global__ void __launch_bounds__(256) k_sa_ring_full(FsZone z, FsBox box, const double *__restrict__ rop,
+                                                      const double *__restrict__ dlng, double *__restrict__ drodm)
+{
+  const int gk = TWOD ? 0 : 1;
+  const int i = box.b[0] - 1 + blockIdx.x * blockDim.x + threadIdx.x, j = box.b[2] - 1 + blockIdx.y, k = box.b[4] - gk + blockIdx.z;
+  if (i > box.b[1] + 1) return;
+  if (i >= box.b[0] && i <= box.b[1] && j >= box.b[2] && j <= box.b[3] && k >= box.b[4] && k <= box.b[5]) return;
+  if (i < 1 || i > z.iv || j < 1 || j > z.jv || k < 1 || k > z.kv) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  const long long lt = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck;
+  double qc[6];
+#pragma unroll
+  for (int e = 0; e < 6; e++) qc[e] = rop[e * nd + l];
+  drodm[5 * nd + l] = drodm[5 * nd + l] + sa_source_full<TWOD, HOMO>(z, rop, dlng, l, lt, qc);
+}
+
 }  // namespace
+
+void fsk_box_faces_full(const FsZone &z, const int *box, const double *rop, const double *xmut, unsigned char *wig,
+                        double *drodm, hipStream_t s)
+{
+  FsBox b;
+  int m = 1;
+  for (int q = 0; q < 6; q++) b.b[q] = box[q];
+  for (int d = 0; d < 3; d++) {
+    const int a = d == 0 ? 1 : 0, c = d == 2 ? 1 : 2;
+    const int n = (box[2 * a + 1] - box[2 * a] + 1) * (box[2 * c + 1] - box[2 * c] + 1);
+    if (n > m) m = n;
+  }
+  dim3 g((unsigned)((m + 127) / 128), 6);
+#define FS_GO(K, F)                                                                                                     \
+  do {                                                                                                                  \
+    if (z.twod) hipLaunchKernelGGL((k_box_faces_full<K, F, true, false>), g, dim3(128), 0, s, z, b, rop, xmut, wig, drodm); \
+    else if (z.homo) hipLaunchKernelGGL((k_box_faces_full<K, F, false, true>), g, dim3(128), 0, s, z, b, rop, xmut, wig, drodm); \
+    else hipLaunchKernelGGL((k_box_faces_full<K, F, false, false>), g, dim3(128), 0, s, z, b, rop, xmut, wig, drodm);   \
+  } while (0)
+#define FS_CASE(K, F) if (z.kflu == K && z.iflow == F) { FS_GO(K, F); return; }
+  FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2) FS_CASE(1, 3) FS_CASE(2, 3) FS_CASE(5, 3)
+#undef FS_CASE
+#undef FS_GO
+}
+
+void fsk_sa_ring_source_full(const FsZone &z, const int *box, const double *rop, const double *dist, double *drodm,
+                             hipStream_t s)
+{
+  FsBox b;
+  for (int q = 0; q < 6; q++) b.b[q] = box[q];
+  const int gk = z.twod ? 0 : 1;
+  dim3 g((unsigned)((box[1] - box[0] + 3 + 255) / 256), (unsigned)(box[3] - box[2] + 3), (unsigned)(box[5] - box[4] + 1 + 2 * gk));
+  if (z.twod) hipLaunchKernelGGL(k_sa_ring_full<true>, g, dim3(256), 0, s, z, b, rop, dist, drodm);
+  else if (z.homo) hipLaunchKernelGGL((k_sa_ring_full<false, true>), g, dim3(256), 0, s, z, b, rop, dist, drodm);
+  else hipLaunchKernelGGL(k_sa_ring_full<false>, g, dim3(256), 0, s, z, b, rop, dist, drodm);
+}
 
 void fsk_sa_coe6_full(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s)
 {

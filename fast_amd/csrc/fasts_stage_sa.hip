@@ -208,8 +208,10 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const dou
             if (bdf.nit1) o[5] = coe * d[5] + (bdf.c1 + bdf.c2) * qb[5] * qb[0] + bdf.c3 * qn1[5] * qn1[0];
             else o[5] = coe * d[5] + bdf.c1 * qb[5] * qb[0] + bdf.c2 * qn[5] * qn[0] + bdf.c3 * qn1[5] * qn1[0];
           }
+          if (fs_in_box(bdf, i, j, k - 1)) {   // a sub-zone: the other cells keep their residual
 #pragma unroll
-          for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = o[e];
+            for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = o[e];
+          }
         } else {
         if (keep) {   // the balance of the last Runge-Kutta stage of a step is read by nothing
 #pragma unroll
@@ -307,7 +309,79 @@ __global__ void __launch_bounds__(256) k_sa_coe6(FsZone z, const double *__restr
   coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
 }
 
+template <int KFLU>
+__global__ void __launch_bounds__(128) k_box_faces_sa(FsZone z, FsBox box, const double *__restrict__ rop,
+                                                      const double *__restrict__ xmut, unsigned char *__restrict__ wig,
+                                                      double *__restrict__ drodm)
+{
+  const int side = blockIdx.y;
+  int i, j, k;
+  if (!box_face_cell(z, box, side, (long long)blockIdx.x * blockDim.x + threadIdx.x, i, j, k)) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  const int d = side >> 1;
+  const long long st = d == 0 ? 1 : (d == 1 ? z.incj : z.inck);
+  double qm2[NQ], qm1[NQ], q0[NQ], qp1[NQ], f[NQ];
+#pragma unroll
+  for (int e = 0; e < NQ; e++) {
+    qm2[e] = rop[e * nd + l - 2 * st]; qm1[e] = rop[e * nd + l - st]; q0[e] = rop[e * nd + l]; qp1[e] = rop[e * nd + l + st];
+  }
+  if (d == 0) face_sa<KFLU, 0, false>(z, rop, xmut, wig, l, qm2, qm1, q0, qp1, f);
+  else if (d == 1) face_sa<KFLU, 1, false>(z, rop, xmut, wig, l, qm2, qm1, q0, qp1, f);
+  else face_sa<KFLU, 2, false>(z, rop, xmut, wig, l, qm2, qm1, q0, qp1, f);
+  if (side & 1) {
+    // the cell past the box takes the flux of the five mean-flow equations only (SA/flu_send_scater_vec1.for gives the
+    // 6th to the cell inside alone)
+#pragma unroll
+    for (int e = 0; e < 5; e++) drodm[e * nd + l] = drodm[e * nd + l] + f[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < NQ; e++) drodm[e * nd + l - st] = drodm[e * nd + l - st] - f[e];
+  }
+}
+
+// cells of the layer around the box that are interior cells of the zone: drodm(:,6) += vol * source
+__global__ void __launch_bounds__(256) k_sa_ring(FsZone z, FsBox box, const double *__restrict__ rop,
+                                                 const double *__restrict__ dlng, double *__restrict__ drodm)
+{
+  const int i = box.b[0] - 1 + blockIdx.x * blockDim.x + threadIdx.x, j = box.b[2] - 1 + blockIdx.y, k = box.b[4] - 1 + blockIdx.z;
+  if (i > box.b[1] + 1) return;
+  if (i >= box.b[0] && i <= box.b[1] && j >= box.b[2] && j <= box.b[3] && k >= box.b[4] && k <= box.b[5]) return;
+  if (i < 1 || i > z.iv || j < 1 || j > z.jv || k < 1 || k > z.kv) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  double qc[NQ];
+#pragma unroll
+  for (int e = 0; e < NQ; e++) qc[e] = rop[e * nd + l];
+  drodm[5 * nd + l] = drodm[5 * nd + l] + sa_source(z, rop, dlng, l, qc);
+}
+
 }  // namespace
+
+void fsk_box_faces_sa(const FsZone &z, const int *box, const double *rop, const double *xmut, unsigned char *wig,
+                      double *drodm, hipStream_t s)
+{
+  FsBox b;
+  int m = 1;
+  for (int q = 0; q < 6; q++) b.b[q] = box[q];
+  for (int d = 0; d < 3; d++) {
+    const int a = d == 0 ? 1 : 0, c = d == 2 ? 1 : 2;
+    const int n = (box[2 * a + 1] - box[2 * a] + 1) * (box[2 * c + 1] - box[2 * c] + 1);
+    if (n > m) m = n;
+  }
+  dim3 g((unsigned)((m + 127) / 128), 6);
+  if (z.kflu == 1) hipLaunchKernelGGL(k_box_faces_sa<1>, g, dim3(128), 0, s, z, b, rop, xmut, wig, drodm);
+  else if (z.kflu == 2) hipLaunchKernelGGL(k_box_faces_sa<2>, g, dim3(128), 0, s, z, b, rop, xmut, wig, drodm);
+  else hipLaunchKernelGGL(k_box_faces_sa<5>, g, dim3(128), 0, s, z, b, rop, xmut, wig, drodm);
+}
+
+void fsk_sa_ring_source(const FsZone &z, const int *box, const double *rop, const double *dist, double *drodm, hipStream_t s)
+{
+  FsBox b;
+  for (int q = 0; q < 6; q++) b.b[q] = box[q];
+  dim3 g((unsigned)((box[1] - box[0] + 3 + 255) / 256), (unsigned)(box[3] - box[2] + 3), (unsigned)(box[5] - box[4] + 3));
+  hipLaunchKernelGGL(k_sa_ring, g, dim3(256), 0, s, z, b, rop, dist, drodm);
+}
 
 void fsk_sa_coe6(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s)
 {

@@ -163,6 +163,77 @@ long long row_cells(const FsWallRow &w)
 }  // namespace
 
 // One wall window: glo/ghi = its ghost-cell window (interior-based indices), tag = BC tag of the reference.
+// ---- faces of a sub-zone box: the flux of a face between cell l - inc(DIR) and cell l of a Cartesian zone, operands
+// from memory (the stage kernel takes them from its tile) ------------------------------------------------------------
+namespace {
+
+template <int KFLU, int IFLOW, int DIR>
+FS_DEV void face_cart(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
+                      const unsigned char *__restrict__ wig, long long l, double *flu)
+{
+  const long long nd = z.nd;
+  const long long inc[3] = {1, z.incj, z.inck};
+  const long long st = inc[DIR];
+  double qm2[5], qm1[5], q0[5], qp1[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    qm2[e] = rop[e * nd + l - 2 * st]; qm1[e] = rop[e * nd + l - st]; q0[e] = rop[e * nd + l]; qp1[e] = rop[e * nd + l + st];
+  }
+  // sensor of the face: bit DIR of the byte of cell l (written at the first sub-iteration, which covers the zone)
+  const double wg = KFLU == 2 ? (double)((wig[l] >> DIR) & 1u) : 0.;
+  fs_flux_inviscid<KFLU, DIR>(z, qm2, qm1, q0, qp1, wg, flu);
+  if (IFLOW == 2) {
+    constexpr int A = DIR == 0 ? 1 : 0, B = DIR == 2 ? 1 : 2;   // the transverse directions, in the order (i, j, k)
+    auto q = [&](int e, int da, int db, int dn) -> double { return rop[e * nd + l + dn * st + da * inc[A] + db * inc[B]]; };
+    fs_flux_viscous<DIR>(z, q, xmut[l - st], xmut[l], flu);
+  }
+}
+
+template <int KFLU, int IFLOW>
+__global__ void __launch_bounds__(128) k_box_faces_cart(FsZone z, FsBox box, const double *__restrict__ rop,
+                                                        const double *__restrict__ xmut,
+                                                        const unsigned char *__restrict__ wig, double *__restrict__ drodm)
+{
+  const int side = blockIdx.y;
+  int i, j, k;
+  if (!box_face_cell(z, box, side, (long long)blockIdx.x * blockDim.x + threadIdx.x, i, j, k)) return;
+  const long long l = wcell(z, i, j, k), nd = z.nd;
+  const int d = side >> 1;
+  double f[5];
+  if (d == 0) face_cart<KFLU, IFLOW, 0>(z, rop, xmut, wig, l, f);
+  else if (d == 1) face_cart<KFLU, IFLOW, 1>(z, rop, xmut, wig, l, f);
+  else face_cart<KFLU, IFLOW, 2>(z, rop, xmut, wig, l, f);
+  if (side & 1) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) drodm[e * nd + l] = drodm[e * nd + l] + f[e];
+  } else {
+    const long long l0 = l - (d == 0 ? 1 : (d == 1 ? z.incj : z.inck));
+#pragma unroll
+    for (int e = 0; e < 5; e++) drodm[e * nd + l0] = drodm[e * nd + l0] - f[e];
+  }
+}
+
+}  // namespace
+
+void fsk_box_faces_cart(const FsZone &z, const int *box, const double *rop, const double *xmut, const unsigned char *wig,
+                        double *drodm, hipStream_t s)
+{
+  FsBox b;
+  int m = 1;
+  for (int q = 0; q < 6; q++) b.b[q] = box[q];
+  for (int d = 0; d < 3; d++) {
+    const int a = d == 0 ? 1 : 0, c = d == 2 ? 1 : 2;
+    const int n = (box[2 * a + 1] - box[2 * a] + 1) * (box[2 * c + 1] - box[2 * c] + 1);
+    if (n > m) m = n;
+  }
+  dim3 g((unsigned)((m + 127) / 128), 6);
+#define FS_GO(K, F) hipLaunchKernelGGL((k_box_faces_cart<K, F>), g, dim3(128), 0, s, z, b, rop, xmut, wig, drodm)
+  if (z.kflu == 1) { if (z.iflow == 2) FS_GO(1, 2); else FS_GO(1, 1); }
+  else if (z.kflu == 2) { if (z.iflow == 2) FS_GO(2, 2); else FS_GO(2, 1); }
+  else { if (z.iflow == 2) FS_GO(5, 2); else FS_GO(5, 1); }
+#undef FS_GO
+}
+
 void fsk_roe_wall(const FsZone &z, int idir, const int *glo, const int *ghi, int tag, const double *rop, double *drodm,
                   hipStream_t s)
 {

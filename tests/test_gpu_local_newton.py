@@ -1,0 +1,90 @@
+"""'implicit_local' on the device against the golden vectors of the compiled reference (tests/golden/local_*.npz,
+make_golden_local.py): after every time step the field of every zone bit for bit, the boxes every sub-iteration worked
+on, the targets of the blocks, and on verification steps the norms of the sub-iterations that ran."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from fast_amd import connect, FastC, Internal
+import fast_amd.pytree_lite as C
+import fast_amd.PyTree as FastS
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import make_golden_local as ML
+
+
+def _run(name, layer):
+    c = ML.CASES[name]
+    g = np.load(os.path.join(HERE, 'golden', name + '.npz'))
+    t = ML.build(c)
+    tc = None
+    zones = Internal.getZones(t)
+    joins = ML.case_joins(c)
+    if joins:
+        tc = C.node2Center(t)
+        connect.add_joins_to_tc(tc, joins, [z[0] for z in zones])
+    (t, tc, metrics) = FastS.warmup(t, tc)
+    zones = Internal.getZones(t)
+    ctx = FastC.HOOK['ctx']
+    assert FastC.HOOK['lssiter_loc'] == 1
+    for b, z in enumerate(zones):
+        assert np.array_equal(Internal.getNodeFromName2(z, 'Parameter_int')[1], g['pint%d' % b])
+        assert np.array_equal(metrics[b][0], g['mtr%d' % b])
+        assert np.array_equal(FastC.level_buffer(z), g['ghost_%d' % b])
+    sa = c['model'] == 'NSTurbulent'
+    nssiter = int(g['pint0'][58])
+    for it in range(1, int(g['nit']) + 1):
+        FastS._compute(t, metrics, it, tc, layer=layer)
+        verif = it % c['kmod'] == 0
+        nbox = g['nbox_it%d' % it]; boxes = g['boxes_it%d' % it]
+        for b, z in enumerate(zones):
+            for nstep in range(1, nbox.shape[0] + 1):
+                if nstep == nssiter and not verif:
+                    continue          # the verification slot does not run: its list is not looked at
+                got = ctx.subzone_list(b, nstep)
+                want = boxes[nstep - 1, b, :nbox[nstep - 1, b]]
+                assert np.array_equal(got, want), "step %d zone %d sub-iteration %d: boxes %s, reference %s" % (
+                    it, b, nstep, got.tolist(), want.tolist())
+            key = 'ro_it%d_%d' % (it, b)
+            got = FastC.level_buffer(z)
+            if sa:
+                # the destruction term of the model takes a 1/6 power, and the device pow differs from the host's in
+                # the last bit: 1e-12 relative instead of equality
+                from common import rel_err
+                e = rel_err(got, g[key], int(g['pint%d' % b][41]), neq=6)
+                assert e.max() < 1e-12, "step %d zone %d: rel err %s" % (it, b, e)
+            else:
+                assert np.array_equal(got, g[key]), "step %d zone %d: max abs diff %g" % (it, b, np.abs(got - g[key]).max())
+            assert np.array_equal(ctx.subzone_targets(b), g['target_it%d_%d' % (it, b)]), "targets after step %d" % it
+            if verif:
+                h = g['hist_it%d_%d' % (it, b)]
+                l2, loo = ctx.residual_history(b, nssiter, h.shape[2])
+                assert l2.shape[0] == h.shape[0], "slots of the residual table"
+                np.testing.assert_allclose(l2, h[:, 0], rtol=1e-11, atol=1e-300)
+                np.testing.assert_allclose(loo, h[:, 1], rtol=1e-11 if sa else 1e-14, atol=1e-300)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", sorted(ML.CASES))
+def test_local_newton_equals_reference_golden(name):
+    _run(name, "c")
+
+
+def test_local_newton_python_layer():
+    """One sub-iteration per native call (stage / joins / BCs driven from Python): the same result."""
+    _run('local_channel_curv', "Python")
+
+
+def test_local_newton_refusals():
+    """Combinations the sub-zones are not implemented with are refused at upload, with a message."""
+    from fast_amd import _capi
+    c = dict(ML.CASES['local_tgv_ausmpred'])
+    t = ML.build(c)
+    FastC._setNum2Zones(t, {'nb_relax': 2})
+    with pytest.raises(_capi.FastsHipError, match="local Newton"):
+        FastS.warmup(t, None)
