@@ -8,7 +8,9 @@ import pytest
 from oracle import oracle as O
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLD = sorted(glob.glob(os.path.join(HERE, 'golden', '*.npz')))
+# the files of make_golden.py; those of make_golden_local.py ('implicit_local', local_*.npz) are replayed on the device
+# only (tests/test_gpu_local_newton.py), the host logic of their sub-zones in tests/test_subzones_pinned.py
+GOLD = sorted(f for f in glob.glob(os.path.join(HERE, 'golden', '*.npz')) if not os.path.basename(f).startswith('local_'))
 
 
 def load(path):
