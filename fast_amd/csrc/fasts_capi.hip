@@ -88,7 +88,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.blk_res);
-    for (auto &bb : zn.box_bcs) (void)hipFree(bb.dev);
+    for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); }
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
@@ -1006,6 +1006,27 @@ static int local_bc_tables(fs_ctx *ctx, Zone &zn, int nstep)
     bb.cap = wins.size();
   }
   if (!wins.empty()) HIPCHK(ctx, hipMemcpy(bb.dev, wins.data(), sizeof(FsBcWin) * wins.size(), hipMemcpyHostToDevice));
+  // tiles (Cartesian kernel) or patches (curvilinear kernel) that hold cells of a box: the stage of a box launches those
+  // alone; the Cartesian Spalart-Allmaras kernel takes no list and runs its whole grid, cells outside the box masked
+  bb.tile_off.clear(); bb.tile_cnt.clear();
+  if (!(z.iflow == 3 && z.ityp != 0)) {
+    const FsTiling t = z.ityp == 0 ? fsk_stage_full_tiling(z) : fsk_stage_dma_tiling(z);
+    std::vector<int> tiles;
+    for (size_t b = 0; b + 6 <= bx.size(); b += 6) {
+      bb.tile_off.push_back((int)tiles.size());
+      for (int bk = (bx[b + 4] - 1) / t.kchunk; bk <= (bx[b + 5] - 1) / t.kchunk; bk++)
+        for (int bj = (bx[b + 2] - 1) / t.tj; bj <= (bx[b + 3] - 1) / t.tj; bj++)
+          for (int bi = (bx[b] - 1) / t.ti; bi <= (bx[b + 1] - 1) / t.ti; bi++) tiles.push_back(bi + t.nti * (bj + t.ntj * bk));
+      bb.tile_cnt.push_back((int)tiles.size() - bb.tile_off.back());
+    }
+    if (tiles.size() > bb.tiles_cap) {
+      (void)hipFree(bb.tiles_dev);
+      bb.tiles_dev = nullptr; bb.tiles_cap = 0;
+      HIPCHK(ctx, hipMalloc(&bb.tiles_dev, sizeof(int) * tiles.size()));
+      bb.tiles_cap = tiles.size();
+    }
+    if (!tiles.empty()) HIPCHK(ctx, hipMemcpy(bb.tiles_dev, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
+  }
   return FS_OK;
 }
 
@@ -1188,18 +1209,25 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     const int keep = ctx->implicit || deferred || dtloc || nstep < z.nssiter || nstep == 1;
     for (int b = 0; b < nbox && !krc; b++) {
     if (boxes) for (int q = 0; q < 6; q++) bdf.box[q] = boxes[6 * b + q];   // cells outside the box keep their residual
+    // a box smaller than the zone: only the tiles that hold some of its cells are launched
+    const bool partial_box = boxes && memcmp(boxes + 6 * b, whole_box, sizeof whole_box) != 0 &&
+                             !zn.box_bcs[(size_t)nstep - 1].tile_cnt.empty();
+    const int *box_tiles = partial_box ? zn.box_bcs[(size_t)nstep - 1].tiles_dev + zn.box_bcs[(size_t)nstep - 1].tile_off[(size_t)b] : nullptr;
+    const int box_ntiles = partial_box ? zn.box_bcs[(size_t)nstep - 1].tile_cnt[(size_t)b] : 0;
     if (z.iflow == 3 && z.ityp != 0)
       krc = fsk_stage_sa(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut, zn.dist,
                          (unsigned char *)zn.wig, kbdf, keep, ctx->stream);
     else if (z.ityp == 0) {
       const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
-      const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
+      int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
+      if (partial_box) { blist = box_tiles; nlist = box_ntiles; }
       if (!split || nlist > 0)
         krc = fsk_stage_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
                              (unsigned char *)zn.wig, kbdf, zn.dist, keep, blist, nlist, ctx->stream);
     } else {
       const int *blist = !split ? nullptr : (part == 0 ? zn.shell_dev : zn.inner_dev);
-      const int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
+      int nlist = !split ? 0 : (part == 0 ? zn.n_shell : zn.n_inner);
+      if (partial_box) { blist = box_tiles; nlist = box_ntiles; }
       if (!split || nlist > 0)
         krc = fsk_stage_dma(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
                             (unsigned char *)zn.wig, blist, nlist, kbdf, keep, ctx->stream);

@@ -60,7 +60,12 @@ struct Zone {
   double *blk_res = nullptr;
   struct PendingNorms { int nstep, nis; std::vector<int32_t> no_lu; };
   std::vector<PendingNorms> pending;
-  struct BoxBcs { FsBcWin *dev = nullptr; size_t cap = 0; int n = 0, kinds = 0; long long max_cells = 0; };
+  struct BoxBcs {
+    FsBcWin *dev = nullptr; size_t cap = 0; int n = 0, kinds = 0; long long max_cells = 0;
+    // tiles of the stage kernel that hold cells of each box: one list after the other on the device
+    int *tiles_dev = nullptr; size_t tiles_cap = 0;
+    std::vector<int> tile_off, tile_cnt;
+  };
   std::vector<BoxBcs> box_bcs;
   std::vector<double> res_host;   // 12 norms per slot of the last verification step, summed over the blocks
 };
