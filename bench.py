@@ -206,6 +206,11 @@ def main():
     ap.add_argument('--lu-threads', type=int, default=1, metavar='T', help='with --implicit / --naca: LU-SGS solve in the '
                     'blocks of T OpenMP threads of the reference (its result with OMP_NUM_THREADS=T); 1 = one sweep per zone')
     ap.add_argument('--nb-relax', type=int, default=1, metavar='R', help='with --implicit / --naca: LU-SSOR with R relaxations')
+    ap.add_argument('--local-newton', type=int, default=0, metavar='S', help="with --implicit: temporal_scheme "
+                    "'implicit_local', Newton sub-iterations on the sub-zones (blocks of S^3 cells) that have not converged; "
+                    "modulo_verif 7, the reference's default for this scheme")
+    ap.add_argument('--epsi-newton', type=float, default=0.1, help='convergence threshold of the Newton sub-iterations '
+                    '(--local-newton)')
     ap.add_argument('--cfl', type=float, default=1., help='CFL number of the local time step (--naca)')
     ap.add_argument('--channel', type=int, nargs=3, default=None, metavar=('BI', 'BJ', 'BK'), help='one GPU\'s share of a '
                     'multi-block channel: the --cells^3 box cut in BI x 1 x BK curvilinear blocks (BJ must be 1), no-slip '
@@ -276,6 +281,10 @@ def main():
             kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': a.implicit}}
         if a.implicit and a.nb_relax > 1:
             kw['extra_numz'] = {'nb_relax': a.nb_relax}
+        if a.implicit and a.local_newton:
+            kw['temporal_scheme'] = 'implicit_local'
+            kw['modulo_verif'] = 7
+            kw['extra_numz'] = dict(kw.get('extra_numz') or {}, ssdom_IJK=[a.local_newton] * 3, epsi_newton=a.epsi_newton)
         t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n * (10. if a.implicit else 1.),
                       perturb=a.perturb, **kw)
         (t, tc, metrics) = FastS.warmup(t, None, device=local_rank)
@@ -318,6 +327,14 @@ def main():
     if not np.isfinite(FastC.level_buffer(z0)).all():
         raise SystemExit("bench.py: non-finite field after the run")
 
+    local_share = None
+    if a.implicit and a.local_newton and world == 1 and not a.naca and not a.channel:
+        # share of the cells each Newton sub-iteration works on, from the lists the library holds now
+        local_share = []
+        for ns in range(1, a.implicit + 1):
+            bx = ctx.subzone_list(0, ns)
+            cells = sum(int((b[1] - b[0] + 1) * (b[3] - b[2] + 1) * (b[5] - b[4] + 1)) for b in bx)
+            local_share.append(round(cells / float(a.n ** 3), 3))
     if rank == 0:
         # HBM bytes per launch from the PMC passes of this same command (collected in runs of their
         # own by profiles/run_profiles.sh; counters cannot be read inside a timed run)
@@ -353,7 +370,9 @@ def main():
                        "time_scheme": ("implicit BDF1 local time step, LU-SGS, %d Newton sub-iterations" if a.naca else
                                        "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit +
                                       (", %d LU-SSOR relaxations" % a.nb_relax if a.nb_relax > 1 else "") +
-                                      (", LU-SGS in the blocks of %d threads" % a.lu_threads if a.lu_threads > 1 else "")
+                                      (", LU-SGS in the blocks of %d threads" % a.lu_threads if a.lu_threads > 1 else "") +
+                                      (", implicit_local: sub-zones of %d^3-cell blocks, cells worked on per sub-iteration "
+                                       "at the end of the run: %s" % (a.local_newton, local_share) if local_share else "")
                                       if a.implicit else "explicit RK3"},
             "roofline": {"bound": "hbm", "kernel": "rk_stage", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

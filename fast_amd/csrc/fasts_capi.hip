@@ -88,7 +88,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.blk_res);
-    for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); }
+    for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); (void)hipFree(bb.lu_dev); }
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
@@ -1006,6 +1006,18 @@ static int local_bc_tables(fs_ctx *ctx, Zone &zn, int nstep)
     bb.cap = wins.size();
   }
   if (!wins.empty()) HIPCHK(ctx, hipMemcpy(bb.dev, wins.data(), sizeof(FsBcWin) * wins.size(), hipMemcpyHostToDevice));
+  // LU ranges: a box that reaches a wall face of the zone takes the ghost layer there (BC/BCzone.cpp:99-127)
+  bb.lu_ranges.clear();
+  for (size_t b = 0; b + 6 <= bx.size(); b += 6)
+    for (int q = 0; q < 6; q++) bb.lu_ranges.push_back(bx[b + q] == ends[q] ? zn.lu[q] : bx[b + q]);
+  if (bb.lu_ranges.size() > bb.lu_cap) {
+    (void)hipFree(bb.lu_dev);
+    bb.lu_dev = nullptr; bb.lu_cap = 0;
+    HIPCHK(ctx, hipMalloc(&bb.lu_dev, sizeof(int) * bb.lu_ranges.size()));
+    bb.lu_cap = bb.lu_ranges.size();
+  }
+  if (!bb.lu_ranges.empty())
+    HIPCHK(ctx, hipMemcpy(bb.lu_dev, bb.lu_ranges.data(), sizeof(int) * bb.lu_ranges.size(), hipMemcpyHostToDevice));
   // tiles (Cartesian kernel) or patches (curvilinear kernel) that hold cells of a box: the stage of a box launches those
   // alone; the Cartesian Spalart-Allmaras kernel takes no list and runs its whole grid, cells outside the box masked
   bb.tile_off.clear(); bb.tile_cnt.clear();
@@ -1328,14 +1340,11 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       }
       int lrc = 0;
       if (ctx->local_newton) {
-        // one sweep pair per box; its range takes the ghost layer of a wall face where the box reaches it
-        // (BC/BCzone.cpp:99-127), neighbour terms across the other borders of the box are left out (LU/invlu_l.for:90-215)
-        for (int b = 0; b < nbox && !lrc; b++) {
-          int range[6];
-          for (int q = 0; q < 6; q++) range[q] = boxes[6 * b + q] == whole_box[q] ? zn.lu[q] : boxes[6 * b + q];
-          lrc = fsk_lusgs(z, range, 0, nullptr, nullptr, zn.preal[GAMMA], zn.dev[in], zn.dev[out], zn.scratch, zn.drodm,
-                          zn.coe, ls);
-        }
+        // one sweep pair over the boxes, side by side like the blocks of the reference's threads: neighbour terms across
+        // the borders of a box are left out (LU/invlu_l.for:90-215), the Newton update touches the boxes alone
+        const Zone::BoxBcs &bb = zn.box_bcs[(size_t)nstep - 1];
+        lrc = fsk_lusgs(z, nbox > 1 ? zn.lu : bb.lu_ranges.data(), nbox, bb.lu_ranges.data(), bb.lu_dev, zn.preal[GAMMA],
+                        zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, true);
       } else {
       const int sdm[6] = {1, z.iv, 1, z.jv, 1, z.kv};
       // lu_match = 1: the sweeps of invlu_overlap_{l,u}.for (with nb_relax > 1, 5 equations: the LU-SSOR sweeps whatever

@@ -65,6 +65,8 @@ struct Zone {
     // tiles of the stage kernel that hold cells of each box: one list after the other on the device
     int *tiles_dev = nullptr; size_t tiles_cap = 0;
     std::vector<int> tile_off, tile_cnt;
+    // LU ranges of the boxes (a wall face takes its ghost layer), host and device
+    std::vector<int> lu_ranges; int *lu_dev = nullptr; size_t lu_cap = 0;
   };
   std::vector<BoxBcs> box_bcs;
   std::vector<double> res_host;   // 12 norms per slot of the last verification step, summed over the blocks

@@ -62,11 +62,7 @@ int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const d
                  int keep_balance, hipStream_t s);
 // coe(:,6), diagonal of the nu_tilde equation, interior + one ghost layer; needs coe(:,1) and coe(:,5)
 void fsk_sa_coe6(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
-// Sub-zones: the source term of the nu_tilde equation is evaluated on the box and the layer of cells around it
-// (ind_ssa of Fast/FastC/FastC/HPC_LAYER/indice_boucle_ssdom.for:105-160; SA/spsource_SA.for adds it to drodm(:,6)
-// there), the balance is started from zero on the box alone: the interior cells of that layer keep what they held of
-// the 6th equation plus the source.  box = i1, i2, j1, j2, k1, k2.  _full: curvilinear, k-homogeneous and 2-D zones.
-struct FsBox { int b[6]; };
+struct FsBox { int b[6]; };   // i1, i2, j1, j2, k1, k2
 // Sub-zones: the flux loops of the reference add the flux of a face to the cell on its upper side and take it from the
 // cell on its lower side, the cells just outside the range included (Compute/template_FluxAndBalance.for:192-271,
 // assemble_drodm_plus_vec1.for, flu_send_scater_vec1.for).  For a box inside a zone the interior cells that touch it
@@ -80,6 +76,10 @@ void fsk_box_faces_sa(const FsZone &z, const int *box, const double *rop, const 
                       double *drodm, hipStream_t s);
 void fsk_box_faces_full(const FsZone &z, const int *box, const double *rop, const double *xmut, unsigned char *wig,
                         double *drodm, hipStream_t s);
+// Sub-zones: the source term of the nu_tilde equation is evaluated on the box and the layer of cells around it
+// (ind_ssa of Fast/FastC/FastC/HPC_LAYER/indice_boucle_ssdom.for:105-160; SA/spsource_SA.for adds it to drodm(:,6)
+// there), the balance is started from zero on the box alone: the interior cells of that layer keep what they held of
+// the 6th equation plus the source.  box = i1, i2, j1, j2, k1, k2.  _full: curvilinear, k-homogeneous and 2-D zones.
 void fsk_sa_ring_source(const FsZone &z, const int *box, const double *rop, const double *dist, double *drodm, hipStream_t s);
 void fsk_sa_ring_source_full(const FsZone &z, const int *box, const double *rop, const double *dist, double *drodm,
                              hipStream_t s);
@@ -114,8 +114,10 @@ void fsk_tgv_sums(const FsZone &z, const double *rop, double *part, double *out,
 void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, double gamma, double prandtl, double rgp,
                       const double *rop, const double *xmut, double *coe, hipStream_t s);
 // range[6] = cells swept (interior, plus one ghost layer on wall faces)
+// apart = true: the blocks are boxes that do not cover `range` (sub-zones): nothing outside them is touched
 int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
-              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s);
+              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s,
+              bool apart = false);
 int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nblocks, const int *blocks, const int *blocks_dev,
                int nb_relax, int overlap, double gamma, const double *rop, double *rop_out, double *scratch, const double *din,
                double *work, const double *coe, hipStream_t s);

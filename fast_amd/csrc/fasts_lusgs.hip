@@ -774,7 +774,8 @@ void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, doub
 // blocks tile `range`.  A launch then advances every block by one hyperplane (blockIdx.z = block).
 template <int U>
 static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
-                        const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s)
+                        const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s,
+                        bool apart)
 {
   LuConst c;
   c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
@@ -849,7 +850,14 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
 #undef FS_LOW
 #undef FS_UPP
     }
-  if (inplace) {
+  if (inplace && multi && apart) {   // the new iterate exists inside the boxes only
+    for (int b = 0; b < nb; b++) {
+      const int *q = br + 6 * b;
+      const LuRange rb = {q[0], q[1], q[2], q[3], q[4], q[5]};
+      dim3 g((unsigned)((q[1] - q[0] + 1 + 255) / 256), (unsigned)(q[3] - q[2] + 1), (unsigned)(q[5] - q[4] + 1));
+      hipLaunchKernelGGL(k_copy_range, g, dim3(256), 0, s, z, rb, (const double *)scratch, rop_out);
+    }
+  } else if (inplace) {
     dim3 g((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
     hipLaunchKernelGGL(k_copy_range, g, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
   }
@@ -857,7 +865,7 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
 }
 
 int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
-              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s)
+              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s, bool apart)
 {
   // units of U consecutive cells of an i-line: the recurrence of a launch has U steps, a sweep ni/U + nj + nk - 2
   // launches of (cells of the hyperplane)/64 waves.  One sweep of the zone is bound by the latency of a launch:
@@ -866,8 +874,8 @@ int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks,
   // a launch carries a hyperplane of every block and is bound by memory instead: a unit of 16 cells is a whole
   // 128-byte line of every array where 8 cells use half of each line they touch (256^3 in the blocks of 64 threads:
   // 23.4 ms per step with U = 8, 17.2 ms with U = 16; NACA0012 in 24 blocks 5.6 / 4.1 ms).
-  if (nblocks > 1) return lusgs_sweeps<16>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s);
-  return lusgs_sweeps<8>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s);
+  if (nblocks > 1) return lusgs_sweeps<16>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s, apart);
+  return lusgs_sweeps<8>(z, range, nblocks, blocks, blocks_dev, gamma, rop, rop_out, scratch, dw, coe, s, false);
 }
 
 // LU-SSOR with nb_relax >= 2 on the range `range`, Newton update on the cells of `sdm` (the interior of the zone).
