@@ -9,7 +9,7 @@
  *
  * Scope: zone types 0 (curvilinear), 1 (k-homogeneous), 2 (Cartesian, constant step) and 3 (two-dimensional);
  * 5 equations or 6 (Spalart-Allmaras); schemes ausmpred (1) / senseur (2) / roe (5), slope o3 (roe also o1 and
- * minmod); explicit RK1/2/3 with a global or a local time step; implicit BDF with LU-SGS, LU-SSOR, the overlap
+ * minmod) or, with 5 equations, o3sc (the o3 states weighted by a shock sensor); explicit RK1/2/3 with a global or a local time step; implicit BDF with LU-SGS, LU-SSOR, the overlap
  * sweeps of lu_match and selective frequency damping; ghost fill for the boundary conditions cited at fo_bc_*,
  * roe wall-flux correction,
  * edge/corner fix.  Array layout, loop ranges and
@@ -164,9 +164,137 @@ void fo_wiggle(const i32 *p, const i32 *ind, const double *rop, double *wig)
       }
 }
 
+/* Directional shock sensor of the o3sc slope (Fast/FastS/FastS/Compute/SENSOR/sciacovelli.for, shock_sensor.for; velocity
+ * divergence and squared vorticity from SA/div_rot_{3dfull,3dhomo,3dcart,2d}.for, face sizes from SA/metric_*.for):
+ * for every cell of the range and, on the max sides of the zone, the plane of ghost cells whose lower face is the
+ * boundary face, wig(l, dir) = 1 - min(2 div^2 / (div^2 + rot + 1e-15) * |p- - 2 p + p+| / |p- + 2 p + p+| *
+ * 0.5 (1 - tanh(2.5 + 10 div / (tc a))), 1), written after the three wiggle arrays when the scheme is senseur.
+ * ti / tj / tk of a k-homogeneous zone padded to three components as for the fluxes. */
+#define NIJK_MTR_ 5
+#define NDIMDX_MTR_ 43
+static void shock_cell(const i32 *p, const double *pr, const double *rop, const double *ti, const double *tj,
+                       const double *tk, const double *vol, double *wsc, int i, int j, int k, int dirs, const int *mcell)
+{
+  const long ni = p[NIJK], nj = p[NIJK + 1], nd = p[NDIMDX];
+  const int ific = p[NIJK + 3], ifick = p[NIJK + 4];
+  const long inc[3] = {1, ni, ni * nj};
+  const long l = (long)(i + ific - 1) + (long)(j + ific - 1) * ni + (long)(k + ifick - 1) * ni * nj;
+  const int typ = p[ITYPZONE];
+  const long l1 = l + 1, l2 = l - 1, l3 = l + inc[1], l4 = l - inc[1], l5 = l + inc[2], l6 = l - inc[2];
+  const double gam = pr[GAMMA], rgp = pr[CVINF] * (gam - 1.);
+  const double *U = rop + nd, *V = rop + 2 * nd, *W = rop + 3 * nd;
+  double div, rot, tc[3];
+  if (typ == 2) {
+    const double tix = ti[0], tjy = tj[0], tkz = tk[0];
+    tc[0] = fabs(tix); tc[1] = fabs(tjy); tc[2] = fabs(tkz);
+    const double xvol = 0.5 / vol[0];
+    double u1, u2, u3, u4, u5, u6, dudx, rotx, roty, rotz;
+    u1 = U[l] + U[l2]; u2 = U[l] + U[l3]; u3 = U[l] + U[l1]; u4 = U[l] + U[l4]; u5 = U[l] + U[l5]; u6 = U[l] + U[l6];
+    dudx = (u3 - u1) * tix; rotz = -(u2 - u4) * tjy; roty = (u5 - u6) * tkz; div = dudx * xvol;
+    u1 = V[l] + V[l2]; u2 = V[l] + V[l3]; u3 = V[l] + V[l1]; u4 = V[l] + V[l4]; u5 = V[l] + V[l5]; u6 = V[l] + V[l6];
+    dudx = (u3 - u1) * tix; rotz = (rotz + dudx) * xvol;
+    dudx = (u2 - u4) * tjy; div = div + dudx * xvol;
+    dudx = (u5 - u6) * tkz; rotx = -dudx;
+    u1 = W[l] + W[l2]; u2 = W[l] + W[l3]; u3 = W[l] + W[l1]; u4 = W[l] + W[l4]; u5 = W[l] + W[l5]; u6 = W[l] + W[l6];
+    dudx = (u3 - u1) * tix; roty = (roty - dudx) * xvol;
+    dudx = (u2 - u4) * tjy; rotx = (rotx + dudx) * xvol;
+    dudx = (u5 - u6) * tkz; div = div + dudx * xvol;
+    rot = rotx * rotx + roty * roty + rotz * rotz;
+  } else {
+    const long ndm = p[NDIMDX_MTR_];
+    const long minc[3] = {p[NIJK_MTR_], p[NIJK_MTR_ + 1], p[NIJK_MTR_ + 2]};
+    /* mcell: the cell whose metrics are used (the ghost planes take those of the last cell of the range, see below) */
+    const long lt = (long)(mcell[0] + p[NIJK_MTR_ + 3] - 1) * minc[0] + (long)(mcell[1] + p[NIJK_MTR_ + 3] - 1) * minc[1] +
+                    (long)(mcell[2] + p[NIJK_MTR_ + 4] - 1) * minc[2];
+    const int twod = typ == 3, homo = typ == 1;
+    const double tix = ti[lt], tiy = ti[lt + ndm], tiz = (twod || homo) ? 0. : ti[lt + 2 * ndm];
+    const double tix1 = ti[lt + minc[0]], tiy1 = ti[lt + minc[0] + ndm], tiz1 = (twod || homo) ? 0. : ti[lt + minc[0] + 2 * ndm];
+    const double tjx = tj[lt], tjy = tj[lt + ndm], tjz = (twod || homo) ? 0. : tj[lt + 2 * ndm];
+    const double tjx1 = tj[lt + minc[1]], tjy1 = tj[lt + minc[1] + ndm], tjz1 = (twod || homo) ? 0. : tj[lt + minc[1] + 2 * ndm];
+    double tkx = 0., tky = 0., tkz = 0., tkx1 = 0., tky1 = 0., tkz1 = 0.;
+    if (homo) tkz = tk[lt + 2 * ndm];
+    else if (!twod) {
+      tkx = tk[lt]; tky = tk[lt + ndm]; tkz = tk[lt + 2 * ndm];
+      tkx1 = tk[lt + minc[2]]; tky1 = tk[lt + minc[2] + ndm]; tkz1 = tk[lt + minc[2] + 2 * ndm];
+    }
+    double t;
+    t = sqrt(tix * tix + tiy * tiy + tiz * tiz); t = t + sqrt(tix1 * tix1 + tiy1 * tiy1 + tiz1 * tiz1); tc[0] = dmax(.5 * t, 1.e-27);
+    t = sqrt(tjx * tjx + tjy * tjy + tjz * tjz); t = t + sqrt(tjx1 * tjx1 + tjy1 * tjy1 + tjz1 * tjz1); tc[1] = dmax(.5 * t, 1.e-27);
+    if (homo) tc[2] = dmax(fabs(tkz), 1.e-27);
+    else {
+      t = sqrt(tkx * tkx + tky * tky + tkz * tkz); t = t + sqrt(tkx1 * tkx1 + tky1 * tky1 + tkz1 * tkz1); tc[2] = dmax(.5 * t, 1.e-27);
+    }
+    const double xvol = 0.5 / vol[lt];
+    double u1, u2, u3, u4, u5 = 0., u6 = 0., dudx, rotx = 0., roty = 0., rotz;
+    /* gradient component along m of a velocity: the general sum, or its two- / one-term forms */
+#define GX (twod || homo ? (u3 * tix1 - u1 * tix + u2 * tjx1 - u4 * tjx) : (u3 * tix1 - u1 * tix + u2 * tjx1 - u4 * tjx + u5 * tkx1 - u6 * tkx))
+#define GY (twod || homo ? (u3 * tiy1 - u1 * tiy + u2 * tjy1 - u4 * tjy) : (u3 * tiy1 - u1 * tiy + u2 * tjy1 - u4 * tjy + u5 * tky1 - u6 * tky))
+#define GZ (homo ? (u5 - u6) * tkz : (u3 * tiz1 - u1 * tiz + u2 * tjz1 - u4 * tjz + u5 * tkz1 - u6 * tkz))
+    u1 = U[l] + U[l2]; u2 = U[l] + U[l3]; u3 = U[l] + U[l1]; u4 = U[l] + U[l4];
+    if (!twod) { u5 = U[l] + U[l5]; u6 = U[l] + U[l6]; }
+    dudx = GX; div = dudx * xvol;
+    rotz = -GY;
+    if (!twod) roty = GZ;
+    u1 = V[l] + V[l2]; u2 = V[l] + V[l3]; u3 = V[l] + V[l1]; u4 = V[l] + V[l4];
+    if (!twod) { u5 = V[l] + V[l5]; u6 = V[l] + V[l6]; }
+    dudx = GX; rotz = (rotz + dudx) * xvol;
+    dudx = GY; div = div + dudx * xvol;
+    if (!twod) {
+      dudx = GZ; rotx = -dudx;
+      u1 = W[l] + W[l2]; u2 = W[l] + W[l3]; u3 = W[l] + W[l1]; u4 = W[l] + W[l4]; u5 = W[l] + W[l5]; u6 = W[l] + W[l6];
+      dudx = GX; roty = (roty - dudx) * xvol;
+      dudx = GY; rotx = (rotx + dudx) * xvol;
+      dudx = GZ; div = div + dudx * xvol;
+      rot = rotx * rotx + roty * roty + rotz * rotz;
+    } else
+      rot = rotz * rotz;
+#undef GX
+#undef GY
+#undef GZ
+  }
+  for (int d = 0; d < 3; d++) {
+    if (!(dirs & (1 << d))) continue;
+    double mach = sqrt(gam * rgp * rop[l + 4 * nd]);
+    mach = 10.0 * (1.0 / tc[d]) * (1.0 / mach) * div;
+    mach = 0.5 * (1.0 - tanh(2.5 + mach));
+    const double p2 = rop[l - inc[d]] * rop[l - inc[d] + 4 * nd], p0 = rop[l] * rop[l + 4 * nd];
+    const double p1 = rop[l + inc[d]] * rop[l + inc[d] + 4 * nd];
+    double w = fabs(p2 - 2. * p0 + p1) / fabs(p2 + 2. * p0 + p1);
+    w = dmin(2.0 * div * div / (div * div + rot + 1e-15) * w * mach, 1.0);
+    wsc[l + d * nd] = 1.0 - w;
+  }
+}
+
+void fo_sciacovelli(const i32 *p, const double *pr, const i32 *ind, const double *rop, const double *ti,
+                    const double *tj, const double *tk, const double *vol, double *wig)
+{
+  const long nd = p[NDIMDX];
+  double *wsc = wig + (p[KFLUDOM] == 2 ? 3 * nd : 0);
+  const int twod = p[ITYPZONE] == 3;
+  const int all = twod ? 3 : 7;
+  for (int k = ind[4]; k <= ind[5]; k++)
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) {
+        const int c[3] = {i, j, k};
+        shock_cell(p, pr, rop, ti, tj, tk, vol, wsc, i, j, k, all, c);
+      }
+  /* The loops over the ghost planes of the max sides (loopPlanI/J/K_begin.for) set the cell index only: the metric
+   * index keeps the value the main loop left, that of its last cell (sciacovelli.for:96-127). */
+  const int last[3] = {ind[1], ind[3], ind[5]};
+  if (ind[1] == p[IJKV])
+    for (int k = ind[4]; k <= ind[5]; k++)
+      for (int j = ind[2]; j <= ind[3]; j++) shock_cell(p, pr, rop, ti, tj, tk, vol, wsc, ind[1] + 1, j, k, 1, last);
+  if (ind[3] == p[IJKV + 1])
+    for (int k = ind[4]; k <= ind[5]; k++)
+      for (int i = ind[0]; i <= ind[1]; i++) shock_cell(p, pr, rop, ti, tj, tk, vol, wsc, i, ind[3] + 1, k, 2, last);
+  if (!twod && ind[5] == p[IJKV + 2])
+    for (int j = ind[2]; j <= ind[3]; j++)
+      for (int i = ind[0]; i <= ind[1]; i++) shock_cell(p, pr, rop, ti, tj, tk, vol, wsc, i, j, ind[5] + 1, 4, last);
+}
+
 typedef struct {
   int kflu, iflow;
-  int slope;        /* 1 o1, 2 o3, 3 minmod (roe only: ROE/fluroe_select.for) */
+  int slope;        /* 1 o1, 2 o3, 3 minmod (roe only: ROE/fluroe_select.for); 6 o3sc (every scheme) */
   double tmin_1;    /* minmod: no slope below 0.01 Tinf (template_FluxAndBalance.for:136) */
   double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
   double tcx, tcy, tcz, si, sj, sk, volinv;
@@ -189,8 +317,14 @@ static inline double avmin(double c, double r)
 
 /* Right (qm) and left (qp) states of one variable q on the face between nm and l:
  * Fast/FastS/FastS/Compute/Slope/o3_slope_var.for, o1_slope_var.for, minmod_slope_var.for.  t_l = temperature of l. */
-#define SLOPE_STATES(c, q, t_l, l, nm, nm2, np, qm_, qp_)                                   \
+#define SLOPE_STATES(c, q, t_l, l, nm, nm2, np, qm_, qp_, csc)                              \
   do {                                                                                     \
+    if ((c)->slope == 6) {   /* o3sc_slope_var.for: o3 states weighted by the shock sensor of the face */ \
+      qm_ = (c)->c4 * (q)[l] + (c)->c5 * (q)[nm] + (c)->c6 * (q)[np];                      \
+      qp_ = (c)->c4 * (q)[nm] + (c)->c6 * (q)[nm2] + (c)->c5 * (q)[l];                     \
+      qm_ = (q)[l] * (1. - (csc)) + qm_ * (csc);                                           \
+      qp_ = (q)[nm] * (1. - (csc)) + qp_ * (csc);                                          \
+    } else                                                                                 \
     if ((c)->slope == 1) { qm_ = (q)[l]; qp_ = (q)[nm]; }                                  \
     else if ((c)->slope == 3) {                                                            \
       const double roff_ = .5 * fmax(0., fmin((t_l) * (c)->tmin_1 - .5, 1.));              \
@@ -226,9 +360,12 @@ static inline void face_flux(const fluxctx *c, const double *rop, const double *
   const double tc = dir == 0 ? c->tcx : (dir == 1 ? c->tcy : c->tcz);
   const double s = dir == 0 ? c->si : (dir == 1 ? c->sj : c->sk);
   double qm[5], qp[5];
+  /* shock sensor of the face: the arrays after the wiggle sensor's when the scheme has one (sl_i / sl_j / sl_k of
+   * template_FluxAndBalance.for:175-182) */
+  const double csc = c->slope == 6 ? wig[l + dir * nd + (c->kflu == 2 ? 3 * nd : 0)] : 1.;
   for (int e = 0; e < 5; e++) {
     const double *q = rop + e * nd;
-    SLOPE_STATES(c, q, rop[l + 4 * nd], l, nm, nm2, np, qm[e], qp[e]);
+    SLOPE_STATES(c, q, rop[l + 4 * nd], l, nm, nm2, np, qm[e], qp[e], csc);
   }
   const int vn = 1 + dir; /* normal velocity component */
   double flu1, flu2, flu3, flu4, flu5, flu6 = 0., u_sa = 0., tdu_sa = 0.;
@@ -472,9 +609,10 @@ static inline void face_flux_full(const fluxctx *c, const double *rop, const dou
   const double tcx = Tn[lt], tcy = Tn[lt + ndm], tcz = twod ? 0. : Tn[lt + 2 * ndm];
   const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
   double qm[5], qp[5];
+  const double csc = c->slope == 6 ? wig[l + dir * nd + (c->kflu == 2 ? 3 * nd : 0)] : 1.;
   for (int e = 0; e < 5; e++) {
     const double *q = rop + e * nd;
-    SLOPE_STATES(c, q, rop[l + 4 * nd], l, nm, nm2, np, qm[e], qp[e]);
+    SLOPE_STATES(c, q, rop[l + 4 * nd], l, nm, nm2, np, qm[e], qp[e], csc);
   }
   double flu1, flu2, flu3, flu4, flu5, flu6 = 0., u_sa = 0., tdu_sa = 0.;
   if (c->kflu == 5) {
@@ -675,7 +813,7 @@ static void fluxctx_init(fluxctx *c, const i32 *p, const double *pr, const doubl
   c->minc[0] = p[NIJK_MTR]; c->minc[1] = p[NIJK_MTR + 1]; c->minc[2] = p[NIJK_MTR + 2];
   /* constants: Fast/FastS/FastS/Compute/template_FluxAndBalance.for:108-156 */
   c->kflu = p[KFLUDOM]; c->iflow = p[IFLOW];
-  c->slope = p[KFLUDOM] == 5 ? p[SLOPE] : 2;
+  c->slope = p[SLOPE] == 6 ? 6 : (p[KFLUDOM] == 5 ? p[SLOPE] : 2);
   c->tmin_1 = 100. / pr[TINF];
   c->tcx = ti[0]; c->tcy = tj[0]; c->tcz = p[ITYPZONE] == 3 ? 0. : tk[0];
   c->si = fabs(c->tcx); c->sj = fabs(c->tcy); c->sk = fabs(c->tcz);
@@ -1807,6 +1945,7 @@ void fo_subiter(const i32 *p, const double *pr, int nitcfg, const double *rop_in
   fo_init_rhs(p, nitcfg, sdm, drodm);
   if (p[IFLOW] == 3)   /* src_term.for:87-96: dist = second slot of the viscosity array */
     fo_spsource_SA(p, pr, nitcfg, sdm, rop_in, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
+  if (p[SLOPE] == 6) fo_sciacovelli(p, pr, sdm, rop_in, ti, tj, tk, vol, wig);   /* src_term.for:246-255: every sub-iteration */
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_in, wig);
   fo_flux(p, pr, sdm, rop_in, drodm, wig, xmut, ti, tj, tk, vol);
   fo_bfl3(p, pr, rop_in, drodm, wig, xmut, ti, tj, tk, vol);
@@ -1875,6 +2014,7 @@ void fo_subiter_mt(const i32 *p, const double *pr, int nitcfg, const double *rop
     fo_init_rhs(p, nitcfg, sdm, drodm);
 #pragma omp barrier
     if (p[IFLOW] == 3) fo_spsource_SA(p, pr, nitcfg, sdm, rop_in, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
+    if (p[SLOPE] == 6) fo_sciacovelli(p, pr, sdm, rop_in, ti, tj, tk, vol, wig);
     if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_in, wig);
 #pragma omp barrier
     flux_own(p, pr, sdm, rop_in, drodm, wig, xmut, ti, tj, tk, vol, klo, khi);
@@ -2733,6 +2873,7 @@ int fo_subiter_implicit_blocks(const i32 *p, const double *pr, int nitcfg, int f
     const i32 ssa[6] = {0, iv + 1, 0, jv + 1, 1 - gk, kv + gk};
     fo_spsource_SA(p, pr, nitcfg, ssa, rop_ss, coe, ti, tj, tk, vol, xmut + p[NDIMDX], drodm);
   }
+  if (p[SLOPE] == 6) fo_sciacovelli(p, pr, sdm, rop_ss, ti, tj, tk, vol, wig);
   if (p[KFLUDOM] == 2 && nitcfg == 1) fo_wiggle(p, sdm, rop_ss, wig);
   fo_flux(p, pr, sdm, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);
   fo_bfl3(p, pr, rop_ss, drodm, wig, xmut, ti, tj, tk, vol);

@@ -101,7 +101,9 @@ class OracleZone:
         self.first_it = 0          # FIRST_IT of the reference: 0 until one time step is done (BDF1)
         self.drodm = np.zeros(n); self.coe = np.zeros(self.ndimdx * max(1, int(p[NEQ_COE])))
         # viscosity; the SA model keeps the wall distance in a second slot (src_term.for:93-96)
-        self.xmut = np.zeros(2 * self.ndimdx); self.wig = np.zeros(3 * self.ndimdx)
+        self.xmut = np.zeros(2 * self.ndimdx)
+        # wiggle sensor (3 arrays), then with the o3sc slope the shock sensor (3 more when the scheme is senseur)
+        self.wig = np.zeros((6 if (int(p[64]) == 6 and int(p[33]) == 2) else 3) * self.ndimdx)
         if dist is not None:
             d = np.ascontiguousarray(np.asarray(dist).reshape(-1, order='F'), dtype=np.float64)
             self.xmut[self.ndimdx:self.ndimdx + d.size] = d
