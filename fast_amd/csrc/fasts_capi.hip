@@ -87,7 +87,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     for (int r = 0; r < 3; r++) if (zn.pinned[r]) { if (hipHostUnregister(zn.pinned[r]) != hipSuccess) (void)hipGetLastError(); }
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
-    (void)hipFree(zn.blk_res);
+    (void)hipFree(zn.blk_res); (void)hipFree(zn.wsc);
     for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); (void)hipFree(bb.lu_dev); }
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
@@ -418,9 +418,12 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (sa && (p[47] > 1 || p[SA_DIST] != 1))
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the Spalart-Allmaras model is implemented as plain SA (no DES variant), "
                 "with a TurbulentDistance field");
-  // slopes of the reference's flux tables: o3 for every scheme; o1 and minmod exist for roe alone (ROE/fluroe_select.for)
-  if (p[SLOPE] != 2 && !(p[KFLUDOM] == 5 && (p[SLOPE] == 1 || p[SLOPE] == 3)))
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: slope must be 'o3' (or, with roe, 'o1' / 'minmod')");
+  // slopes of the reference's flux tables: o3 and o3sc for every scheme; o1 and minmod exist for roe alone
+  // (ROE/fluroe_select.for); o3sc is implemented for 5 equations
+  if (p[SLOPE] != 2 && p[SLOPE] != 6 && !(p[KFLUDOM] == 5 && (p[SLOPE] == 1 || p[SLOPE] == 3)))
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: slope must be 'o3' or 'o3sc' (or, with roe, 'o1' / 'minmod')");
+  if (p[SLOPE] == 6 && sa)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the o3sc slope is implemented for Euler and NSLaminar");
   if (p[SFD] != 0 && p[SFD] != 1) return fail(ctx, FS_ERR_ARG, "fs_zone_add: SFD must be 0 or 1");
   if (p[SFD] == 1 && !implicit)
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: selective frequency damping is implemented with the implicit scheme");
@@ -620,6 +623,9 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
       zn.roe_walls.push_back(rw);
     }
   }
+  if (p[SLOPE] == 6 && !zn.roe_walls.empty())
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the o3sc slope with the roe scheme is implemented on zones without walls "
+                "(the wall-flux correction of the reference has o3sc variants of its own)");
   if (implicit) {
     // BCzone with lrhs = 1 (Fast/FastS/FastS/BC/BCzone.cpp:93-191,193-226,262-264): faces that carry a wall
     // BC (tags 3..7) get the ghost residual zeroed over the whole face (extrapolation with c1 = 0), then their BCs
@@ -772,10 +778,10 @@ extern "C" int fs_upload(fs_ctx *ctx)
   if (!ctx->uploaded && ctx->local_newton) {
     if (!ctx->implicit) return fail(ctx, FS_ERR_STATE, "fs_upload: local Newton sub-iterations need the implicit scheme");
     for (auto &zn : ctx->zones)
-      if (!zn.lu_blocks.empty() || zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0 || !zn.roe_walls.empty() ||
+      if (!zn.lu_blocks.empty() || zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0 || !zn.roe_walls.empty() || zn.z.slope == 6 ||
           zn.pint[SIZE_SSDOM] < 1 || zn.pint[SIZE_SSDOM + 1] < 1 || zn.pint[SIZE_SSDOM + 2] < 1)
         return fail(ctx, FS_ERR_UNSUPPORTED, "fs_upload: local Newton sub-iterations are implemented with one LU-SGS sweep "
-                    "per sub-zone (no thread blocks, nb_relax = 1, lu_match = 0, no roe scheme with walls)");
+                    "per sub-zone (no thread blocks, nb_relax = 1, lu_match = 0, no roe scheme with walls, no o3sc slope)");
   }
   for (auto &zn : ctx->zones) {
     const size_t nb = sizeof(double) * (size_t)zn.z.neq * (size_t)zn.z.nd;
@@ -785,6 +791,11 @@ extern "C" int fs_upload(fs_ctx *ctx)
       HIPCHK(ctx, hipMemsetAsync(zn.drodm, 0, nb, ctx->stream));
       HIPCHK(ctx, hipMalloc(&zn.xmut, sizeof(double) * (size_t)zn.z.nd));
       HIPCHK(ctx, hipMemsetAsync(zn.xmut, 0, sizeof(double) * (size_t)zn.z.nd, ctx->stream));
+      if (zn.z.slope == 6) {
+        const size_t nw = sizeof(double) * 3 * (size_t)zn.z.nd;
+        HIPCHK(ctx, hipMalloc(&zn.wsc, nw));
+        HIPCHK(ctx, hipMemsetAsync(zn.wsc, 0, nw, ctx->stream));
+      }
       if (zn.z.kflu == 2) {
         // face sensors: 0/1 values, one byte per cell and direction (curvilinear and SA kernels) or one byte per
         // cell holding the three of them (Cartesian kernel)
@@ -935,7 +946,7 @@ static int build_shell_lists(fs_ctx *ctx)
     for (auto &j : ctx->joins) if (j.donor_zone < 0 && j.rcv_zone == (int)nz) zn.has_recvs = true;
     // implicit zones, roe + walls and the local time step run their stage in one piece (later kernels of the stage read
     // the whole balance); so do Spalart-Allmaras zones on Cartesian meshes (their stage kernel takes no tile list)
-    if (ctx->implicit || (z.iflow == 3 && z.ityp != 0) || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1) continue;
+    if (ctx->implicit || (z.iflow == 3 && z.ityp != 0) || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1 || z.slope == 6) continue;
     zn.z.split = zn.has_sends ? 1 : 0;
     // tiles of the Cartesian stage kernel, patches (owned cells) of the curvilinear one
     const FsTiling t = z.ityp == 0 ? fsk_stage_full_tiling(zn.z) : fsk_stage_dma_tiling(zn.z);
@@ -1226,7 +1237,14 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
                              !zn.box_bcs[(size_t)nstep - 1].tile_cnt.empty();
     const int *box_tiles = partial_box ? zn.box_bcs[(size_t)nstep - 1].tiles_dev + zn.box_bcs[(size_t)nstep - 1].tile_off[(size_t)b] : nullptr;
     const int box_ntiles = partial_box ? zn.box_bcs[(size_t)nstep - 1].tile_cnt[(size_t)b] : 0;
-    if (z.iflow == 3 && z.ityp != 0)
+    if (z.slope == 6) {
+      // o3sc: the shock sensor of the state this sub-iteration starts from (src_term.for:246-255), then kernels of its own
+      fsk_sciacovelli(z, zn.dev[in], zn.wsc, ctx->stream);
+      krc = z.ityp == 0 ? fsk_stage_o3sc_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
+                                              (unsigned char *)zn.wig, zn.wsc, kbdf, keep, ctx->stream)
+                        : fsk_stage_o3sc_cart(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
+                                              (unsigned char *)zn.wig, zn.wsc, kbdf, keep, ctx->stream);
+    } else if (z.iflow == 3 && z.ityp != 0)
       krc = fsk_stage_sa(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut, zn.dist,
                          (unsigned char *)zn.wig, kbdf, keep, ctx->stream);
     else if (z.ityp == 0) {

@@ -31,7 +31,7 @@ struct FsZone {
   // fluid / scheme constants
   double gam, rgp, gam1, gam3, c1, c2, c3, opt0, c4, c5, c6, cvisq, psiroe;
   double tmin_1;      // 100 / Tinf (minmod limiter)
-  int slope;          // 1 o1, 2 o3, 3 minmod (1 and 3: roe only)
+  int slope;          // 1 o1, 2 o3, 3 minmod (1 and 3: roe only), 6 o3sc (kernels of their own, fasts_stage_o3sc.hip)
   double tcx, tcy, tcz, si, sj, sk, volinv;
   double coe;              // dt/vol (constant on a Cartesian zone with a global time step)
   double vol0;             // cell volume of a Cartesian zone
@@ -89,10 +89,22 @@ FS_DEV double fs_avmin(double c, double r)
 // Right (qm) and left (qp) states on the face between the cells of qm1_ and q0.  o3: Slope/o3_slope_var.for:2-3.
 // roe alone also has first-order states (slope 1, Slope/o1_slope_var.for) and the minmod limiter (slope 3,
 // Slope/minmod_slope_var.for: no slope where the temperature of the right cell is below 0.01 Tinf).
+// csc >= 0 (slope 6, o3sc: Slope/o3sc_slope_var.for): the o3 states weighted by the shock sensor csc of the face, the rest
+// of the weight going to the cell values.
 template <int KFLU>
 FS_DEV void fs_states(const FsZone &z, const double *qm2, const double *qm1_, const double *q0, const double *qp1_,
-                      double *qm, double *qp)
+                      double *qm, double *qp, double csc = -1.)
 {
+  if (csc >= 0.) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+      qm[e] = z.c4 * q0[e] + z.c5 * qm1_[e] + z.c6 * qp1_[e];
+      qp[e] = z.c4 * qm1_[e] + z.c6 * qm2[e] + z.c5 * q0[e];
+      qm[e] = q0[e] * (1. - csc) + qm[e] * csc;
+      qp[e] = qm1_[e] * (1. - csc) + qp[e] * csc;
+    }
+    return;
+  }
   if (KFLU == 5 && z.slope != 2) {
     if (z.slope == 1) {
 #pragma unroll
@@ -122,12 +134,12 @@ FS_DEV void fs_states(const FsZone &z, const double *qm2, const double *qm1_, co
 // (AUSM/fluFaceSA.for); ausmpred and senseur only.
 template <int KFLU, int DIR>
 FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *qm1_, const double *q0,
-                             const double *qp1_, double wg, double *flu, double *sa = nullptr)
+                             const double *qp1_, double wg, double *flu, double *sa = nullptr, double csc = -1.)
 {
   const double tc = DIR == 0 ? z.tcx : (DIR == 1 ? z.tcy : z.tcz);
   const double s = DIR == 0 ? z.si : (DIR == 1 ? z.sj : z.sk);
   double qm[5], qp[5];
-  fs_states<KFLU>(z, qm2, qm1_, q0, qp1_, qm, qp);
+  fs_states<KFLU>(z, qm2, qm1_, q0, qp1_, qm, qp, csc);
   constexpr int vn = 1 + DIR;
   double flu1, flu2, flu3, flu4, flu5;
   if (KFLU == 5) {
@@ -233,11 +245,11 @@ FS_DEV void fs_flux_inviscid(const FsZone &z, const double *qm2, const double *q
 template <int KFLU>
 FS_DEV void fs_flux_inviscid_full(const FsZone &z, double tcx, double tcy, double tcz, const double *qm2,
                                   const double *qm1_, const double *q0, const double *qp1_, double wg, double *flu,
-                                  bool f3_first = false, double *sa = nullptr)
+                                  bool f3_first = false, double *sa = nullptr, double csc = -1.)
 {
   const double s = sqrt(tcx * tcx + tcy * tcy + tcz * tcz);
   double qm[5], qp[5];
-  fs_states<KFLU>(z, qm2, qm1_, q0, qp1_, qm, qp);
+  fs_states<KFLU>(z, qm2, qm1_, q0, qp1_, qm, qp, csc);
   double flu1, flu2, flu3, flu4, flu5;
   if (KFLU == 5) {
     const double gam = z.gam, rgp = z.rgp, gam1 = z.gam1, psiroe = z.psiroe;

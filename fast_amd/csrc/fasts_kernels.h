@@ -62,6 +62,15 @@ int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const d
                  int keep_balance, hipStream_t s);
 // coe(:,6), diagonal of the nu_tilde equation, interior + one ghost layer; needs coe(:,1) and coe(:,5)
 void fsk_sa_coe6(const FsZone &z, const double *rop, const double *dist, double *coe, hipStream_t s);
+// o3sc slope (SLOPE 6; 5 equations): the shock sensor of every face (3 doubles per cell), evaluated before every
+// sub-iteration, and stage kernels of their own that read it (one thread per cell; the tiled kernels are not involved)
+void fsk_sciacovelli(const FsZone &z, const double *rop, double *wsc, hipStream_t s);
+int fsk_stage_o3sc_cart(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, const FsBdf *bdf,
+                        int keep_balance, hipStream_t s);
+int fsk_stage_o3sc_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, const FsBdf *bdf,
+                        int keep_balance, hipStream_t s);
 struct FsBox { int b[6]; };   // i1, i2, j1, j2, k1, k2
 // Sub-zones: the flux loops of the reference add the flux of a face to the cell on its upper side and take it from the
 // cell on its lower side, the cells just outside the range included (Compute/template_FluxAndBalance.for:192-271,

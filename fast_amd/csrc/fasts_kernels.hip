@@ -487,6 +487,103 @@ __global__ void __launch_bounds__(256) k_bc_edges(FsZone z, FsBox box, double *_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Directional shock sensor of the o3sc slope (SENSOR/sciacovelli.for, shock_sensor.for; velocity divergence and squared
+// vorticity as SA/div_rot_{3dcart,3dfull,3dhomo,2d}.for, face sizes as SA/metric_*.for): wsc(l, dir) = weight of the o3
+// states on the face between l - inc(dir) and l.  Interior cells: the three directions; the plane of ghost cells past
+// each max side: the direction of that side, with the metrics of the LAST interior cell (the reference's plane loops
+// set the cell index only, sciacovelli.for:96-127).  MODE 0 Cartesian, 1 curvilinear, 2 two-dimensional, 3 k-homogeneous.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) k_sciacovelli(FsZone z, const double *__restrict__ rop, double *__restrict__ wsc)
+{
+  constexpr bool TWOD = MODE == 2, HOMO = MODE == 3;
+  const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y, k = 1 + blockIdx.z;
+  if (i > z.iv + 1) return;
+  const bool pi = i == z.iv + 1, pj = j == z.jv + 1, pk = !TWOD && k == z.kv + 1;
+  if ((int)pi + (int)pj + (int)pk > 1) return;
+  const int dirs = pi ? 1 : (pj ? 2 : (pk ? 4 : (TWOD ? 3 : 7)));
+  const long long nd = z.nd;
+  const long long inc[3] = {1, z.incj, TWOD ? 0 : z.inck};
+  const long long l = fs_inddm(z, i, j, k);
+  const long long l1 = l + 1, l2 = l - 1, l3 = l + inc[1], l4 = l - inc[1], l5 = l + inc[2], l6 = l - inc[2];
+  const double *__restrict__ U = rop + nd, *__restrict__ V = rop + 2 * nd, *__restrict__ W = rop + 3 * nd;
+  double div, rot, tc[3];
+  if (MODE == 0) {
+    const double tix = z.tcx, tjy = z.tcy, tkz = z.tcz;
+    tc[0] = fabs(tix); tc[1] = fabs(tjy); tc[2] = fabs(tkz);
+    const double xvol = 0.5 / z.vol0;
+    double u1, u2, u3, u4, u5, u6, dudx, rotx, roty, rotz;
+    u1 = U[l] + U[l2]; u2 = U[l] + U[l3]; u3 = U[l] + U[l1]; u4 = U[l] + U[l4]; u5 = U[l] + U[l5]; u6 = U[l] + U[l6];
+    dudx = (u3 - u1) * tix; rotz = -(u2 - u4) * tjy; roty = (u5 - u6) * tkz; div = dudx * xvol;
+    u1 = V[l] + V[l2]; u2 = V[l] + V[l3]; u3 = V[l] + V[l1]; u4 = V[l] + V[l4]; u5 = V[l] + V[l5]; u6 = V[l] + V[l6];
+    dudx = (u3 - u1) * tix; rotz = (rotz + dudx) * xvol;
+    dudx = (u2 - u4) * tjy; div = div + dudx * xvol;
+    dudx = (u5 - u6) * tkz; rotx = -dudx;
+    u1 = W[l] + W[l2]; u2 = W[l] + W[l3]; u3 = W[l] + W[l1]; u4 = W[l] + W[l4]; u5 = W[l] + W[l5]; u6 = W[l] + W[l6];
+    dudx = (u3 - u1) * tix; roty = (roty - dudx) * xvol;
+    dudx = (u2 - u4) * tjy; rotx = (rotx + dudx) * xvol;
+    dudx = (u5 - u6) * tkz; div = div + dudx * xvol;
+    rot = rotx * rotx + roty * roty + rotz * rotz;
+  } else {
+    const bool plane = pi || pj || pk;
+    const int mi = plane ? z.iv : i, mj = plane ? z.jv : j, mk = plane ? z.kv : k;
+    const long long ndm = z.ndm;
+    const long long lt = (long long)(mi + z.ific - 1) + (long long)(mj + z.ific - 1) * z.mincj + (long long)(mk + z.ifick - 1) * z.minck;
+    const double *__restrict__ ti = z.mt[0], *__restrict__ tj = z.mt[1], *__restrict__ tk = z.mt[2];
+    const double tix = ti[lt], tiy = ti[lt + ndm], tiz = ti[lt + 2 * ndm];
+    const double tix1 = ti[lt + 1], tiy1 = ti[lt + 1 + ndm], tiz1 = ti[lt + 1 + 2 * ndm];
+    const double tjx = tj[lt], tjy = tj[lt + ndm], tjz = tj[lt + 2 * ndm];
+    const double tjx1 = tj[lt + z.mincj], tjy1 = tj[lt + z.mincj + ndm], tjz1 = tj[lt + z.mincj + 2 * ndm];
+    const double tkx = tk[lt], tky = tk[lt + ndm], tkz = tk[lt + 2 * ndm];
+    const double tkx1 = tk[lt + z.minck], tky1 = tk[lt + z.minck + ndm], tkz1 = tk[lt + z.minck + 2 * ndm];
+    double t;
+    t = sqrt(tix * tix + tiy * tiy + tiz * tiz); t = t + sqrt(tix1 * tix1 + tiy1 * tiy1 + tiz1 * tiz1); tc[0] = fs_max(.5 * t, 1.e-27);
+    t = sqrt(tjx * tjx + tjy * tjy + tjz * tjz); t = t + sqrt(tjx1 * tjx1 + tjy1 * tjy1 + tjz1 * tjz1); tc[1] = fs_max(.5 * t, 1.e-27);
+    if (HOMO) tc[2] = fs_max(fabs(tkz), 1.e-27);
+    else {
+      t = sqrt(tkx * tkx + tky * tky + tkz * tkz); t = t + sqrt(tkx1 * tkx1 + tky1 * tky1 + tkz1 * tkz1); tc[2] = fs_max(.5 * t, 1.e-27);
+    }
+    const double xvol = 0.5 / z.vol[lt];
+    double u1, u2, u3, u4, u5 = 0., u6 = 0., dudx, rotx = 0., roty = 0., rotz;
+    // the sums of the two-dimensional and k-homogeneous fragments are the general ones without the terms a zero
+    // metric multiplies (the same bits), except along z on a k-homogeneous zone, where the difference is taken first
+    auto gx = [&]() { return (TWOD || HOMO) ? (u3 * tix1 - u1 * tix + u2 * tjx1 - u4 * tjx) : (u3 * tix1 - u1 * tix + u2 * tjx1 - u4 * tjx + u5 * tkx1 - u6 * tkx); };
+    auto gy = [&]() { return (TWOD || HOMO) ? (u3 * tiy1 - u1 * tiy + u2 * tjy1 - u4 * tjy) : (u3 * tiy1 - u1 * tiy + u2 * tjy1 - u4 * tjy + u5 * tky1 - u6 * tky); };
+    auto gz = [&]() { return HOMO ? (u5 - u6) * tkz : (u3 * tiz1 - u1 * tiz + u2 * tjz1 - u4 * tjz + u5 * tkz1 - u6 * tkz); };
+    u1 = U[l] + U[l2]; u2 = U[l] + U[l3]; u3 = U[l] + U[l1]; u4 = U[l] + U[l4];
+    if (!TWOD) { u5 = U[l] + U[l5]; u6 = U[l] + U[l6]; }
+    dudx = gx(); div = dudx * xvol;
+    rotz = -gy();
+    if (!TWOD) roty = gz();
+    u1 = V[l] + V[l2]; u2 = V[l] + V[l3]; u3 = V[l] + V[l1]; u4 = V[l] + V[l4];
+    if (!TWOD) { u5 = V[l] + V[l5]; u6 = V[l] + V[l6]; }
+    dudx = gx(); rotz = (rotz + dudx) * xvol;
+    dudx = gy(); div = div + dudx * xvol;
+    if (!TWOD) {
+      dudx = gz(); rotx = -dudx;
+      u1 = W[l] + W[l2]; u2 = W[l] + W[l3]; u3 = W[l] + W[l1]; u4 = W[l] + W[l4]; u5 = W[l] + W[l5]; u6 = W[l] + W[l6];
+      dudx = gx(); roty = (roty - dudx) * xvol;
+      dudx = gy(); rotx = (rotx + dudx) * xvol;
+      dudx = gz(); div = div + dudx * xvol;
+      rot = rotx * rotx + roty * roty + rotz * rotz;
+    } else
+      rot = rotz * rotz;
+  }
+  for (int d = 0; d < 3; d++) {
+    if (!(dirs & (1 << d))) continue;
+    double mach = sqrt(z.gam * z.rgp * rop[l + 4 * nd]);
+    mach = 10.0 * (1.0 / tc[d]) * (1.0 / mach) * div;
+    mach = 0.5 * (1.0 - tanh(2.5 + mach));
+    const double p2 = rop[l - inc[d]] * rop[l - inc[d] + 4 * nd], p0 = rop[l] * rop[l + 4 * nd];
+    const double p1 = rop[l + inc[d]] * rop[l + inc[d] + 4 * nd];
+    double w = fabs(p2 - 2. * p0 + p1) / fabs(p2 + 2. * p0 + p1);
+    w = fs_min(2.0 * div * div / (div * div + rot + 1e-15) * w * mach, 1.0);
+    wsc[l + d * nd] = 1.0 - w;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // joins: ghost[rcv] = donor[dnr] for every variable (type-0 'direct' transfer,
 // setInterpTransfersFast.cpp:440-935), pack / unpack for joins that cross contexts
@@ -870,6 +967,15 @@ void fsk_residual(const FsZone &z, int use_coe, const double *drodm, double *par
 {
   hipLaunchKernelGGL(k_residual_partial, dim3(z.jv, z.kv), dim3(256), 0, s, z, use_coe, drodm, part, coe1);
   hipLaunchKernelGGL(k_residual_final, dim3(1), dim3(256), 0, s, (long long)z.jv * z.kv, part, out);
+}
+
+void fsk_sciacovelli(const FsZone &z, const double *rop, double *wsc, hipStream_t s)
+{
+  dim3 g((unsigned)((z.iv + 1 + 255) / 256), (unsigned)(z.jv + 1), (unsigned)(z.twod ? 1 : z.kv + 1));
+  if (z.ityp != 0) hipLaunchKernelGGL(k_sciacovelli<0>, g, dim3(256), 0, s, z, rop, wsc);
+  else if (z.twod) hipLaunchKernelGGL(k_sciacovelli<2>, g, dim3(256), 0, s, z, rop, wsc);
+  else if (z.homo) hipLaunchKernelGGL(k_sciacovelli<3>, g, dim3(256), 0, s, z, rop, wsc);
+  else hipLaunchKernelGGL(k_sciacovelli<1>, g, dim3(256), 0, s, z, rop, wsc);
 }
 
 void fsk_residual_blocks(const FsZone &z, const int nblk[3], const int size[3], const double *drodm, double *out,

@@ -20,6 +20,8 @@
 #include "fasts_kernels.h"
 #include "fasts_flux.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TI = 32, TJ = 8, OI = TI - 1, OJ = TJ - 1;
@@ -52,7 +54,7 @@ struct RdLds {
 template <int KFLU, int IFLOW, int DIR, bool FIRST, bool TWOD, bool HOMO = false, class RD>
 FS_DEV void face_full(const FsZone &z, const RD &rd, const double *__restrict__ xmut,
                       unsigned char *__restrict__ wig, long long l, long long lt, const double *qm2,
-                      const double *qm1, const double *q0, const double *qp1, double *flu)
+                      const double *qm1, const double *q0, const double *qp1, double *flu, double csc = -1.)
 {
   const long long nd = z.nd, ndm = z.ndm;
   const double *__restrict__ Tn = z.mt[DIR];
@@ -69,7 +71,7 @@ FS_DEV void face_full(const FsZone &z, const RD &rd, const double *__restrict__ 
   }
   double sa[4];
   fs_flux_inviscid_full<KFLU>(z, tcx, tcy, tcz, qm2, qm1, q0, qp1, wg, flu, TWOD && DIR == 1,
-                              (IFLOW == 3 && KFLU != 5) ? sa : nullptr);
+                              (IFLOW == 3 && KFLU != 5) ? sa : nullptr, csc);
   if (IFLOW == 3 && KFLU == 5) {
     // roe: first-order upwinding with the Roe-averaged normal velocity (ROE/fluFaceSA.for, Vit_ent/qn_3dfull_i.for)
     double qp1r = qm1[0], qm1r = q0[0];
@@ -414,6 +416,74 @@ __global__ void __launch_bounds__(256) k_sa_coe6_full(FsZone z, const double *__
   coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
 }
 
+// o3sc slope on curvilinear / two-dimensional / k-homogeneous zones: one thread per cell, its six (four) face fluxes from
+// memory (every face is evaluated by the two cells it separates, with the same operands), balance and end of the stage
+// as k_stage_full has them.  5 equations.
+template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO>
+__global__ void __launch_bounds__(256) k_stage_o3sc_full(FsZone z, double coefH, double coefW, int keep,
+                                                         const double *__restrict__ rop, double *__restrict__ rop_out,
+                                                         double *__restrict__ drodm, const double *__restrict__ xmut,
+                                                         unsigned char *__restrict__ wig, const double *__restrict__ wsc,
+                                                         FsBdf bdf)
+{
+  const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y, k = 1 + blockIdx.z;
+  if (i > z.iv) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  const long long lt = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck;
+  auto face = [&](auto dirc, long long lf, long long ltf, double *f) {
+    constexpr int DIR = decltype(dirc)::value;
+    const long long st = DIR == 0 ? 1 : (DIR == 1 ? z.incj : z.inck);
+    double qm2[5], qm1[5], q0[5], qp1[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+      qm2[e] = rop[e * nd + lf - 2 * st]; qm1[e] = rop[e * nd + lf - st]; q0[e] = rop[e * nd + lf]; qp1[e] = rop[e * nd + lf + st];
+    }
+    const RdGlobal rdg = {rop, nd, lf, z.incj, TWOD ? 0 : z.inck};
+    face_full<KFLU, IFLOW, DIR, FIRST, TWOD, HOMO>(z, rdg, xmut, wig, lf, ltf, qm2, qm1, q0, qp1, f, wsc[lf + DIR * nd]);
+  };
+  double fkm[5] = {0., 0., 0., 0., 0.}, fjm[5], fim[5], fip[5], fjp[5], fkp[5] = {0., 0., 0., 0., 0.};
+  if (!TWOD) face(std::integral_constant<int, 2>(), l, lt, fkm);
+  face(std::integral_constant<int, 1>(), l, lt, fjm);
+  face(std::integral_constant<int, 0>(), l, lt, fim);
+  face(std::integral_constant<int, 0>(), l + 1, lt + 1, fip);
+  face(std::integral_constant<int, 1>(), l + z.incj, lt + z.mincj, fjp);
+  if (!TWOD) face(std::integral_constant<int, 2>(), l + z.inck, lt + z.minck, fkp);
+  double q[5], d[5], o[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    q[e] = rop[e * nd + l];
+    const double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
+    double a = dr + fkm[e];
+    a = a + fjm[e]; a = a + fim[e];
+    a = a - fip[e]; a = a - fjp[e];
+    d[e] = TWOD ? a : a - fkp[e];
+  }
+  const double coe = z.dt / z.vol[lt];
+  if (BDF) {
+    double qn[5] = {0., 0., 0., 0., 0.}, qn1[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) qn1[e] = bdf.ro_n1[e * nd + l];
+    if (!bdf.nit1) {
+#pragma unroll
+      for (int e = 0; e < 5; e++) qn[e] = bdf.ro_n[e * nd + l];
+    }
+    const double coeb = bdf.coe1 ? bdf.coe1[l] : coe;
+    fs_bdf_residual(z, bdf, coeb, q, qn, qn1, d, o);
+#pragma unroll
+    for (int e = 0; e < 5; e++) drodm[e * nd + l] = o[e];
+  } else {
+    if (keep) {
+#pragma unroll
+      for (int e = 0; e < 5; e++) drodm[e * nd + l] = d[e];
+    }
+    fs_rk_update_c(z, coefW, coe, q, d, o);
+    if (TWOD) o[3] = 0.;   // core3ark3.for:156-183
+#pragma unroll
+    for (int e = 0; e < 5; e++) rop_out[e * nd + l] = o[e];
+  }
+}
+
 template <int KFLU, int IFLOW, bool TWOD, bool HOMO>
 __global__ void __launch_bounds__(128) k_box_faces_full(FsZone z, FsBox box, const double *__restrict__ rop,
                                                         const double *__restrict__ xmut, unsigned char *__restrict__ wig,
@@ -470,6 +540,35 @@ __global__ void __launch_bounds__(256) k_sa_ring_full(FsZone z, FsBox box, const
 }
 
 }  // namespace
+
+int fsk_stage_o3sc_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, const FsBdf *bdf,
+                        int keep_balance, hipStream_t s)
+{
+  if (z.ityp != 0 || z.neq != 5 || !wsc || !z.vol || (z.kflu == 2 && !wig)) return -1;
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
+  if (bdf) b = *bdf;
+  dim3 g((unsigned)((z.iv + 255) / 256), (unsigned)z.jv, (unsigned)z.kv);
+#define FS_L(...) hipLaunchKernelGGL((k_stage_o3sc_full<__VA_ARGS__>), g, dim3(256), 0, s, z, coefH, coefW, keep_balance, rop, \
+                                     rop_out, drodm, xmut, wig, wsc, b)
+#define FS_GO(K, F, FIRST_, BDF_)                                                                   \
+  do {                                                                                              \
+    if (z.twod) FS_L(K, F, FIRST_, BDF_, true, false);                                              \
+    else if (z.homo) FS_L(K, F, FIRST_, BDF_, false, true);                                         \
+    else FS_L(K, F, FIRST_, BDF_, false, false);                                                    \
+  } while (0)
+#define FS_CASE(K, F)                                                                                         \
+  if (z.kflu == K && z.iflow == F) {                                                                          \
+    if (bdf) { if (first) FS_GO(K, F, true, true); else FS_GO(K, F, false, true); }                           \
+    else { if (first) FS_GO(K, F, true, false); else FS_GO(K, F, false, false); }                             \
+    return 0;                                                                                                 \
+  }
+  FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)
+#undef FS_CASE
+#undef FS_GO
+#undef FS_L
+  return -1;
+}
 
 void fsk_box_faces_full(const FsZone &z, const int *box, const double *rop, const double *xmut, unsigned char *wig,
                         double *drodm, hipStream_t s)

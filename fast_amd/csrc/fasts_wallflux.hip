@@ -167,9 +167,12 @@ long long row_cells(const FsWallRow &w)
 // from memory (the stage kernel takes them from its tile) ------------------------------------------------------------
 namespace {
 
+// csc >= 0: weight of the o3 states (o3sc slope).  wg_first != NULL: first sub-iteration of the senseur scheme, the
+// sensor of the face is evaluated here and returned instead of read.
 template <int KFLU, int IFLOW, int DIR>
 FS_DEV void face_cart(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
-                      const unsigned char *__restrict__ wig, long long l, double *flu)
+                      const unsigned char *__restrict__ wig, long long l, double *flu, double csc = -1.,
+                      double *wg_first = nullptr)
 {
   const long long nd = z.nd;
   const long long inc[3] = {1, z.incj, z.inck};
@@ -180,8 +183,16 @@ FS_DEV void face_cart(const FsZone &z, const double *__restrict__ rop, const dou
     qm2[e] = rop[e * nd + l - 2 * st]; qm1[e] = rop[e * nd + l - st]; q0[e] = rop[e * nd + l]; qp1[e] = rop[e * nd + l + st];
   }
   // sensor of the face: bit DIR of the byte of cell l (written at the first sub-iteration, which covers the zone)
-  const double wg = KFLU == 2 ? (double)((wig[l] >> DIR) & 1u) : 0.;
-  fs_flux_inviscid<KFLU, DIR>(z, qm2, qm1, q0, qp1, wg, flu);
+  double wg = 0.;
+  if (KFLU == 2) {
+    if (wg_first) {
+      auto qs = [&](int e, int o) -> double { return o == -2 ? qm2[e] : (o == -1 ? qm1[e] : (o == 0 ? q0[e] : qp1[e])); };
+      wg = fs_wiggle(qs);
+      *wg_first = wg;
+    } else
+      wg = (double)((wig[l] >> DIR) & 1u);
+  }
+  fs_flux_inviscid<KFLU, DIR>(z, qm2, qm1, q0, qp1, wg, flu, nullptr, csc);
   if (IFLOW == 2) {
     constexpr int A = DIR == 0 ? 1 : 0, B = DIR == 2 ? 1 : 2;   // the transverse directions, in the order (i, j, k)
     auto q = [&](int e, int da, int db, int dn) -> double { return rop[e * nd + l + dn * st + da * inc[A] + db * inc[B]]; };
@@ -214,6 +225,95 @@ __global__ void __launch_bounds__(128) k_box_faces_cart(FsZone z, FsBox box, con
 }
 
 }  // namespace
+
+// ---- o3sc slope on Cartesian zones: one thread per cell, its six face fluxes from memory (every face is evaluated by
+// the two cells it separates, with the same operands), balance and end of the stage as the tiled kernel has them -----------
+namespace {
+
+template <int KFLU, int IFLOW, bool FIRST, bool BDF>
+__global__ void __launch_bounds__(256) k_stage_o3sc_cart(FsZone z, double coefH, double coefW, int keep,
+                                                         const double *__restrict__ rop, double *__restrict__ rop_out,
+                                                         double *__restrict__ drodm, const double *__restrict__ xmut,
+                                                         unsigned char *__restrict__ wig, const double *__restrict__ wsc,
+                                                         FsBdf bdf)
+{
+  const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y, k = 1 + blockIdx.z;
+  if (i > z.iv) return;
+  const long long nd = z.nd, l = wcell(z, i, j, k);
+  const long long li = l + 1, lj = l + z.incj, lk = l + z.inck;
+  double fkm[5], fjm[5], fim[5], fip[5], fjp[5], fkp[5];
+  double w[6] = {0., 0., 0., 0., 0., 0.};
+  constexpr bool SEN = KFLU == 2 && FIRST;
+  face_cart<KFLU, IFLOW, 2>(z, rop, xmut, wig, l, fkm, wsc[l + 2 * nd], SEN ? &w[2] : nullptr);
+  face_cart<KFLU, IFLOW, 1>(z, rop, xmut, wig, l, fjm, wsc[l + nd], SEN ? &w[1] : nullptr);
+  face_cart<KFLU, IFLOW, 0>(z, rop, xmut, wig, l, fim, wsc[l], SEN ? &w[0] : nullptr);
+  face_cart<KFLU, IFLOW, 0>(z, rop, xmut, wig, li, fip, wsc[li], SEN ? &w[3] : nullptr);
+  face_cart<KFLU, IFLOW, 1>(z, rop, xmut, wig, lj, fjp, wsc[lj + nd], SEN ? &w[4] : nullptr);
+  face_cart<KFLU, IFLOW, 2>(z, rop, xmut, wig, lk, fkp, wsc[lk + 2 * nd], SEN ? &w[5] : nullptr);
+  if (SEN) {
+    // the byte of a cell holds the sensors of its three lower faces; the ghost cells past a max side have no thread:
+    // their byte (the sensor of the boundary face alone) is written by the cell before them
+    wig[l] = (unsigned char)((w[0] != 0. ? 1u : 0u) | (w[1] != 0. ? 2u : 0u) | (w[2] != 0. ? 4u : 0u));
+    if (i == z.iv) wig[li] = w[3] != 0. ? 1 : 0;
+    if (j == z.jv) wig[lj] = w[4] != 0. ? 2 : 0;
+    if (k == z.kv) wig[lk] = w[5] != 0. ? 4 : 0;
+  }
+  double q[5], d[5], o[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    q[e] = rop[e * nd + l];
+    const double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
+    double a = dr + fkm[e];
+    a = a + fjm[e]; a = a + fim[e];
+    a = a - fip[e]; a = a - fjp[e];
+    d[e] = a - fkp[e];
+  }
+  if (BDF) {
+    double qn[5] = {0., 0., 0., 0., 0.}, qn1[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) qn1[e] = bdf.ro_n1[e * nd + l];
+    if (!bdf.nit1) {
+#pragma unroll
+      for (int e = 0; e < 5; e++) qn[e] = bdf.ro_n[e * nd + l];
+    }
+    const double coe1 = bdf.coe1 ? bdf.coe1[l] : z.coe;
+    fs_bdf_residual(z, bdf, coe1, q, qn, qn1, d, o);
+#pragma unroll
+    for (int e = 0; e < 5; e++) drodm[e * nd + l] = o[e];
+  } else {
+    if (keep) {
+#pragma unroll
+      for (int e = 0; e < 5; e++) drodm[e * nd + l] = d[e];
+    }
+    fs_rk_update(z, coefW, q, d, o);
+#pragma unroll
+    for (int e = 0; e < 5; e++) rop_out[e * nd + l] = o[e];
+  }
+}
+
+}  // namespace
+
+int fsk_stage_o3sc_cart(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
+                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, const FsBdf *bdf,
+                        int keep_balance, hipStream_t s)
+{
+  if (z.ityp == 0 || z.neq != 5 || !wsc || (z.kflu == 2 && !wig)) return -1;
+  FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
+  if (bdf) b = *bdf;
+  dim3 g((unsigned)((z.iv + 255) / 256), (unsigned)z.jv, (unsigned)z.kv);
+#define FS_GO(K, F, FIRST_, BDF_) hipLaunchKernelGGL((k_stage_o3sc_cart<K, F, FIRST_, BDF_>), g, dim3(256), 0, s, z, coefH, coefW, \
+                                                     keep_balance, rop, rop_out, drodm, xmut, wig, wsc, b)
+#define FS_CASE(K, F)                                                                                         \
+  if (z.kflu == K && z.iflow == F) {                                                                          \
+    if (bdf) { if (first) FS_GO(K, F, true, true); else FS_GO(K, F, false, true); }                           \
+    else { if (first) FS_GO(K, F, true, false); else FS_GO(K, F, false, false); }                             \
+    return 0;                                                                                                 \
+  }
+  FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)
+#undef FS_CASE
+#undef FS_GO
+  return -1;
+}
 
 void fsk_box_faces_cart(const FsZone &z, const int *box, const double *rop, const double *xmut, const unsigned char *wig,
                         double *drodm, hipStream_t s)

@@ -81,6 +81,14 @@ CASES = {
     'collapsed_walls_sa_impl':  ('tgv', (10, 9, 8), 'ausmpred', 'NSTurbulent', (1, 1, 1), 'single', 6,
                                  {'jmin': 'BCWall', 'kmax': 'BCWall', 'imin': 'BCExtrapolateRANS'},
                                  {'perturb': 0.15, 'collapse': ('jmin', 'kmax'), 'ss_iteration': 3, 'time_step': 0.02}),
+    # slope 'o3sc': the o3 states weighted by the shock sensor of SENSOR/sciacovelli.for; 'front' puts a compression
+    # front across the zone so that the sensor departs from 1
+    'o3sc_senseur_walls':       ('tgv', (14, 10, 9), 'senseur', 'NSLaminar', (1, 1, 1), 'single', 10,
+                                 {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {'slope': 'o3sc', 'front': 1}),
+    'o3sc_ausmpred_curv':       ('tgv', (12, 10, 9), 'ausmpred', 'NSLaminar', (1, 1, 1), 'single', 10,
+                                 {'kmin': 'BCWall'}, {'slope': 'o3sc', 'front': 1, 'perturb': 0.15}),
+    'o3sc_roe_implicit_curv':   ('tgv', (12, 10, 9), 'roe', 'Euler', (1, 1, 1), 'single', 6, None,
+                                 {'slope': 'o3sc', 'front': 1, 'perturb': 0.15, 'ss_iteration': 3, 'time_step': 0.02}),
     'tgv12_ausmpred_default':   ('tgv', 12, 'ausmpred', 'NSLaminar', (1, 1, 1), 'default', 100),
     'tgv12_senseur_default':    ('tgv', 12, 'senseur', 'NSLaminar', (1, 1, 1), 'default', 100),
 }
@@ -92,14 +100,21 @@ def build(kind, n, scheme, model, blocks, cache, bcs=None, opts=None, modulo_ver
     opts = opts or {}
     if opts.get('local'):      # time_step_nature='local' at the given CFL number
         extra = dict(extra or {}, time_step_nature='local', cfl=opts['local'])
+    if opts.get('slope'):
+        extra = dict(extra or {}, slope=opts['slope'])
     if kind == 'tgv':
         kw = {}
         if 'collapse' in opts:
             kw['collapse'] = opts['collapse']
         if 'ss_iteration' in opts:
             kw.update({'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': opts['ss_iteration']}})
-        return cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra, bcs=bcs, modulo_verif=modulo_verif,
-                         perturb=opts.get('perturb', 0.), time_step=opts.get('time_step'), **kw)
+        t = cases.tgv(n, scheme, model=model, blocks=blocks, extra_numz=extra, bcs=bcs, modulo_verif=modulo_verif,
+                      perturb=opts.get('perturb', 0.), time_step=opts.get('time_step'), **kw)
+        if opts.get('front'):      # u falls by 4 over a few cells along i
+            for z in Internal.getZones(t):
+                u = Internal.getNodeFromName2(z, 'VelocityX')[1]
+                u -= 2. * np.tanh((np.arange(u.shape[0]) - u.shape[0] / 2.) / 1.5)[:, None, None]
+        return t
     if kind == 'tgv2d':
         kw = {}
         if 'ss_iteration' in opts:

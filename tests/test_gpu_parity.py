@@ -236,7 +236,7 @@ def test_slopes_without_a_reference_flux_are_refused():
     t = cases.tgv(8, 'ausmpred', extra_numz={'slope': 'minmod'})
     with pytest.raises(_capi.FastsHipError, match="slope"):
         FastS.warmup(t, None)
-    t = cases.tgv(8, 'roe', extra_numz={'slope': 'o3sc'})
+    t = cases.tgv(8, 'senseur', extra_numz={'slope': 'o1'})
     with pytest.raises(_capi.FastsHipError, match="slope"):
         FastS.warmup(t, None)
 
