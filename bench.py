@@ -195,6 +195,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--cells', dest='n', type=int, default=256, help='cells per direction per GPU block')
     ap.add_argument('--scheme', default='senseur', choices=['senseur', 'ausmpred', 'roe'])
+    ap.add_argument('--slope', default='o3', choices=['o3', 'o3sc'], help="o3sc: the o3 states weighted by a shock sensor "
+                    "(kernels of their own, one thread per cell); single GPU, TGV case")
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--implicit', type=int, default=0, metavar='SS_ITERATION', help='implicit BDF/LU-SGS steps with '
                     'this many Newton sub-iterations; not the headline workload')
@@ -281,6 +283,8 @@ def main():
             kw = {'temporal_scheme': 'implicit', 'extra_numb': {'ss_iteration': a.implicit}}
         if a.implicit and a.nb_relax > 1:
             kw['extra_numz'] = {'nb_relax': a.nb_relax}
+        if a.slope != 'o3':
+            kw['extra_numz'] = dict(kw.get('extra_numz') or {}, slope=a.slope)
         if a.implicit and a.local_newton:
             kw['temporal_scheme'] = 'implicit_local'
             kw['modulo_verif'] = 7
@@ -366,6 +370,7 @@ def main():
                        "blocks": list(a.channel) if a.channel else list(split_for(world) or (1, 1, 1)),
                        "block_cells": [a.n // b for b in a.channel] if a.channel else list(block_cells(a.n, world)),
                        "ghost_layers": 2,
+                       "slope": a.slope,
                        "mesh": "two-dimensional C-mesh" if a.naca else ("curvilinear (perturb %g)" % a.perturb if a.perturb else "cartesian"),
                        "time_scheme": ("implicit BDF1 local time step, LU-SGS, %d Newton sub-iterations" if a.naca else
                                        "implicit BDF2 LU-SGS, %d Newton sub-iterations") % a.implicit +
