@@ -47,6 +47,13 @@ CASES = {
                                    ssdom=(4, 4, 4), epsi=0.1, nit=7, bcs={'jmin': 'BCWall', 'jmax': 'BCWallViscous'}),
     'local_two_blocks':       dict(kind='tgv', n=(12, 12, 24), scheme='ausmpred', model='NSLaminar', ss_iteration=6, kmod=1,
                                    ssdom=(4, 4, 4), epsi=0.1, nit=6, blocks=(1, 1, 2)),
+    # wider than one tile of the Cartesian stage kernel (64 x 8 cells) and than one patch of the curvilinear one (31 x 7):
+    # the boxes launch tile lists; the field is kept for the last step only
+    'local_tiles_cart':       dict(kind='tgv', n=(72, 20, 16), scheme='senseur', model='NSLaminar', ss_iteration=6, kmod=2,
+                                   ssdom=(12, 5, 4), epsi=0.1, nit=6, last_only=True),
+    'local_tiles_curv':       dict(kind='tgv', n=(40, 18, 20), scheme='ausmpred', model='NSLaminar', ss_iteration=6, kmod=2,
+                                   ssdom=(8, 6, 5), epsi=0.1, nit=6, perturb=0.15, last_only=True,
+                                   bcs={'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
     'local_plane2d':          dict(kind='tgv2d', n=(24, 16), scheme='ausmpred', model='NSLaminar', ss_iteration=6, kmod=2,
                                    ssdom=(4, 4, 1), epsi=0.1, nit=10, perturb=0.15, bcs={'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
 }
@@ -120,7 +127,8 @@ def main():
             shapes.append([int(v) for v in nbox.sum(axis=1)])
             for b, zn in enumerate(rz):
                 out['target_it%d_%d' % (it, b)] = s._sz_views(zn)['it_target'][:zn.sz_n].copy()
-                out['ro_it%d_%d' % (it, b)] = zn.ro.copy()
+                if not c.get('last_only') or it == nit:
+                    out['ro_it%d_%d' % (it, b)] = zn.ro.copy()
                 if it % c['kmod'] == 0:
                     l2, loo = assemble_rdm(zn.pint, zn.preal, zn.rdm, nssiter, zn.it_bloc)
                     out['hist_it%d_%d' % (it, b)] = np.stack([l2, loo], axis=1)

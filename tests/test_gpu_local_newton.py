@@ -52,7 +52,9 @@ def _run(name, layer):
                     it, b, nstep, got.tolist(), want.tolist())
             key = 'ro_it%d_%d' % (it, b)
             got = FastC.level_buffer(z)
-            if sa:
+            if key not in g.files:
+                pass          # large cases keep the field of the last step only
+            elif sa:
                 # the destruction term of the model takes a 1/6 power, and the device pow differs from the host's in
                 # the last bit: 1e-12 relative instead of equality
                 from common import rel_err
