@@ -87,7 +87,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     for (int r = 0; r < 3; r++) if (zn.pinned[r]) { if (hipHostUnregister(zn.pinned[r]) != hipSuccess) (void)hipGetLastError(); }
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
-    (void)hipFree(zn.blk_res); (void)hipFree(zn.wsc);
+    (void)hipFree(zn.blk_res); (void)hipFree(zn.wsc); (void)hipFree(zn.wflux);
     for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); (void)hipFree(bb.lu_dev); }
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
@@ -795,6 +795,8 @@ extern "C" int fs_upload(fs_ctx *ctx)
         const size_t nw = sizeof(double) * 3 * (size_t)zn.z.nd;
         HIPCHK(ctx, hipMalloc(&zn.wsc, nw));
         HIPCHK(ctx, hipMemsetAsync(zn.wsc, 0, nw, ctx->stream));
+        HIPCHK(ctx, hipMalloc(&zn.wflux, 5 * nw));
+        HIPCHK(ctx, hipMemsetAsync(zn.wflux, 0, 5 * nw, ctx->stream));
       }
       if (zn.z.kflu == 2) {
         // face sensors: 0/1 values, one byte per cell and direction (curvilinear and SA kernels) or one byte per
@@ -1241,7 +1243,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       // o3sc: the shock sensor of the state this sub-iteration starts from (src_term.for:246-255), then kernels of its own
       fsk_sciacovelli(z, zn.dev[in], zn.wsc, ctx->stream);
       krc = z.ityp == 0 ? fsk_stage_o3sc_full(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
-                                              (unsigned char *)zn.wig, zn.wsc, kbdf, keep, ctx->stream)
+                                              (unsigned char *)zn.wig, zn.wsc, zn.wflux, kbdf, keep, ctx->stream)
                         : fsk_stage_o3sc_cart(z, coefH, coefW, kfirst, zn.dev[in], kout, zn.drodm, zn.xmut,
                                               (unsigned char *)zn.wig, zn.wsc, kbdf, keep, ctx->stream);
     } else if (z.iflow == 3 && z.ityp != 0)

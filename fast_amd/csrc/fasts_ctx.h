@@ -18,6 +18,7 @@ struct Zone {
   double *dev[3] = {nullptr, nullptr, nullptr};
   double *drodm = nullptr, *xmut = nullptr, *wig = nullptr;
   double *wsc = nullptr;       // o3sc slope: shock sensor of the faces, 3 doubles per cell
+  double *wflux = nullptr;     // o3sc slope: face fluxes of the three directions, 15 doubles per cell
   double *mtr_dev = nullptr;   // curvilinear zones: [ti(ndm,3) | tj | tk | vol]
   // implicit scheme: coe(nd,5) = dt/vol, spectral radii i/j/k, LU diagonal; one spare time level
   double *coe = nullptr, *scratch = nullptr;

@@ -68,9 +68,10 @@ void fsk_sciacovelli(const FsZone &z, const double *rop, double *wsc, hipStream_
 int fsk_stage_o3sc_cart(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
                         double *drodm, const double *xmut, unsigned char *wig, const double *wsc, const FsBdf *bdf,
                         int keep_balance, hipStream_t s);
+// flux: work array of 15 doubles per cell (the fluxes of the faces of the three directions)
 int fsk_stage_o3sc_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, const FsBdf *bdf,
-                        int keep_balance, hipStream_t s);
+                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, double *flux,
+                        const FsBdf *bdf, int keep_balance, hipStream_t s);
 struct FsBox { int b[6]; };   // i1, i2, j1, j2, k1, k2
 // Sub-zones: the flux loops of the reference add the flux of a face to the cell on its upper side and take it from the
 // cell on its lower side, the cells just outside the range included (Compute/template_FluxAndBalance.for:192-271,

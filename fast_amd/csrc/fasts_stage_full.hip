@@ -416,48 +416,53 @@ __global__ void __launch_bounds__(256) k_sa_coe6_full(FsZone z, const double *__
   coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
 }
 
-// o3sc slope on curvilinear / two-dimensional / k-homogeneous zones: one thread per cell, its six (four) face fluxes from
-// memory (every face is evaluated by the two cells it separates, with the same operands), balance and end of the stage
-// as k_stage_full has them.  5 equations.
-template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO>
-__global__ void __launch_bounds__(256) k_stage_o3sc_full(FsZone z, double coefH, double coefW, int keep,
-                                                         const double *__restrict__ rop, double *__restrict__ rop_out,
-                                                         double *__restrict__ drodm, const double *__restrict__ xmut,
-                                                         unsigned char *__restrict__ wig, const double *__restrict__ wsc,
-                                                         FsBdf bdf)
+// o3sc slope on curvilinear / two-dimensional / k-homogeneous zones, 5 equations: the fluxes of the faces of one
+// direction per launch, one thread per face, operands from memory through the face function of k_stage_full (with the
+// weight of the shock sensor), into an array of 15 doubles per cell; then one thread per cell adds them up in the order
+// k_stage_full has and ends the stage the same way.  (All six faces of a cell in one thread want some 900 registers.)
+template <int KFLU, int IFLOW, int DIR, bool FIRST, bool TWOD, bool HOMO>
+__global__ void __launch_bounds__(256) k_faces_o3sc_full(FsZone z, const double *__restrict__ rop,
+                                                         const double *__restrict__ xmut, unsigned char *__restrict__ wig,
+                                                         const double *__restrict__ wsc, double *__restrict__ flux)
+{
+  // faces of direction DIR: their right cells run to n + 1 along DIR
+  const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y, k = 1 + blockIdx.z;
+  if (i > z.iv + (DIR == 0 ? 1 : 0) || j > z.jv + (DIR == 1 ? 1 : 0) || k > z.kv + (DIR == 2 ? 1 : 0)) return;
+  const long long nd = z.nd;
+  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  const long long lt = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck;
+  const long long st = DIR == 0 ? 1 : (DIR == 1 ? z.incj : z.inck);
+  double qm2[5], qm1[5], q0[5], qp1[5], f[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    qm2[e] = rop[e * nd + l - 2 * st]; qm1[e] = rop[e * nd + l - st]; q0[e] = rop[e * nd + l]; qp1[e] = rop[e * nd + l + st];
+  }
+  const RdGlobal rdg = {rop, nd, l, z.incj, TWOD ? 0 : z.inck};
+  face_full<KFLU, IFLOW, DIR, FIRST, TWOD, HOMO>(z, rdg, xmut, wig, l, lt, qm2, qm1, q0, qp1, f, wsc[l + DIR * nd]);
+#pragma unroll
+  for (int e = 0; e < 5; e++) flux[(DIR * 5 + e) * nd + l] = f[e];
+}
+
+template <bool FIRST, bool BDF, bool TWOD>
+__global__ void __launch_bounds__(256) k_balance_o3sc_full(FsZone z, double coefH, double coefW, int keep,
+                                                           const double *__restrict__ rop, double *__restrict__ rop_out,
+                                                           double *__restrict__ drodm, const double *__restrict__ flux,
+                                                           FsBdf bdf)
 {
   const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y, k = 1 + blockIdx.z;
   if (i > z.iv) return;
   const long long nd = z.nd;
   const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
   const long long lt = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck;
-  auto face = [&](auto dirc, long long lf, long long ltf, double *f) {
-    constexpr int DIR = decltype(dirc)::value;
-    const long long st = DIR == 0 ? 1 : (DIR == 1 ? z.incj : z.inck);
-    double qm2[5], qm1[5], q0[5], qp1[5];
-#pragma unroll
-    for (int e = 0; e < 5; e++) {
-      qm2[e] = rop[e * nd + lf - 2 * st]; qm1[e] = rop[e * nd + lf - st]; q0[e] = rop[e * nd + lf]; qp1[e] = rop[e * nd + lf + st];
-    }
-    const RdGlobal rdg = {rop, nd, lf, z.incj, TWOD ? 0 : z.inck};
-    face_full<KFLU, IFLOW, DIR, FIRST, TWOD, HOMO>(z, rdg, xmut, wig, lf, ltf, qm2, qm1, q0, qp1, f, wsc[lf + DIR * nd]);
-  };
-  double fkm[5] = {0., 0., 0., 0., 0.}, fjm[5], fim[5], fip[5], fjp[5], fkp[5] = {0., 0., 0., 0., 0.};
-  if (!TWOD) face(std::integral_constant<int, 2>(), l, lt, fkm);
-  face(std::integral_constant<int, 1>(), l, lt, fjm);
-  face(std::integral_constant<int, 0>(), l, lt, fim);
-  face(std::integral_constant<int, 0>(), l + 1, lt + 1, fip);
-  face(std::integral_constant<int, 1>(), l + z.incj, lt + z.mincj, fjp);
-  if (!TWOD) face(std::integral_constant<int, 2>(), l + z.inck, lt + z.minck, fkp);
   double q[5], d[5], o[5];
 #pragma unroll
   for (int e = 0; e < 5; e++) {
     q[e] = rop[e * nd + l];
     const double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
-    double a = dr + fkm[e];
-    a = a + fjm[e]; a = a + fim[e];
-    a = a - fip[e]; a = a - fjp[e];
-    d[e] = TWOD ? a : a - fkp[e];
+    double a = dr + (TWOD ? 0. : flux[(10 + e) * nd + l]);
+    a = a + flux[(5 + e) * nd + l]; a = a + flux[e * nd + l];
+    a = a - flux[e * nd + l + 1]; a = a - flux[(5 + e) * nd + l + z.incj];
+    d[e] = TWOD ? a : a - flux[(10 + e) * nd + l + z.inck];
   }
   const double coe = z.dt / z.vol[lt];
   if (BDF) {
@@ -542,32 +547,44 @@ __global__ void __launch_bounds__(256) k_sa_ring_full(FsZone z, FsBox box, const
 }  // namespace
 
 int fsk_stage_o3sc_full(const FsZone &z, double coefH, double coefW, int first, const double *rop, double *rop_out,
-                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, const FsBdf *bdf,
-                        int keep_balance, hipStream_t s)
+                        double *drodm, const double *xmut, unsigned char *wig, const double *wsc, double *flux,
+                        const FsBdf *bdf, int keep_balance, hipStream_t s)
 {
-  if (z.ityp != 0 || z.neq != 5 || !wsc || !z.vol || (z.kflu == 2 && !wig)) return -1;
+  if (z.ityp != 0 || z.neq != 5 || !wsc || !flux || !z.vol || (z.kflu == 2 && !wig)) return -1;
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
   if (bdf) b = *bdf;
-  dim3 g((unsigned)((z.iv + 255) / 256), (unsigned)z.jv, (unsigned)z.kv);
-#define FS_L(...) hipLaunchKernelGGL((k_stage_o3sc_full<__VA_ARGS__>), g, dim3(256), 0, s, z, coefH, coefW, keep_balance, rop, \
-                                     rop_out, drodm, xmut, wig, wsc, b)
-#define FS_GO(K, F, FIRST_, BDF_)                                                                   \
-  do {                                                                                              \
-    if (z.twod) FS_L(K, F, FIRST_, BDF_, true, false);                                              \
-    else if (z.homo) FS_L(K, F, FIRST_, BDF_, false, true);                                         \
-    else FS_L(K, F, FIRST_, BDF_, false, false);                                                    \
+  const unsigned gx = (unsigned)((z.iv + 1 + 255) / 256);
+#define FS_F(K, F, D, FIRST_, T2, HO, g) hipLaunchKernelGGL((k_faces_o3sc_full<K, F, D, FIRST_, T2, HO>), g, dim3(256), 0, s, z, rop, xmut, wig, wsc, flux)
+#define FS_FACES(K, F, FIRST_, T2, HO)                                                             \
+  do {                                                                                             \
+    if (!T2) FS_F(K, F, 2, FIRST_, T2, HO, dim3(gx, (unsigned)z.jv, (unsigned)z.kv + 1));         \
+    FS_F(K, F, 1, FIRST_, T2, HO, dim3(gx, (unsigned)z.jv + 1, (unsigned)z.kv));                  \
+    FS_F(K, F, 0, FIRST_, T2, HO, dim3(gx, (unsigned)z.jv, (unsigned)z.kv));                      \
   } while (0)
-#define FS_CASE(K, F)                                                                                         \
-  if (z.kflu == K && z.iflow == F) {                                                                          \
-    if (bdf) { if (first) FS_GO(K, F, true, true); else FS_GO(K, F, false, true); }                           \
-    else { if (first) FS_GO(K, F, true, false); else FS_GO(K, F, false, false); }                             \
-    return 0;                                                                                                 \
-  }
+#define FS_GO(K, F, FIRST_)                                                                        \
+  do {                                                                                             \
+    if (z.twod) FS_FACES(K, F, FIRST_, true, false);                                               \
+    else if (z.homo) FS_FACES(K, F, FIRST_, false, true);                                          \
+    else FS_FACES(K, F, FIRST_, false, false);                                                     \
+  } while (0)
+#define FS_CASE(K, F) if (z.kflu == K && z.iflow == F) { if (first) FS_GO(K, F, true); else FS_GO(K, F, false); ok = true; }
+  bool ok = false;
   FS_CASE(1, 1) FS_CASE(1, 2) FS_CASE(2, 1) FS_CASE(2, 2) FS_CASE(5, 1) FS_CASE(5, 2)
 #undef FS_CASE
 #undef FS_GO
-#undef FS_L
-  return -1;
+#undef FS_FACES
+#undef FS_F
+  if (!ok) return -1;
+  dim3 g((unsigned)((z.iv + 255) / 256), (unsigned)z.jv, (unsigned)z.kv);
+#define FS_B(FIRST_, BDF_)                                                                                        \
+  do {                                                                                                            \
+    if (z.twod) hipLaunchKernelGGL((k_balance_o3sc_full<FIRST_, BDF_, true>), g, dim3(256), 0, s, z, coefH, coefW, keep_balance, rop, rop_out, drodm, flux, b); \
+    else hipLaunchKernelGGL((k_balance_o3sc_full<FIRST_, BDF_, false>), g, dim3(256), 0, s, z, coefH, coefW, keep_balance, rop, rop_out, drodm, flux, b);      \
+  } while (0)
+  if (bdf) { if (first) FS_B(true, true); else FS_B(false, true); }
+  else { if (first) FS_B(true, false); else FS_B(false, false); }
+#undef FS_B
+  return 0;
 }
 
 void fsk_box_faces_full(const FsZone &z, const int *box, const double *rop, const double *xmut, unsigned char *wig,
