@@ -91,6 +91,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); (void)hipFree(bb.lu_dev); }
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
+    fsk_luflow_free(zn.lu_flow);
     if (zn.ev_part) (void)hipEventDestroy(zn.ev_part);
     if (zn.ev_lu_fork) (void)hipEventDestroy(zn.ev_lu_fork);
     if (zn.ev_lu_join) (void)hipEventDestroy(zn.ev_lu_join);
@@ -1376,7 +1377,8 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
                                        zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
                                        zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
                           : fsk_lusgs(z, zn.lu, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.preal[GAMMA], zn.dev[in],
-                                      zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls);
+                                      zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, false,
+                                      zn.lu_flow ? zn.lu_flow : (zn.lu_flow = fsk_luflow_new()));
       }
       if (sfd && !verif && nstep == z.nssiter - 1)
         fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, zn.coe, ls);

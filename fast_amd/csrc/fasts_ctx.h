@@ -36,6 +36,7 @@ struct Zone {
   // whole range `lu` in one lexicographic sweep
   std::vector<int> lu_blocks;
   int *lu_blocks_dev = nullptr;
+  FsLuFlow *lu_flow = nullptr;   // one-launch-per-sweep form of the LU-SGS sweeps (created at the first implicit solve)
   double *res_part = nullptr, *res_out = nullptr;   // res_out: 12 residual sums / maxima per sub-iteration, then the CFL triple
   int res_slots = 0;              // sub-iterations of the last verification step whose norms are in res_out
   bool have_cfl = false;

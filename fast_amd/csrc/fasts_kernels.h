@@ -125,9 +125,15 @@ void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, doub
                       const double *rop, const double *xmut, double *coe, hipStream_t s);
 // range[6] = cells swept (interior, plus one ghost layer on wall faces)
 // apart = true: the blocks are boxes that do not cover `range` (sub-zones): nothing outside them is touched
+// flow: state of the one-launch-per-sweep form of a zone (used for one sweep of the range; nullptr: one launch per
+// hyperplane); fsk_luflow_gave_up: 1 once a wave of such a launch has stopped waiting for a predecessor (a defect)
+struct FsLuFlow;
+FsLuFlow *fsk_luflow_new();
+void fsk_luflow_free(FsLuFlow *f);
+int fsk_luflow_gave_up(const FsLuFlow *f);
 int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
               const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s,
-              bool apart = false);
+              bool apart = false, FsLuFlow *flow = nullptr);
 int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nblocks, const int *blocks, const int *blocks_dev,
                int nb_relax, int overlap, double gamma, const double *rop, double *rop_out, double *scratch, const double *din,
                double *work, const double *coe, hipStream_t s);

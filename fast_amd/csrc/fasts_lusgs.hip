@@ -14,8 +14,10 @@
 #include "fasts_kernels.h"
 #include "fasts_flux.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -234,8 +236,17 @@ extern "C" int fs_lu_stamp_fetch(long long *host)
 {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fs_lu_stamp_buf), sizeof(long long) * 1024 * 8);
 }
+// the same for the one-launch sweeps: wall-clock stamps of the wave that works the task in the middle of the order
+// (lower sweep), five per step
+#define FLOWSTAMP(slot)                                                                                   \
+  {                                                                                                       \
+    asm volatile("" ::: "memory");                                                                        \
+    if (n == ntasks / 2 && threadIdx.x == 0 && s < 128) fs_lu_stamp_buf[s * 8 + (slot)] = (long long)wall_clock64(); \
+    asm volatile("" ::: "memory");                                                                        \
+  }
 #else
 #define LUSTAMP(slot, wait)
+#define FLOWSTAMP(slot)
 #endif
 
 // Value of the previous / next lane by a DPP row shift (a VALU move, no trip through the LDS crossbar as
@@ -740,6 +751,312 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Dataflow form of the two LU-SGS sweeps: ONE launch per sweep instead of one per hyperplane.  A task is a pencil of 8
+// consecutive j-lines of one k-plane; a wave takes a task and walks along i in steps: at step s the unit (8 cells) of its
+// line number q (in sweep order) is chunk s - q of that line, lane = (line, cell).  The three predecessors of that unit
+// are then: the chunk before it on its line and the same chunk of the line before -- both worked by this wave one step
+// earlier -- and the same chunk of the line in the plane before, worked at step s by the pencil (jb, k -+ 1).  The first
+// line of a pencil follows the last line of pencil jb -+ 1, which reaches that chunk at its step s + 7.  Every wave
+// publishes the number of steps it has finished in a word of its task; a wave polls the words of its two predecessor
+// pencils before it reads their increments.  Tasks are handed out in the order of their first possible step by an atomic
+// counter, so whatever the number of waves the chip runs at once, the predecessors of a task are finished or held by a
+// running wave.  Per cell the operations are those of the per-hyperplane kernels above, in the same order.
+// Visibility between waves of one launch (the L2 caches of the 8 XCDs are private, a CU's L1 is never refreshed): every
+// increment (and, in the upper sweep, every new state) is stored write-through (sc1), the storing wave waits for its
+// stores (vmcnt(0)) before one lane publishes the step count by an sc1 store; the reader polls that word by sc1 loads and
+// reads increments and new states by sc1 loads only (they bypass the L1).  Everything else the sweeps read is written
+// by no wave of the launch.
+// ------------------------------------------------------------------------------------------------------
+struct FlowTask { int jb, k, fid, pad; };    // group of 8 lines, k-plane, index of the progress word
+
+FS_DEV double ld_sc1(const double *p)
+{
+  return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+FS_DEV void st_sc1(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+enum { FLOW_COUNTER = 0, FLOW_ABORT = 1, FLOW_FLAGS = 16 };
+constexpr unsigned FLOW_SPIN_LIMIT = 1u << 22;
+
+// Lane 0 waits for *fa >= na, lane 1 for *fb >= nb (0: nothing to wait for).  When the first poll has landed every
+// older store of the wave has too: the step count `done` of the wave's own task is published then (0: nothing to
+// publish).  false: gave up (a predecessor never came, or another wave gave up): the caller leaves the kernel.
+FS_DEV bool flow_wait(const unsigned *fa, unsigned na, const unsigned *fb, unsigned nb, unsigned *mine, unsigned done,
+                      unsigned *sync, unsigned *sticky)
+{
+  const int lane = threadIdx.x;
+  const unsigned *p = lane == 0 ? fa : fb;
+  const unsigned need = lane == 0 ? na : (lane == 1 ? nb : 0u);
+  bool ok = need == 0u;
+  if (!ok) ok = __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (done && lane == 0) __hip_atomic_store(mine, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__all(ok)) return true;
+  bool alive = true;
+  for (unsigned spins = 1; alive; spins++) {
+    __builtin_amdgcn_s_sleep(1);
+    if (!ok) ok = __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+    if (__all(ok)) break;
+    bool stop = spins > FLOW_SPIN_LIMIT;
+    if ((spins & 255u) == 255u && lane == 0)
+      stop = stop || __hip_atomic_load(sync + FLOW_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (__any(stop)) alive = false;
+  }
+  if (!alive && lane == 0) {
+    __hip_atomic_store(sync + FLOW_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return alive;
+}
+
+template <bool FULL, int NE>
+__global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRange r, int njb,
+                                                      const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
+                                                      unsigned *sticky, const double *__restrict__ rop, double *dw,
+                                                      const double *__restrict__ coe)
+{
+  const int lane = threadIdx.x, jj = lane >> 3, m = lane & 7;
+  unsigned *flags = sync + FLOW_FLAGS;
+  const long long nd = z.nd;
+  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + 7) >> 3, nsteps = nchunk + 7;
+  const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
+  // Every lane adds one to the counter (the compiler turns that into one add of 64 by one lane): a task index that
+  // depended on which lanes are active at this point would not survive the restructuring of the loops around it.
+  for (bool alive = true; alive;) {
+    const int n = (int)(__builtin_amdgcn_readfirstlane(
+                      __hip_atomic_fetch_add(sync + FLOW_COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6);
+    if (n >= ntasks) break;
+    const FlowTask t = tasks[n];
+    const int j = r.j0 + 8 * t.jb + jj, k = t.k;
+    const bool line_ok = j <= r.j1;
+    const bool has_j = j > r.j0, has_k = k > r.k0;
+    const unsigned *fk = flags + t.fid - njb, *fj = flags + t.fid - 1;
+    unsigned *mine = flags + t.fid;
+    const long long lrow = lcell(z, r.i0, line_ok ? j : r.j0, k) + m, ltrow = FULL ? lmtr(z, r.i0, line_ok ? j : r.j0, k) + m : 0;
+    const long long dj_ = has_j ? z.incj : 0, dk_ = has_k ? z.inck : 0;   // a cell without a neighbour reads itself, and drops the term
+    // cell of this lane at step s: lanes without one read the first cell of the range and store nothing
+    auto geom = [&](int s, bool &active, bool &has_prev, long long &l, long long &lt) {
+      const int cn = s - jj, di = cn * 8;
+      active = line_ok && cn >= 0 && cn < nchunk && di + m < ni;
+      has_prev = active && di + m > 0;
+      l = active ? lrow + di : lsafe;
+      lt = FULL ? (active ? ltrow + di : ltsafe) : 0;
+    };
+    // what a step reads that no wave of the launch writes, loaded one step ahead
+    double sA[NE], sxal, sc5, sc6 = 1., sk[4], ck, sj[4], cj, si[4], ci;
+    auto load_stat = [&](int s) {
+      bool active, has_prev; long long l, lt;
+      geom(s, active, has_prev, l, lt);
+      const long long lj = l - dj_, lk = l - dk_, li = has_prev ? l - 1 : l;
+      sxal = coe[l]; sc5 = coe[l + 4 * nd];
+      if (NE == 6) sc6 = coe[l + 5 * nd];
+#pragma unroll
+      for (int e = 0; e < NE; e++) sA[e] = dw[l + e * nd];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { sk[e] = rop[lk + (e + 1) * nd]; sj[e] = rop[lj + (e + 1) * nd]; si[e] = rop[li + (e + 1) * nd]; }
+      ck = coe[lk + 3 * nd]; cj = coe[lj + 2 * nd]; ci = coe[li + nd];
+    };
+    load_stat(0);
+    for (int s = 0; s <= nsteps && alive; s++) {   // pass nsteps publishes the last count only
+      bool active, has_prev; long long l, lt;
+      geom(s, active, has_prev, l, lt);
+      const long long lj = l - dj_, lk = l - dk_, li = (has_prev && m == 0) ? l - 1 : l;
+      // the plane before has finished this step; the pencil before has finished the chunk its last line hands over
+      const unsigned need_k = (k > r.k0 && s < nsteps) ? (unsigned)(s + 1) : 0u;
+      const unsigned need_j = (t.jb > 0 && s < nchunk) ? (unsigned)(s + 8) : 0u;
+      FLOWSTAMP(0)
+      alive = flow_wait(fk, need_k, fj, need_j, mine, (unsigned)s, sync, sticky);
+      FLOWSTAMP(1)
+      if (!alive || s == nsteps) continue;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double A[NE], P[NE], dk[NE], dj[NE];
+#pragma unroll
+      for (int e = 0; e < NE; e++) { dk[e] = ld_sc1(dw + lk + e * nd); dj[e] = ld_sc1(dw + lj + e * nd); P[e] = ld_sc1(dw + li + e * nd); }
+      // the matrices of the three neighbours while the increments are on their way, then the loads of the next step
+      double MI[26], MJ[26], MK[26];
+      const double XAL = sxal * 0.5, DG = 1. / sc5, C6 = sc6;
+#pragma unroll
+      for (int e = 0; e < NE; e++) A[e] = sA[e];
+      lu_mat<FULL, 2, 1, NE>(z, c, lt, sk[0], sk[1], sk[2], sk[3], ck, MK);
+      lu_mat<FULL, 1, 1, NE>(z, c, lt, sj[0], sj[1], sj[2], sj[3], cj, MJ);
+      lu_mat<FULL, 0, 1, NE>(z, c, lt, si[0], si[1], si[2], si[3], ci, MI);
+      if (s + 1 < nsteps) load_stat(s + 1);
+      {
+        double bk[NE], bj[NE];
+        lu_mul<FULL, 2, NE>(MK, dk[0], dk[1], dk[2], dk[3], dk[4], bk, NE == 6 ? dk[NE - 1] : 0.);
+        lu_mul<FULL, 1, NE>(MJ, dj[0], dj[1], dj[2], dj[3], dj[4], bj, NE == 6 ? dj[NE - 1] : 0.);
+        if (FULL) {
+          if (has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
+          if (has_j) { for (int e = 0; e < NE; e++) A[e] = A[e] + bj[e] * XAL; }
+        } else {
+          if (has_j) { for (int e = 0; e < NE; e++) A[e] = A[e] + bj[e] * XAL; }
+          if (has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
+        }
+      }
+      FLOWSTAMP(2)
+      auto cell = [&](const double *pin) {
+        if (has_prev) {
+          double b[NE];
+          lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+#pragma unroll
+          for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
+        }
+#pragma unroll
+        for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+        if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
+      };
+      if (m == 0 && active) {
+        double pin[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) pin[e] = P[e];
+        cell(pin);
+      }
+#pragma unroll
+      for (int st = 1; st < 8; st++) {
+        double pin[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) pin[e] = lane_prev(P[e]);
+        if (m == st && active) cell(pin);
+      }
+      FLOWSTAMP(3)
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) st_sc1(dw + l + e * nd, P[e]);
+      }
+      FLOWSTAMP(4)
+    }
+  }
+}
+
+// Upper sweep and Newton update: the pencils in the opposite order, the lines of a pencil downwards, the chunks of a
+// line from the last to the first.  The state of the k + 1 neighbour is the new one when the update is in place
+// (rop_kn = the array the new iterate is built in): handed over like the increments.
+template <bool FULL, int NE>
+__global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, LuRange r, int njb,
+                                                      const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
+                                                      unsigned *sticky, const double *__restrict__ rop, const double *rop_kn,
+                                                      double *rop_new, double *dw, const double *__restrict__ coe)
+{
+  const int lane = threadIdx.x, jj = lane >> 3, m = lane & 7, q7 = 7 - jj;
+  unsigned *flags = sync + FLOW_FLAGS;
+  const long long nd = z.nd;
+  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + 7) >> 3, nsteps = nchunk + 7;
+  const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
+  for (bool alive = true; alive;) {
+    const int n = (int)(__builtin_amdgcn_readfirstlane(
+                      __hip_atomic_fetch_add(sync + FLOW_COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6);
+    if (n >= ntasks) break;
+    const FlowTask t = tasks[ntasks - 1 - n];
+    const int j = r.j0 + 8 * t.jb + jj, k = t.k;
+    const bool line_ok = j <= r.j1;
+    const bool has_j = j < r.j1, has_k = k < r.k1;
+    const unsigned *fk = flags + t.fid + njb, *fj = flags + t.fid + 1;
+    unsigned *mine = flags + t.fid;
+    const long long lrow = lcell(z, r.i0, line_ok ? j : r.j0, k) + m, ltrow = FULL ? lmtr(z, r.i0, line_ok ? j : r.j0, k) + m : 0;
+    const long long dj_ = has_j ? z.incj : 0, dk_ = has_k ? z.inck : 0;
+    auto geom = [&](int s, bool &active, bool &has_next, long long &l, long long &lt) {
+      const int cn = nchunk - 1 - (s - q7), di = cn * 8;
+      active = line_ok && cn >= 0 && cn < nchunk && di + m < ni;
+      has_next = active && di + m < ni - 1;
+      l = active ? lrow + di : lsafe;
+      lt = FULL ? (active ? ltrow + di : ltsafe) : 0;
+    };
+    double sA[NE], sq[NE], sxal, sc5, sc6 = 1., ck, sj[4], cj, si[4], ci;
+    auto load_stat = [&](int s) {
+      bool active, has_next; long long l, lt;
+      geom(s, active, has_next, l, lt);
+      const long long lj = l + dj_, lk = l + dk_, li = has_next ? l + 1 : l;
+      sxal = coe[l]; sc5 = coe[l + 4 * nd];
+      if (NE == 6) sc6 = coe[l + 5 * nd];
+#pragma unroll
+      for (int e = 0; e < NE; e++) { sA[e] = dw[l + e * nd]; sq[e] = rop[l + e * nd]; }
+#pragma unroll
+      for (int e = 0; e < 4; e++) { sj[e] = rop[lj + (e + 1) * nd]; si[e] = rop[li + (e + 1) * nd]; }
+      ck = coe[lk + 3 * nd]; cj = coe[lj + 2 * nd]; ci = coe[li + nd];
+    };
+    load_stat(0);
+    for (int s = 0; s <= nsteps && alive; s++) {   // pass nsteps publishes the last count only
+      bool active, has_next; long long l, lt;
+      geom(s, active, has_next, l, lt);
+      const bool last_of_unit = m == 7 || !has_next;
+      const long long lj = l + dj_, lk = l + dk_, li = (has_next && last_of_unit) ? l + 1 : l;
+      const unsigned need_k = (k < r.k1 && s < nsteps) ? (unsigned)(s + 1) : 0u;
+      const unsigned need_j = (t.jb < njb - 1 && s < nchunk) ? (unsigned)(s + 8) : 0u;
+      alive = flow_wait(fk, need_k, fj, need_j, mine, (unsigned)s, sync, sticky);
+      if (!alive || s == nsteps) continue;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double A[NE], P[NE], dk[NE], dj[NE], sk[4], q[NE];
+#pragma unroll
+      for (int e = 0; e < 4; e++) sk[e] = ld_sc1(rop_kn + lk + (e + 1) * nd);
+#pragma unroll
+      for (int e = 0; e < NE; e++) { dk[e] = ld_sc1(dw + lk + e * nd); dj[e] = ld_sc1(dw + lj + e * nd); P[e] = ld_sc1(dw + li + e * nd); }
+      double MI[26], MJ[26], MK[26];
+      const double XAL = sxal * -0.5, c5 = sc5, DG = 1. / c5, C6 = sc6, ckk = ck;
+#pragma unroll
+      for (int e = 0; e < NE; e++) { A[e] = sA[e] * c5; q[e] = sq[e]; }
+      if (NE == 6) A[NE - 1] = sA[NE - 1] * C6;   // LU/lu_d_SA.for
+      lu_mat<FULL, 1, -1, NE>(z, c, lt, sj[0], sj[1], sj[2], sj[3], cj, MJ);
+      lu_mat<FULL, 0, -1, NE>(z, c, lt, si[0], si[1], si[2], si[3], ci, MI);
+      if (s + 1 < nsteps) load_stat(s + 1);
+      {
+        double bk[NE], bj[NE];
+        lu_mat<FULL, 2, -1, NE>(z, c, lt, sk[0], sk[1], sk[2], sk[3], ckk, MK);
+        lu_mul<FULL, 2, NE>(MK, dk[0], dk[1], dk[2], dk[3], dk[4], bk, NE == 6 ? dk[NE - 1] : 0.);
+        lu_mul<FULL, 1, NE>(MJ, dj[0], dj[1], dj[2], dj[3], dj[4], bj, NE == 6 ? dj[NE - 1] : 0.);
+        if (has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
+        if (has_j) { for (int e = 0; e < NE; e++) A[e] = A[e] + bj[e] * XAL; }
+      }
+      auto cell = [&](const double *pin) {
+        if (has_next) {
+          double b[NE];
+          lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+#pragma unroll
+          for (int e = 0; e < NE; e++) A[e] = A[e] + b[e] * XAL;
+        }
+#pragma unroll
+        for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
+        if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
+      };
+      if (m == 7 && active) {
+        double pin[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) pin[e] = P[e];
+        cell(pin);
+      }
+#pragma unroll
+      for (int st = 6; st >= 0; st--) {
+        double pin[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) pin[e] = lane_next(P[e]);
+        if (m == st && active) cell(pin);
+      }
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) st_sc1(dw + l + e * nd, P[e]);
+        // Newton update (mjr_newton.for)
+        const double ro_old = q[0], u_old = q[1], v_old = q[2], w_old = q[3], t_old = q[4];
+        const double rn = ro_old + P[0];
+        const double r_1 = 1. / rn;
+        const double un = (ro_old * u_old + P[1]) * r_1;
+        const double vn = (ro_old * v_old + P[2]) * r_1;
+        const double wn = (ro_old * w_old + P[3]) * r_1;
+        const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+        st_sc1(rop_new + l, rn); st_sc1(rop_new + l + nd, un); st_sc1(rop_new + l + 2 * nd, vn); st_sc1(rop_new + l + 3 * nd, wn);
+        const double tn = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+        st_sc1(rop_new + l + 4 * nd, tn);
+        if (NE == 6) {   // LU/mjr_newton_SA.for: nu_tilde clipped to [0, ratiom * nu]
+          double anulam = fs_mulam_sa(z, tn);
+          anulam = anulam * r_1 * z.ratiom;
+          double t6 = (ro_old * q[NE - 1] + P[NE - 1]) * r_1;
+          t6 = fs_min(t6, anulam);
+          st_sc1(rop_new + l + 5 * nd, fs_max(t6, 0.));
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const double *__restrict__ src,
                                                     double *__restrict__ dst)
 {
@@ -864,9 +1181,122 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
   return 0;
 }
 
-int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
-              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s, bool apart)
+// Task table and synchronisation words of the dataflow sweeps of one zone (built at the first solve of a range)
+struct FsLuFlow {
+  int key[6] = {0, 0, 0, 0, 0, 0};
+  int ntasks = 0, njb = 0;
+  FlowTask *tasks_dev = nullptr;
+  unsigned *sync_dev = nullptr;     // [counter, abort, ..., one progress word per task] zeroed before every sweep, then the
+  size_t sync_bytes = 0;            // word that stays set once a wave has given up
+};
+
+FsLuFlow *fsk_luflow_new() { return new FsLuFlow; }
+void fsk_luflow_free(FsLuFlow *f)
 {
+  if (!f) return;
+  (void)hipFree(f->tasks_dev); (void)hipFree(f->sync_dev);
+  delete f;
+}
+int fsk_luflow_gave_up(const FsLuFlow *f)
+{
+  if (!f || !f->sync_dev) return 0;
+  unsigned w = 0;
+  if (hipMemcpy(&w, reinterpret_cast<const char *>(f->sync_dev) + f->sync_bytes, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return w != 0u;
+}
+
+// FASTS_HIP_LU_FLOW: 1 (default) one launch per sweep, 0 one launch per hyperplane.  FASTS_HIP_LU_FLOW_WAVES: waves of a
+// sweep launch.
+static int flow_setting(const char *name, int dflt)
+{
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+static int flow_prepare(FsLuFlow *f, const LuRange &r)
+{
+  const int key[6] = {r.i0, r.i1, r.j0, r.j1, r.k0, r.k1};
+  if (f->tasks_dev && memcmp(key, f->key, sizeof(key)) == 0) return 0;
+  const int nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
+  const int njb = (nj + 7) / 8, ntasks = njb * nk;
+  // order of the first possible step: pencil jb starts 8 steps after pencil jb - 1, plane k one step after plane k - 1
+  std::vector<FlowTask> tasks;
+  tasks.reserve((size_t)ntasks);
+  for (int T = 0; T <= 8 * (njb - 1) + nk - 1; T++)
+    for (int jb = 0; jb < njb; jb++) {
+      const int kk = T - 8 * jb;
+      if (kk < 0 || kk >= nk) continue;
+      tasks.push_back({jb, r.k0 + kk, kk * njb + jb, 0});
+    }
+  if ((int)tasks.size() != ntasks) return -1;
+  (void)hipFree(f->tasks_dev); (void)hipFree(f->sync_dev);
+  f->tasks_dev = nullptr; f->sync_dev = nullptr;
+  f->sync_bytes = (((size_t)FLOW_FLAGS + (size_t)ntasks) * sizeof(unsigned) + 15) / 16 * 16;
+  if (hipMalloc(&f->tasks_dev, sizeof(FlowTask) * (size_t)ntasks) != hipSuccess) return -1;
+  if (hipMalloc(&f->sync_dev, f->sync_bytes + 16) != hipSuccess) return -1;
+  if (hipMemcpy(f->tasks_dev, tasks.data(), sizeof(FlowTask) * (size_t)ntasks, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (hipMemset(f->sync_dev, 0, f->sync_bytes + 16) != hipSuccess) return -1;
+  memcpy(f->key, key, sizeof(key));
+  f->ntasks = ntasks; f->njb = njb;
+  return 0;
+}
+
+static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out,
+                      double *scratch, double *dw, const double *coe, hipStream_t s)
+{
+  LuConst c;
+  c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
+  c.cv = z.cv; c.cvinv = 1. / z.cv; c.cvinv2 = 0.5 * c.cvinv;
+  LuRange r = {range[0], range[1], range[2], range[3], range[4], range[5]};
+  const int ni = r.i1 - r.i0 + 1, nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
+  if (ni < 1 || nj < 1 || nk < 1) return -1;
+  const bool full = z.ityp == 0, sa = z.neq == 6;
+  const bool inplace = rop_out == rop;
+  if (inplace && !scratch) return -1;
+  double *rop_new = inplace ? scratch : rop_out;
+  const double *rop_kn = inplace ? scratch : rop;
+  if (flow_prepare(f, r) != 0) return -1;
+  int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 2048);
+  if (waves < 1) waves = 1;
+  if (waves > f->ntasks) waves = f->ntasks;
+  unsigned *sticky = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(f->sync_dev) + f->sync_bytes);
+  const dim3 g((unsigned)waves);
+  if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
+#define FS_LOW(F, N) hipLaunchKernelGGL((k_lu_lower_flow<F, N>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe)
+  if (sa && full) FS_LOW(true, 6); else if (sa) FS_LOW(false, 6); else if (full) FS_LOW(true, 5); else FS_LOW(false, 5);
+#undef FS_LOW
+  auto debug_dump = [&](const char *what) {   // FASTS_HIP_LU_FLOW_DEBUG: wait for the sweep and show the words of a sweep that gave up
+    if (!flow_setting("FASTS_HIP_LU_FLOW_DEBUG", 0)) return;
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned> w(f->sync_bytes / sizeof(unsigned) + 4);
+    (void)hipMemcpy(w.data(), f->sync_dev, f->sync_bytes + 16, hipMemcpyDeviceToHost);
+    if (!w[FLOW_ABORT]) return;
+    fprintf(stderr, "lusgs_flow %s gave up: range %d-%d %d-%d %d-%d, %d tasks (%d pencils per plane), %d waves, counter %u; steps done per task (plane by plane):\n",
+            what, r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, f->ntasks, f->njb, waves, w[FLOW_COUNTER]);
+    for (int kk = 0; kk < nk && kk < 40; kk++) {
+      for (int jb = 0; jb < f->njb && jb < 40; jb++) fprintf(stderr, " %3u", w[FLOW_FLAGS + kk * f->njb + jb]);
+      fprintf(stderr, "\n");
+    }
+  };
+  debug_dump("lower sweep");
+  if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
+#define FS_UPP(F, N) hipLaunchKernelGGL((k_lu_upper_flow<F, N>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe)
+  if (sa && full) FS_UPP(true, 6); else if (sa) FS_UPP(false, 6); else if (full) FS_UPP(true, 5); else FS_UPP(false, 5);
+#undef FS_UPP
+  debug_dump("upper sweep");
+  if (inplace) {
+    dim3 gc((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
+    hipLaunchKernelGGL(k_copy_range, gc, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
+  }
+  return 0;
+}
+
+int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
+              const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s, bool apart,
+              FsLuFlow *flow)
+{
+  if (flow && nblocks <= 1 && !apart && flow_setting("FASTS_HIP_LU_FLOW", 1) != 0)
+    return lusgs_flow(flow, z, range, gamma, rop, rop_out, scratch, dw, coe, s);
   // units of U consecutive cells of an i-line: the recurrence of a launch has U steps, a sweep ni/U + nj + nk - 2
   // launches of (cells of the hyperplane)/64 waves.  One sweep of the zone is bound by the latency of a launch:
   // measured at 256^3, 3 Newton sub-iterations: U = 4 40.2 ms per step (twice the waves in the large hyperplanes of
