@@ -760,6 +760,17 @@ extern "C" int fs_send_add(fs_ctx *ctx, int donor_zone, int peer_tag, const int3
   return FS_OK;
 }
 
+// A sweep launch whose waves stopped waiting for each other (fasts_lusgs.hip: a defect, or a device in trouble) leaves
+// a zone half swept: reported at the next point where the host waits for the stream anyway.
+static int check_sweeps(fs_ctx *ctx, const char *who)
+{
+  for (auto &zn : ctx->zones)
+    if (zn.lu_flow && fsk_luflow_gave_up(zn.lu_flow) != 0)
+      return fail(ctx, FS_ERR_HIP, std::string(who) + ": an LU-SGS sweep launch gave up waiting for a predecessor pencil; the "
+                  "fields of the context are not to be trusted (FASTS_HIP_LU_FLOW=0 runs one launch per hyperplane)");
+  return FS_OK;
+}
+
 static int build_shell_lists(fs_ctx *ctx);
 static int local_setup(fs_ctx *ctx);
 
@@ -900,7 +911,7 @@ extern "C" int fs_download(fs_ctx *ctx, int mask)
       HIPCHK(ctx, hipMemcpyAsync(zn.rof_host, zn.rof, nb, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return FS_OK;
+  return check_sweeps(ctx, "fs_download");
 }
 
 static int level_role(int level)
@@ -1766,7 +1777,7 @@ extern "C" int fs_sync(fs_ctx *ctx)
   if (!ctx) return FS_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return FS_OK;
+  return check_sweeps(ctx, "fs_sync");
 }
 
 // Streaming rate of the device this context runs on: triad a = b + s*c over three arrays of n doubles, timed with HIP

@@ -1206,7 +1206,8 @@ int fsk_luflow_gave_up(const FsLuFlow *f)
 }
 
 // FASTS_HIP_LU_FLOW: 1 (default) one launch per sweep, 0 one launch per hyperplane.  FASTS_HIP_LU_FLOW_WAVES: waves of a
-// sweep launch.
+// sweep launch = pencils in work at a time (256^3, ms per step of 3 Newton sub-iterations: 256 waves 31.9, 512 21.0,
+// 768 20.5, 1024 21.4, 1536 24.2, 2048 24.6: more waves share the issue slots of the waves on the critical path).
 static int flow_setting(const char *name, int dflt)
 {
   const char *e = getenv(name);
@@ -1256,7 +1257,7 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gam
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
   if (flow_prepare(f, r) != 0) return -1;
-  int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 2048);
+  int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 768);
   if (waves < 1) waves = 1;
   if (waves > f->ntasks) waves = f->ntasks;
   unsigned *sticky = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(f->sync_dev) + f->sync_bytes);

@@ -287,3 +287,36 @@ def test_selective_frequency_damping_needs_the_implicit_scheme():
     t = cases.tgv((8, 8, 8), 'senseur', extra_numz=dict(SINGLE, sfd=1))
     with pytest.raises(_capi.FastsHipError, match="frequency damping"):
         FastS.warmup(t, None)
+
+
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs", [
+    ((96, 70, 52), 'senseur', 'NSLaminar', 0., None),
+    ((50, 37, 44), 'ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+    ((41, 30, 1), 'roe', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+])
+def test_sweeps_in_one_launch_equal_one_launch_per_hyperplane(n, scheme, model, perturb, bcs, monkeypatch):
+    """The LU-SGS sweeps as one launch each (pencils of 8 lines that wait for each other's step counts) against one
+    launch per hyperplane, bit for bit, on zones with many pencils in work at a time, with ragged line and pencil counts;
+    with 1, 5 and 64 waves the order in which the pencils are handed out is all that keeps a wave from waiting for
+    a pencil nobody has taken."""
+    def run(flow, waves):
+        monkeypatch.setenv('FASTS_HIP_LU_FLOW', str(flow))
+        monkeypatch.setenv('FASTS_HIP_LU_FLOW_WAVES', str(waves))
+        if len(n) == 3 and n[2] == 1:
+            t = cases.tgv2d(n[:2], scheme, model=model, extra_numz=SINGLE, bcs=bcs, perturb=perturb, time_step=0.02,
+                            temporal_scheme='implicit', extra_numb={'ss_iteration': 3, 'modulo_verif': 1})
+        else:
+            t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': 3}, bcs=bcs,
+                          temporal_scheme='implicit', time_step=0.02, perturb=perturb, modulo_verif=1)
+        (t, tc, metrics) = FastS.warmup(t, None)
+        z = Internal.getZones(t)[0]
+        for it in range(1, 4):
+            FastS._compute(t, metrics, it, None)
+        out = FastC.level_buffer(z).copy()
+        FastC.HOOK['ctx'].close()
+        return out
+    ref = run(0, 768)
+    assert np.isfinite(ref).all()
+    for waves in (768, 64, 5, 1):
+        got = run(1, waves)
+        assert np.array_equal(got, ref), "%d waves: max abs diff %g" % (waves, np.abs(got - ref).max())
