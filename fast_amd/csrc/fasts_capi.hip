@@ -426,8 +426,8 @@ extern "C" int fs_zone_add(fs_ctx *ctx, const int32_t *pint, int n_int, const do
   if (p[SLOPE] == 6 && sa)
     return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: the o3sc slope is implemented for Euler and NSLaminar");
   if (p[SFD] != 0 && p[SFD] != 1) return fail(ctx, FS_ERR_ARG, "fs_zone_add: SFD must be 0 or 1");
-  if (p[SFD] == 1 && !implicit)
-    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: selective frequency damping is implemented with the implicit scheme");
+  if (p[SFD] == 1 && !implicit && p[NSSITER] < 2)
+    return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: selective frequency damping runs after the last stage but one: it needs two stages");
   if (p[KFLUDOM] != 1 && p[KFLUDOM] != 2 && p[KFLUDOM] != 5) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: scheme must be ausmpred, senseur or roe");
   if (p[LALE] != 0 || p[EXPLOC] != 0) return fail(ctx, FS_ERR_UNSUPPORTED, "fs_zone_add: moving mesh / local explicit time stepping are not implemented");
   if (p[DTLOC] != 0 && p[DTLOC] != 1)
@@ -960,7 +960,8 @@ static int build_shell_lists(fs_ctx *ctx)
     for (auto &j : ctx->joins) if (j.donor_zone < 0 && j.rcv_zone == (int)nz) zn.has_recvs = true;
     // implicit zones, roe + walls and the local time step run their stage in one piece (later kernels of the stage read
     // the whole balance); so do Spalart-Allmaras zones on Cartesian meshes (their stage kernel takes no tile list)
-    if (ctx->implicit || (z.iflow == 3 && z.ityp != 0) || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1 || z.slope == 6) continue;
+    if (ctx->implicit || (z.iflow == 3 && z.ityp != 0) || !zn.roe_walls.empty() || zn.pint[DTLOC] == 1 || z.slope == 6 ||
+        zn.pint[SFD] == 1) continue;   // (a filtered zone changes its cells after the stage kernel)
     zn.z.split = zn.has_sends ? 1 : 0;
     // tiles of the Cartesian stage kernel, patches (owned cells) of the curvilinear one
     const FsTiling t = z.ityp == 0 ? fsk_stage_full_tiling(zn.z) : fsk_stage_dma_tiling(zn.z);
@@ -1343,6 +1344,10 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
     const int sfd_pull = nitrun >= zn.pint[SFD_INIT_IT];
     if (sfd && slot)
       fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, zn.coe, ctx->stream);
+    // the explicit loop runs the same condition (no verification slot: nitcfg = nssiter - 1): the state is filtered
+    // after the last stage but one, before its joins and BCs
+    if (sfd && !ctx->implicit && nstep == z.nssiter - 1)
+      fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, dtloc ? zn.coe : nullptr, ctx->stream);
     if (ctx->implicit && !slot) {   // LU-SGS solve of the Newton system, new iterate into P1 (lhs.cpp:53-68,135-161)
       if (!zn.rhs_face.empty()) {   // wall faces: BCs on the residual, two ordered passes, then edges/corners
         fsk_bc_windows(z, (int)zn.rhs_face.size(), zn.rhs_face_dev, bc_kinds(zn.rhs_face), zn.rhs_max_cells, zn.drodm, ctx->stream);

@@ -888,7 +888,9 @@ __global__ void __launch_bounds__(256) k_sfd(FsZone z, double chi, double delta,
   if (z.ityp == 0)
     vol = z.vol[(long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.mincj + (long long)(k + z.ifick - 1) * z.minck];
   const double cd = chi * delta;
-  const double xsi = exp(-(chi + 1. / delta) * coe1[l] * vol);
+  // dt / vol: the coefficient array of the implicit scheme or of the local time step, else the global time step
+  const double c1 = coe1 ? coe1[l] : (z.ityp == 0 ? z.dt / vol : z.coe);
+  const double xsi = exp(-(chi + 1. / delta) * c1 * vol);
   for (int e = 0; e < z.neq; e++) {
     const long long m = l + e * z.nd;
     const double f = 1. / (1. + cd) * ((1. - xsi) * rop[m] + (cd + xsi) * rof[m]);

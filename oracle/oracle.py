@@ -126,14 +126,19 @@ class OracleZone:
         n = int(self.pint[NSSITER])
         return n - 1 if self.implicit else n
 
-    def sfd(self):
-        """Selective frequency damping of the level just written (once per implicit step)."""
+    def sfd(self, level=None):
+        """Selective frequency damping of the level just written (once per time step)."""
         if int(self.pint[62]) != 1:
             return
         if self.rof is None:
             self.rof = np.zeros_like(self.ro)
-        lib().fo_sfd(_p(self.pint), _p(self.preal), ctypes.c_int(self.nitrun), _p(self.ro_p1), _p(self.rof), _p(self.coe),
-                     _p(self.vol))
+        lib().fo_sfd(_p(self.pint), _p(self.preal), ctypes.c_int(self.nitrun), _p(self.ro_p1 if level is None else level),
+                     _p(self.rof), _p(self.coe), _p(self.vol))
+
+    def sfd_stage(self):
+        """Sub-iteration after which sfd runs on a step without a verification slot (lhs.cpp:181-185: nitcfg = nssiter - 1;
+        the explicit loop runs the same condition, so an explicit step is filtered after its last stage but one)."""
+        return int(self.pint[NSSITER]) - 1
 
     def step(self):
         self.nitrun += 1
@@ -144,6 +149,13 @@ class OracleZone:
                     self.sfd()      # before the joins and BCs of the slot (lhs.cpp:181-185)
                 self.bcs(nstep)
             self.verification_slot()
+            return self.rotate()
+        if int(self.pint[62]) == 1:     # filtered between two stages: the split form
+            for nstep in range(1, int(self.pint[NSSITER]) + 1):
+                self.stage(nstep)
+                if nstep == self.sfd_stage():
+                    self.sfd(self.roles(nstep)[1])
+                self.bcs(nstep)
             return self.rotate()
         rc = lib().fo_step_mt(_p(self.pint), _p(self.preal), _p(self.ro), _p(self.ro_p1), _p(self.drodm),
                               _p(self.coe), _p(self.xmut), _p(self.wig), _p(self.ti), _p(self.tj),
@@ -293,6 +305,8 @@ class OracleSolver:
                 z.stage(nstep)
                 if z.implicit and nstep == z.nsub() and not z.verif:
                     z.sfd()
+                if not z.implicit and nstep == z.sfd_stage():
+                    z.sfd(z.roles(nstep)[1])
             self.transfers([z.roles(nstep)[1] for z in self.zones])
             for z in self.zones:
                 z.bcs(nstep)

@@ -651,13 +651,14 @@ class RefSolver:
             out.append(np.array([enst.value, tke.value, cpt.value]))
         return out
 
-    def _sfd(self, zn, nitrun):
+    def _sfd(self, zn, nitrun, level=None):
         """sfd_ on the interior of the level the sub-iteration has written (lhs.cpp:184)."""
         if int(zn.pint[62]) != 1:
             return
         if getattr(zn, 'rof', None) is None:
             zn.rof = np.zeros_like(zn.ro)
-        lib().sfd_(_p(zn.pint), _p(zn.preal), _i(nitrun), _p(zn.ind_dm), _p(zn.ro_p1), _p(zn.rof), _p(zn.coe), _p(zn.vol))
+        lib().sfd_(_p(zn.pint), _p(zn.preal), _i(nitrun), _p(zn.ind_dm), _p(zn.ro_p1 if level is None else level), _p(zn.rof),
+                   _p(zn.coe), _p(zn.vol))
 
     def step_implicit(self, nitrun):
         """One implicit time step: nssiter-1 Newton sub-iterations (the last slot of nssiter is the
@@ -874,6 +875,8 @@ class RefSolver:
                 self._navier_stokes(nd, zn, nitrun, nstep, ssiter)
                 if nstep == 1:
                     zn.stage1_rhs = zn.drodm.copy()
+                if nstep == nssiter - 1:      # lhs.cpp:181-185: the explicit loop runs the same condition (no verification slot)
+                    self._sfd(zn, nitrun, c)
                 cl.append(c)
             self._transfers(cl)
             for nd, zn in enumerate(self.zones):

@@ -282,11 +282,35 @@ def test_selective_frequency_damping(n, scheme, model, bcs, perturb, init, modul
     assert rel_err(rof, oz.rof, int(pint[41]), neq=neq).max() < 1e-12
 
 
-def test_selective_frequency_damping_needs_the_implicit_scheme():
-    from fast_amd import _capi
-    t = cases.tgv((8, 8, 8), 'senseur', extra_numz=dict(SINGLE, sfd=1))
-    with pytest.raises(_capi.FastsHipError, match="frequency damping"):
-        FastS.warmup(t, None)
+@pytest.mark.parametrize("n,scheme,model,bcs,perturb,init,rk", [
+    ((12, 10, 9), 'senseur', 'NSLaminar', None, 0., 1, 3),
+    ((10, 9, 8), 'ausmpred', 'NSLaminar', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 3, 3),
+    ((40, 11, 9), 'roe', 'Euler', None, 0., 2, 2),
+    ((72, 20, 16), 'senseur', 'NSLaminar', None, 0., 1, 3),
+])
+def test_selective_frequency_damping_explicit_scheme(n, scheme, model, bcs, perturb, init, rk):
+    """The explicit loop of the reference runs the condition of lhs.cpp:181-185 too (no verification slot: nitcfg =
+    nssiter - 1): the state is filtered after the last stage but one, before its joins and BCs.  The restatement is
+    bit-exact against the compiled reference (test_oracle_vs_ref.py); device exponential: 1e-12."""
+    extra = dict(SINGLE, sfd=1, sfd_chi=0.5, sfd_delta=0.3, sfd_init_iter=init)
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, time_step=0.02, perturb=perturb,
+                  extra_numb={'rk': rk} if rk != 3 else None)
+    (t, tc, metrics) = FastS.warmup(t, None)
+    z = Internal.getZones(t)[0]
+    pint, preal, _ = zone_arrays(z)
+    assert int(pint[62]) == 1 and int(pint[58]) == rk
+    oz = O.OracleZone(pint, preal, FastC.level_buffer(z).copy(), metrics[0][0])
+    oz.fill_ghostcells()
+    for it in range(1, 6):
+        FastS._compute(t, metrics, it, None)
+        oz.step()
+        got = FastC.level_buffer(z)
+        e = rel_err(got, oz.ro, int(pint[41]))
+        assert e.max() < 1e-12, "step %d: rel err %s" % (it, e)
+    FastS.sync_to_host(t)
+    rof = FastC.level_buffer(z, '_f')
+    assert np.abs(rof).max() > 0.1
+    assert rel_err(rof, oz.rof, int(pint[41])).max() < 1e-12
 
 
 @pytest.mark.parametrize("n,scheme,model,perturb,bcs", [

@@ -610,6 +610,29 @@ def test_selective_frequency_damping_bit_exact(n, scheme, model, bcs, perturb, i
     assert np.abs(s0.zones[0].ro - so.zones[0].ro).max() > 1e-6
 
 
+@pytest.mark.parametrize("n,scheme,model,bcs,perturb,init,rk", [
+    ((12, 10, 9), 'senseur', 'NSLaminar', None, 0., 1, 3),
+    ((10, 9, 8), 'ausmpred', 'NSLaminar', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 3, 3),
+    ((10, 9, 8), 'roe', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 2, 3),
+    ((14, 9, 8), 'roe', 'Euler', None, 0., 2, 2),
+])
+def test_selective_frequency_damping_explicit_bit_exact(n, scheme, model, bcs, perturb, init, rk):
+    """The explicit loop runs the condition of lhs.cpp:181-185 with no verification slot: sfd_ after the last stage but
+    one (nitcfg = nssiter - 1), on the level that stage has written, before its joins and BCs."""
+    extra = {'cache_blocking_I': 100000, 'cache_blocking_J': 100000, 'cache_blocking_K': 100000,
+             'sfd': 1, 'sfd_chi': 0.5, 'sfd_delta': 0.3, 'sfd_init_iter': init}
+    t = cases.tgv(n, scheme, model=model, extra_numz=extra, bcs=bcs, perturb=perturb, time_step=0.02,
+                  extra_numb={'rk': rk} if rk != 3 else None)
+    so, sr = _pair(t)
+    assert int(so.zones[0].pint[62]) == 1 and int(so.zones[0].pint[58]) == rk
+    so.fill_ghostcells(); sr.fill_ghostcells('ro')
+    for it in range(1, 6):
+        so.step(); sr.step(it)
+        assert np.array_equal(so.zones[0].ro, sr.zones[0].ro), "step %d" % it
+        assert np.array_equal(so.zones[0].rof, sr.zones[0].rof), "filtered state, step %d" % it
+    assert np.abs(so.zones[0].rof).max() > 0.1
+
+
 @pytest.mark.parametrize("dim,n,scheme,model,bcs,perturb,nb_relax,lu_match", [
     (3, (10, 9, 8), 'senseur', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0., 2, 0),
     (3, (10, 9, 8), 'ausmpred', 'NSTurbulent', {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, 0.15, 2, 1),
