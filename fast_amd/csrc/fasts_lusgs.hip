@@ -810,16 +810,17 @@ FS_DEV bool flow_wait(const unsigned *fa, unsigned na, const unsigned *fb, unsig
   return alive;
 }
 
-template <bool FULL, int NE>
+template <bool FULL, int NE, int U = 8>
 __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRange r, int njb,
                                                       const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
                                                       unsigned *sticky, const double *__restrict__ rop, double *dw,
                                                       const double *__restrict__ coe)
 {
-  const int lane = threadIdx.x, jj = lane >> 3, m = lane & 7;
+  constexpr int LPP = 64 / U;                       // lines of a pencil
+  const int lane = threadIdx.x, jj = lane / U, m = lane % U;
   unsigned *flags = sync + FLOW_FLAGS;
   const long long nd = z.nd;
-  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + 7) >> 3, nsteps = nchunk + 7;
+  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + U - 1) / U, nsteps = nchunk + LPP - 1;
   const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
   // Every lane adds one to the counter (the compiler turns that into one add of 64 by one lane): a task index that
   // depended on which lanes are active at this point would not survive the restructuring of the loops around it.
@@ -828,7 +829,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
                       __hip_atomic_fetch_add(sync + FLOW_COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6);
     if (n >= ntasks) break;
     const FlowTask t = tasks[n];
-    const int j = r.j0 + 8 * t.jb + jj, k = t.k;
+    const int j = r.j0 + LPP * t.jb + jj, k = t.k;
     const bool line_ok = j <= r.j1;
     const bool has_j = j > r.j0, has_k = k > r.k0;
     const unsigned *fk = flags + t.fid - njb, *fj = flags + t.fid - 1;
@@ -837,7 +838,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
     const long long dj_ = has_j ? z.incj : 0, dk_ = has_k ? z.inck : 0;   // a cell without a neighbour reads itself, and drops the term
     // cell of this lane at step s: lanes without one read the first cell of the range and store nothing
     auto geom = [&](int s, bool &active, bool &has_prev, long long &l, long long &lt) {
-      const int cn = s - jj, di = cn * 8;
+      const int cn = s - jj, di = cn * U;
       active = line_ok && cn >= 0 && cn < nchunk && di + m < ni;
       has_prev = active && di + m > 0;
       l = active ? lrow + di : lsafe;
@@ -864,7 +865,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
       const long long lj = l - dj_, lk = l - dk_, li = (has_prev && m == 0) ? l - 1 : l;
       // the plane before has finished this step; the pencil before has finished the chunk its last line hands over
       const unsigned need_k = (k > r.k0 && s < nsteps) ? (unsigned)(s + 1) : 0u;
-      const unsigned need_j = (t.jb > 0 && s < nchunk) ? (unsigned)(s + 8) : 0u;
+      const unsigned need_j = (t.jb > 0 && s < nchunk) ? (unsigned)(s + LPP) : 0u;
       FLOWSTAMP(0)
       alive = flow_wait(fk, need_k, fj, need_j, mine, (unsigned)s, sync, sticky);
       FLOWSTAMP(1)
@@ -913,7 +914,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
         cell(pin);
       }
 #pragma unroll
-      for (int st = 1; st < 8; st++) {
+      for (int st = 1; st < U; st++) {
         double pin[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) pin[e] = lane_prev(P[e]);
@@ -932,23 +933,24 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
 // Upper sweep and Newton update: the pencils in the opposite order, the lines of a pencil downwards, the chunks of a
 // line from the last to the first.  The state of the k + 1 neighbour is the new one when the update is in place
 // (rop_kn = the array the new iterate is built in): handed over like the increments.
-template <bool FULL, int NE>
+template <bool FULL, int NE, int U = 8>
 __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, LuRange r, int njb,
                                                       const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
                                                       unsigned *sticky, const double *__restrict__ rop, const double *rop_kn,
                                                       double *rop_new, double *dw, const double *__restrict__ coe)
 {
-  const int lane = threadIdx.x, jj = lane >> 3, m = lane & 7, q7 = 7 - jj;
+  constexpr int LPP = 64 / U;
+  const int lane = threadIdx.x, jj = lane / U, m = lane % U, q7 = LPP - 1 - jj;
   unsigned *flags = sync + FLOW_FLAGS;
   const long long nd = z.nd;
-  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + 7) >> 3, nsteps = nchunk + 7;
+  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + U - 1) / U, nsteps = nchunk + LPP - 1;
   const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
   for (bool alive = true; alive;) {
     const int n = (int)(__builtin_amdgcn_readfirstlane(
                       __hip_atomic_fetch_add(sync + FLOW_COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6);
     if (n >= ntasks) break;
     const FlowTask t = tasks[ntasks - 1 - n];
-    const int j = r.j0 + 8 * t.jb + jj, k = t.k;
+    const int j = r.j0 + LPP * t.jb + jj, k = t.k;
     const bool line_ok = j <= r.j1;
     const bool has_j = j < r.j1, has_k = k < r.k1;
     const unsigned *fk = flags + t.fid + njb, *fj = flags + t.fid + 1;
@@ -956,7 +958,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, LuRan
     const long long lrow = lcell(z, r.i0, line_ok ? j : r.j0, k) + m, ltrow = FULL ? lmtr(z, r.i0, line_ok ? j : r.j0, k) + m : 0;
     const long long dj_ = has_j ? z.incj : 0, dk_ = has_k ? z.inck : 0;
     auto geom = [&](int s, bool &active, bool &has_next, long long &l, long long &lt) {
-      const int cn = nchunk - 1 - (s - q7), di = cn * 8;
+      const int cn = nchunk - 1 - (s - q7), di = cn * U;
       active = line_ok && cn >= 0 && cn < nchunk && di + m < ni;
       has_next = active && di + m < ni - 1;
       l = active ? lrow + di : lsafe;
@@ -979,10 +981,10 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, LuRan
     for (int s = 0; s <= nsteps && alive; s++) {   // pass nsteps publishes the last count only
       bool active, has_next; long long l, lt;
       geom(s, active, has_next, l, lt);
-      const bool last_of_unit = m == 7 || !has_next;
+      const bool last_of_unit = m == U - 1 || !has_next;
       const long long lj = l + dj_, lk = l + dk_, li = (has_next && last_of_unit) ? l + 1 : l;
       const unsigned need_k = (k < r.k1 && s < nsteps) ? (unsigned)(s + 1) : 0u;
-      const unsigned need_j = (t.jb < njb - 1 && s < nchunk) ? (unsigned)(s + 8) : 0u;
+      const unsigned need_j = (t.jb < njb - 1 && s < nchunk) ? (unsigned)(s + LPP) : 0u;
       alive = flow_wait(fk, need_k, fj, need_j, mine, (unsigned)s, sync, sticky);
       if (!alive || s == nsteps) continue;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1018,14 +1020,14 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, LuRan
         for (int e = 0; e < 5; e++) { P[e] = A[e] * DG; }
         if (NE == 6) P[NE - 1] = A[NE - 1] / C6;
       };
-      if (m == 7 && active) {
+      if (m == U - 1 && active) {
         double pin[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) pin[e] = P[e];
         cell(pin);
       }
 #pragma unroll
-      for (int st = 6; st >= 0; st--) {
+      for (int st = U - 2; st >= 0; st--) {
         double pin[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) pin[e] = lane_next(P[e]);
@@ -1183,7 +1185,7 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
 
 // Task table and synchronisation words of the dataflow sweeps of one zone (built at the first solve of a range)
 struct FsLuFlow {
-  int key[6] = {0, 0, 0, 0, 0, 0};
+  int key[7] = {0, 0, 0, 0, 0, 0, 0};
   int ntasks = 0, njb = 0;
   FlowTask *tasks_dev = nullptr;
   unsigned *sync_dev = nullptr;     // [counter, abort, ..., one progress word per task] zeroed before every sweep, then the
@@ -1214,18 +1216,19 @@ static int flow_setting(const char *name, int dflt)
   return e ? atoi(e) : dflt;
 }
 
-static int flow_prepare(FsLuFlow *f, const LuRange &r)
+static int flow_prepare(FsLuFlow *f, const LuRange &r, int lpp)
 {
-  const int key[6] = {r.i0, r.i1, r.j0, r.j1, r.k0, r.k1};
+  const int key[7] = {r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, lpp};
   if (f->tasks_dev && memcmp(key, f->key, sizeof(key)) == 0) return 0;
   const int nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
-  const int njb = (nj + 7) / 8, ntasks = njb * nk;
-  // order of the first possible step: pencil jb starts 8 steps after pencil jb - 1, plane k one step after plane k - 1
+  const int njb = (nj + lpp - 1) / lpp, ntasks = njb * nk;
+  // order of the first possible step: pencil jb starts as many steps after pencil jb - 1 as a pencil has lines, plane
+  // k one step after plane k - 1
   std::vector<FlowTask> tasks;
   tasks.reserve((size_t)ntasks);
-  for (int T = 0; T <= 8 * (njb - 1) + nk - 1; T++)
+  for (int T = 0; T <= lpp * (njb - 1) + nk - 1; T++)
     for (int jb = 0; jb < njb; jb++) {
-      const int kk = T - 8 * jb;
+      const int kk = T - lpp * jb;
       if (kk < 0 || kk >= nk) continue;
       tasks.push_back({jb, r.k0 + kk, kk * njb + jb, 0});
     }
@@ -1256,14 +1259,21 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gam
   if (inplace && !scratch) return -1;
   double *rop_new = inplace ? scratch : rop_out;
   const double *rop_kn = inplace ? scratch : rop;
-  if (flow_prepare(f, r) != 0) return -1;
+  // cells of a unit: 8 lines x 8 cells, or 16 x 4 (FASTS_HIP_LU_FLOW_UNIT=4: half the recurrence per step, 6 % more steps;
+  // measured slower, 256^3: 23.7 against 20.5 ms per step -- twice the hand-overs and half-used 64-byte segments)
+  const int unit = flow_setting("FASTS_HIP_LU_FLOW_UNIT", 8) == 4 ? 4 : 8;
+  if (flow_prepare(f, r, 64 / unit) != 0) return -1;
   int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 768);
   if (waves < 1) waves = 1;
   if (waves > f->ntasks) waves = f->ntasks;
   unsigned *sticky = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(f->sync_dev) + f->sync_bytes);
   const dim3 g((unsigned)waves);
   if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
-#define FS_LOW(F, N) hipLaunchKernelGGL((k_lu_lower_flow<F, N>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe)
+#define FS_LOW(F, N)                                                                                                         \
+  do {                                                                                                                       \
+    if (unit == 4) hipLaunchKernelGGL((k_lu_lower_flow<F, N, 4>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
+    else hipLaunchKernelGGL((k_lu_lower_flow<F, N, 8>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
+  } while (0)
   if (sa && full) FS_LOW(true, 6); else if (sa) FS_LOW(false, 6); else if (full) FS_LOW(true, 5); else FS_LOW(false, 5);
 #undef FS_LOW
   auto debug_dump = [&](const char *what) {   // FASTS_HIP_LU_FLOW_DEBUG: wait for the sweep and show the words of a sweep that gave up
@@ -1281,7 +1291,11 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gam
   };
   debug_dump("lower sweep");
   if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
-#define FS_UPP(F, N) hipLaunchKernelGGL((k_lu_upper_flow<F, N>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe)
+#define FS_UPP(F, N)                                                                                                         \
+  do {                                                                                                                       \
+    if (unit == 4) hipLaunchKernelGGL((k_lu_upper_flow<F, N, 4>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
+    else hipLaunchKernelGGL((k_lu_upper_flow<F, N, 8>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
+  } while (0)
   if (sa && full) FS_UPP(true, 6); else if (sa) FS_UPP(false, 6); else if (full) FS_UPP(true, 5); else FS_UPP(false, 5);
 #undef FS_UPP
   debug_dump("upper sweep");
