@@ -88,7 +88,7 @@ extern "C" void fs_destroy(fs_ctx *ctx)
     (void)hipFree(zn.drodm); (void)hipFree(zn.xmut); (void)hipFree(zn.wig);
     (void)hipFree(zn.res_part); (void)hipFree(zn.res_out); (void)hipFree(zn.bc_dev); (void)hipFree(zn.bc_data_dev);
     (void)hipFree(zn.blk_res); (void)hipFree(zn.wsc); (void)hipFree(zn.wflux);
-    for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); (void)hipFree(bb.lu_dev); }
+    for (auto &bb : zn.box_bcs) { (void)hipFree(bb.dev); (void)hipFree(bb.tiles_dev); (void)hipFree(bb.lu_dev); fsk_luflow_free(bb.flow); }
     (void)hipFree(zn.shell_dev); (void)hipFree(zn.inner_dev); (void)hipFree(zn.mtr_dev);
     (void)hipFree(zn.coe); (void)hipFree(zn.scratch); (void)hipFree(zn.ssor_work); (void)hipFree(zn.lu_blocks_dev); (void)hipFree(zn.dist); (void)hipFree(zn.rof); (void)hipFree(zn.rhs_face_dev); (void)hipFree(zn.rhs_bc_dev);
     fsk_luflow_free(zn.lu_flow);
@@ -764,10 +764,13 @@ extern "C" int fs_send_add(fs_ctx *ctx, int donor_zone, int peer_tag, const int3
 // a zone half swept: reported at the next point where the host waits for the stream anyway.
 static int check_sweeps(fs_ctx *ctx, const char *who)
 {
-  for (auto &zn : ctx->zones)
-    if (zn.lu_flow && fsk_luflow_gave_up(zn.lu_flow) != 0)
+  for (auto &zn : ctx->zones) {
+    bool gave_up = zn.lu_flow && fsk_luflow_gave_up(zn.lu_flow) != 0;
+    for (auto &bb : zn.box_bcs) gave_up = gave_up || (bb.flow && fsk_luflow_gave_up(bb.flow) != 0);
+    if (gave_up)
       return fail(ctx, FS_ERR_HIP, std::string(who) + ": an LU-SGS sweep launch gave up waiting for a predecessor pencil; the "
                   "fields of the context are not to be trusted (FASTS_HIP_LU_FLOW=0 runs one launch per hyperplane)");
+  }
   return FS_OK;
 }
 
@@ -1379,9 +1382,10 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       if (ctx->local_newton) {
         // one sweep pair over the boxes, side by side like the blocks of the reference's threads: neighbour terms across
         // the borders of a box are left out (LU/invlu_l.for:90-215), the Newton update touches the boxes alone
-        const Zone::BoxBcs &bb = zn.box_bcs[(size_t)nstep - 1];
+        Zone::BoxBcs &bb = zn.box_bcs[(size_t)nstep - 1];
         lrc = fsk_lusgs(z, nbox > 1 ? zn.lu : bb.lu_ranges.data(), nbox, bb.lu_ranges.data(), bb.lu_dev, zn.preal[GAMMA],
-                        zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, true);
+                        zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, true,
+                        bb.flow ? bb.flow : (bb.flow = fsk_luflow_new()));
       } else {
       const int sdm[6] = {1, z.iv, 1, z.jv, 1, z.kv};
       // lu_match = 1: the sweeps of invlu_overlap_{l,u}.for (with nb_relax > 1, 5 equations: the LU-SSOR sweeps whatever

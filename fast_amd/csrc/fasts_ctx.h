@@ -70,6 +70,7 @@ struct Zone {
     std::vector<int> tile_off, tile_cnt;
     // LU ranges of the boxes (a wall face takes its ghost layer), host and device
     std::vector<int> lu_ranges; int *lu_dev = nullptr; size_t lu_cap = 0;
+    FsLuFlow *flow = nullptr;   // one-launch-per-sweep tables of these ranges (rebuilt when the boxes change)
   };
   std::vector<BoxBcs> box_bcs;
   std::vector<double> res_host;   // 12 norms per slot of the last verification step, summed over the blocks

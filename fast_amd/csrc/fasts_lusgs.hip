@@ -768,7 +768,8 @@ __global__ void __launch_bounds__(64) k_ssor_upper_wave(FsZone z, LuConst c, LuR
 // reads increments and new states by sc1 loads only (they bypass the L1).  Everything else the sweeps read is written
 // by no wave of the launch.
 // ------------------------------------------------------------------------------------------------------
-struct FlowTask { int jb, k, fid, pad; };    // group of 8 lines, k-plane, index of the progress word
+struct FlowTask { int jb, k, fid, b; };      // group of lines, k-plane, index of the progress word, range swept
+struct FlowBox { LuRange r; int njb, pad; }; // a range swept on its own (the zone, a thread block, a sub-zone box) and its pencils per plane
 
 FS_DEV double ld_sc1(const double *p)
 {
@@ -811,7 +812,7 @@ FS_DEV bool flow_wait(const unsigned *fa, unsigned na, const unsigned *fb, unsig
 }
 
 template <bool FULL, int NE, int U = 8>
-__global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRange r, int njb,
+__global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const FlowBox *__restrict__ boxes,
                                                       const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
                                                       unsigned *sticky, const double *__restrict__ rop, double *dw,
                                                       const double *__restrict__ coe)
@@ -820,8 +821,6 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
   const int lane = threadIdx.x, jj = lane / U, m = lane % U;
   unsigned *flags = sync + FLOW_FLAGS;
   const long long nd = z.nd;
-  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + U - 1) / U, nsteps = nchunk + LPP - 1;
-  const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
   // Every lane adds one to the counter (the compiler turns that into one add of 64 by one lane): a task index that
   // depended on which lanes are active at this point would not survive the restructuring of the loops around it.
   for (bool alive = true; alive;) {
@@ -829,6 +828,10 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
                       __hip_atomic_fetch_add(sync + FLOW_COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6);
     if (n >= ntasks) break;
     const FlowTask t = tasks[n];
+    const LuRange r = boxes[t.b].r;
+    const int njb = boxes[t.b].njb;
+    const int ni = r.i1 - r.i0 + 1, nchunk = (ni + U - 1) / U, nsteps = nchunk + LPP - 1;
+    const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
     const int j = r.j0 + LPP * t.jb + jj, k = t.k;
     const bool line_ok = j <= r.j1;
     const bool has_j = j > r.j0, has_k = k > r.k0;
@@ -934,7 +937,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, LuRan
 // line from the last to the first.  The state of the k + 1 neighbour is the new one when the update is in place
 // (rop_kn = the array the new iterate is built in): handed over like the increments.
 template <bool FULL, int NE, int U = 8>
-__global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, LuRange r, int njb,
+__global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const FlowBox *__restrict__ boxes,
                                                       const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
                                                       unsigned *sticky, const double *__restrict__ rop, const double *rop_kn,
                                                       double *rop_new, double *dw, const double *__restrict__ coe)
@@ -943,13 +946,15 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, LuRan
   const int lane = threadIdx.x, jj = lane / U, m = lane % U, q7 = LPP - 1 - jj;
   unsigned *flags = sync + FLOW_FLAGS;
   const long long nd = z.nd;
-  const int ni = r.i1 - r.i0 + 1, nchunk = (ni + U - 1) / U, nsteps = nchunk + LPP - 1;
-  const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
   for (bool alive = true; alive;) {
     const int n = (int)(__builtin_amdgcn_readfirstlane(
                       __hip_atomic_fetch_add(sync + FLOW_COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6);
     if (n >= ntasks) break;
     const FlowTask t = tasks[ntasks - 1 - n];
+    const LuRange r = boxes[t.b].r;
+    const int njb = boxes[t.b].njb;
+    const int ni = r.i1 - r.i0 + 1, nchunk = (ni + U - 1) / U, nsteps = nchunk + LPP - 1;
+    const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
     const int j = r.j0 + LPP * t.jb + jj, k = t.k;
     const bool line_ok = j <= r.j1;
     const bool has_j = j < r.j1, has_k = k < r.k1;
@@ -1183,11 +1188,12 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
   return 0;
 }
 
-// Task table and synchronisation words of the dataflow sweeps of one zone (built at the first solve of a range)
+// Task table and synchronisation words of the dataflow sweeps of one zone (built at the first solve of a set of ranges)
 struct FsLuFlow {
-  int key[7] = {0, 0, 0, 0, 0, 0, 0};
-  int ntasks = 0, njb = 0;
+  std::vector<int> key;             // the ranges the tables were built for, and the lines of a pencil
+  int ntasks = 0;
   FlowTask *tasks_dev = nullptr;
+  FlowBox *boxes_dev = nullptr;
   unsigned *sync_dev = nullptr;     // [counter, abort, ..., one progress word per task] zeroed before every sweep, then the
   size_t sync_bytes = 0;            // word that stays set once a wave has given up
 };
@@ -1196,7 +1202,7 @@ FsLuFlow *fsk_luflow_new() { return new FsLuFlow; }
 void fsk_luflow_free(FsLuFlow *f)
 {
   if (!f) return;
-  (void)hipFree(f->tasks_dev); (void)hipFree(f->sync_dev);
+  (void)hipFree(f->tasks_dev); (void)hipFree(f->boxes_dev); (void)hipFree(f->sync_dev);
   delete f;
 }
 int fsk_luflow_gave_up(const FsLuFlow *f)
@@ -1216,44 +1222,63 @@ static int flow_setting(const char *name, int dflt)
   return e ? atoi(e) : dflt;
 }
 
-static int flow_prepare(FsLuFlow *f, const LuRange &r, int lpp)
+// nb ranges swept independently of each other (6 integers each).  The tables are rebuilt when the ranges change; the
+// frees wait for the device, so a sweep that still reads the old tables has ended by then.
+static int flow_prepare(FsLuFlow *f, int nb, const int *ranges, int lpp)
 {
-  const int key[7] = {r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, lpp};
-  if (f->tasks_dev && memcmp(key, f->key, sizeof(key)) == 0) return 0;
-  const int nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
-  const int njb = (nj + lpp - 1) / lpp, ntasks = njb * nk;
-  // order of the first possible step: pencil jb starts as many steps after pencil jb - 1 as a pencil has lines, plane
-  // k one step after plane k - 1
+  std::vector<int> key(ranges, ranges + 6 * (size_t)nb);
+  key.push_back(lpp);
+  if (f->tasks_dev && key == f->key) return 0;
+  // order of the first possible step: pencil jb of a range starts as many steps after pencil jb - 1 as a pencil has
+  // lines, plane k one step after plane k - 1; the ranges side by side
+  std::vector<FlowBox> boxes((size_t)nb);
+  std::vector<int> fid0((size_t)nb);
+  int ntasks = 0, tmax = 0;
+  for (int b = 0; b < nb; b++) {
+    const int *q = ranges + 6 * b;
+    const int nj = q[3] - q[2] + 1, nk = q[5] - q[4] + 1;
+    if (q[1] < q[0] || nj < 1 || nk < 1) return -1;
+    boxes[b].r = {q[0], q[1], q[2], q[3], q[4], q[5]};
+    boxes[b].njb = (nj + lpp - 1) / lpp; boxes[b].pad = 0;
+    fid0[b] = ntasks;
+    ntasks += boxes[b].njb * nk;
+    const int t = lpp * (boxes[b].njb - 1) + nk - 1;
+    if (t > tmax) tmax = t;
+  }
   std::vector<FlowTask> tasks;
   tasks.reserve((size_t)ntasks);
-  for (int T = 0; T <= lpp * (njb - 1) + nk - 1; T++)
-    for (int jb = 0; jb < njb; jb++) {
-      const int kk = T - lpp * jb;
-      if (kk < 0 || kk >= nk) continue;
-      tasks.push_back({jb, r.k0 + kk, kk * njb + jb, 0});
+  for (int T = 0; T <= tmax; T++)
+    for (int b = 0; b < nb; b++) {
+      const int njb = boxes[b].njb, nk = boxes[b].r.k1 - boxes[b].r.k0 + 1;
+      for (int jb = 0; jb < njb; jb++) {
+        const int kk = T - lpp * jb;
+        if (kk < 0 || kk >= nk) continue;
+        tasks.push_back({jb, boxes[b].r.k0 + kk, fid0[b] + kk * njb + jb, b});
+      }
     }
   if ((int)tasks.size() != ntasks) return -1;
-  (void)hipFree(f->tasks_dev); (void)hipFree(f->sync_dev);
-  f->tasks_dev = nullptr; f->sync_dev = nullptr;
+  (void)hipFree(f->tasks_dev); (void)hipFree(f->boxes_dev); (void)hipFree(f->sync_dev);
+  f->tasks_dev = nullptr; f->boxes_dev = nullptr; f->sync_dev = nullptr;
   f->sync_bytes = (((size_t)FLOW_FLAGS + (size_t)ntasks) * sizeof(unsigned) + 15) / 16 * 16;
   if (hipMalloc(&f->tasks_dev, sizeof(FlowTask) * (size_t)ntasks) != hipSuccess) return -1;
+  if (hipMalloc(&f->boxes_dev, sizeof(FlowBox) * (size_t)nb) != hipSuccess) return -1;
   if (hipMalloc(&f->sync_dev, f->sync_bytes + 16) != hipSuccess) return -1;
   if (hipMemcpy(f->tasks_dev, tasks.data(), sizeof(FlowTask) * (size_t)ntasks, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (hipMemcpy(f->boxes_dev, boxes.data(), sizeof(FlowBox) * (size_t)nb, hipMemcpyHostToDevice) != hipSuccess) return -1;
   if (hipMemset(f->sync_dev, 0, f->sync_bytes + 16) != hipSuccess) return -1;
-  memcpy(f->key, key, sizeof(key));
-  f->ntasks = ntasks; f->njb = njb;
+  f->key = key;
+  f->ntasks = ntasks;
   return 0;
 }
 
-static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gamma, const double *rop, double *rop_out,
+// nb ranges (the range of the zone, or the blocks / boxes swept independently of each other); copy back of an in-place
+// update: the ranges themselves
+static int lusgs_flow(FsLuFlow *f, const FsZone &z, int nb, const int *ranges, double gamma, const double *rop, double *rop_out,
                       double *scratch, double *dw, const double *coe, hipStream_t s)
 {
   LuConst c;
   c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
   c.cv = z.cv; c.cvinv = 1. / z.cv; c.cvinv2 = 0.5 * c.cvinv;
-  LuRange r = {range[0], range[1], range[2], range[3], range[4], range[5]};
-  const int ni = r.i1 - r.i0 + 1, nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
-  if (ni < 1 || nj < 1 || nk < 1) return -1;
   const bool full = z.ityp == 0, sa = z.neq == 6;
   const bool inplace = rop_out == rop;
   if (inplace && !scratch) return -1;
@@ -1262,7 +1287,7 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gam
   // cells of a unit: 8 lines x 8 cells, or 16 x 4 (FASTS_HIP_LU_FLOW_UNIT=4: half the recurrence per step, 6 % more steps;
   // measured slower, 256^3: 23.7 against 20.5 ms per step -- twice the hand-overs and half-used 64-byte segments)
   const int unit = flow_setting("FASTS_HIP_LU_FLOW_UNIT", 8) == 4 ? 4 : 8;
-  if (flow_prepare(f, r, 64 / unit) != 0) return -1;
+  if (flow_prepare(f, nb, ranges, 64 / unit) != 0) return -1;
   int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 768);
   if (waves < 1) waves = 1;
   if (waves > f->ntasks) waves = f->ntasks;
@@ -1271,8 +1296,8 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gam
   if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
 #define FS_LOW(F, N)                                                                                                         \
   do {                                                                                                                       \
-    if (unit == 4) hipLaunchKernelGGL((k_lu_lower_flow<F, N, 4>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
-    else hipLaunchKernelGGL((k_lu_lower_flow<F, N, 8>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
+    if (unit == 4) hipLaunchKernelGGL((k_lu_lower_flow<F, N, 4>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
+    else hipLaunchKernelGGL((k_lu_lower_flow<F, N, 8>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
   } while (0)
   if (sa && full) FS_LOW(true, 6); else if (sa) FS_LOW(false, 6); else if (full) FS_LOW(true, 5); else FS_LOW(false, 5);
 #undef FS_LOW
@@ -1282,26 +1307,28 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, const int *range, double gam
     std::vector<unsigned> w(f->sync_bytes / sizeof(unsigned) + 4);
     (void)hipMemcpy(w.data(), f->sync_dev, f->sync_bytes + 16, hipMemcpyDeviceToHost);
     if (!w[FLOW_ABORT]) return;
-    fprintf(stderr, "lusgs_flow %s gave up: range %d-%d %d-%d %d-%d, %d tasks (%d pencils per plane), %d waves, counter %u; steps done per task (plane by plane):\n",
-            what, r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, f->ntasks, f->njb, waves, w[FLOW_COUNTER]);
-    for (int kk = 0; kk < nk && kk < 40; kk++) {
-      for (int jb = 0; jb < f->njb && jb < 40; jb++) fprintf(stderr, " %3u", w[FLOW_FLAGS + kk * f->njb + jb]);
-      fprintf(stderr, "\n");
-    }
+    fprintf(stderr, "lusgs_flow %s gave up: %d ranges, first %d-%d %d-%d %d-%d, %d tasks, %d waves, counter %u; steps done per task:\n",
+            what, nb, ranges[0], ranges[1], ranges[2], ranges[3], ranges[4], ranges[5], f->ntasks, waves, w[FLOW_COUNTER]);
+    for (int q = 0; q < f->ntasks && q < 1600; q++) fprintf(stderr, " %3u%s", w[FLOW_FLAGS + q], q % 32 == 31 ? "\n" : "");
+    fprintf(stderr, "\n");
   };
   debug_dump("lower sweep");
   if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
 #define FS_UPP(F, N)                                                                                                         \
   do {                                                                                                                       \
-    if (unit == 4) hipLaunchKernelGGL((k_lu_upper_flow<F, N, 4>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
-    else hipLaunchKernelGGL((k_lu_upper_flow<F, N, 8>), g, dim3(64), 0, s, z, c, r, f->njb, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
+    if (unit == 4) hipLaunchKernelGGL((k_lu_upper_flow<F, N, 4>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
+    else hipLaunchKernelGGL((k_lu_upper_flow<F, N, 8>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
   } while (0)
   if (sa && full) FS_UPP(true, 6); else if (sa) FS_UPP(false, 6); else if (full) FS_UPP(true, 5); else FS_UPP(false, 5);
 #undef FS_UPP
   debug_dump("upper sweep");
   if (inplace) {
-    dim3 gc((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
-    hipLaunchKernelGGL(k_copy_range, gc, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
+    for (int b = 0; b < nb; b++) {
+      const int *q = ranges + 6 * b;
+      const LuRange rb = {q[0], q[1], q[2], q[3], q[4], q[5]};
+      dim3 gc((unsigned)((q[1] - q[0] + 1 + 255) / 256), (unsigned)(q[3] - q[2] + 1), (unsigned)(q[5] - q[4] + 1));
+      hipLaunchKernelGGL(k_copy_range, gc, dim3(256), 0, s, z, rb, (const double *)scratch, rop_out);
+    }
   }
   return 0;
 }
@@ -1310,8 +1337,18 @@ int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks,
               const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s, bool apart,
               FsLuFlow *flow)
 {
-  if (flow && nblocks <= 1 && !apart && flow_setting("FASTS_HIP_LU_FLOW", 1) != 0)
-    return lusgs_flow(flow, z, range, gamma, rop, rop_out, scratch, dw, coe, s);
+  // One launch per sweep: one sweep of the range; the boxes of the sub-zones (apart); the thread blocks (they tile the
+  // range, so the copy back of the blocks is the copy back of the range) while they are few: the hyperplane launches of
+  // many blocks are wide enough to be bound by issue and memory like the one-launch form, and their 16-cell units use
+  // whole lines.  Measured, ms per step, one launch per hyperplane / per sweep: 256^3 in 16 blocks 21.4 / 16.0, 64 blocks
+  // 15.4 / 15.7, 128 blocks 13.0 / 16.4; the 1024 x 256 C-mesh in 24 blocks 4.06 / 3.75; sub-zones of 32^3 cells,
+  // epsi_newton 0.3: 45.5 / 30.9.  FASTS_HIP_LU_FLOW_BLOCKS: 0 never for thread blocks, 1 always, else below 48 blocks.
+  if (flow && flow_setting("FASTS_HIP_LU_FLOW", 1) != 0) {
+    if (nblocks <= 1) return lusgs_flow(flow, z, 1, (apart && nblocks == 1 && blocks) ? blocks : range, gamma, rop, rop_out, scratch, dw, coe, s);
+    const int fb = flow_setting("FASTS_HIP_LU_FLOW_BLOCKS", -1);
+    if (blocks && (apart || fb == 1 || (fb != 0 && nblocks < 48)))
+      return lusgs_flow(flow, z, nblocks, blocks, gamma, rop, rop_out, scratch, dw, coe, s);
+  }
   // units of U consecutive cells of an i-line: the recurrence of a launch has U steps, a sweep ni/U + nj + nk - 2
   // launches of (cells of the hyperplane)/64 waves.  One sweep of the zone is bound by the latency of a launch:
   // measured at 256^3, 3 Newton sub-iterations: U = 4 40.2 ms per step (twice the waves in the large hyperplanes of
