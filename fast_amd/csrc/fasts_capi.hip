@@ -1379,15 +1379,19 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
         HIPCHK(ctx, hipStreamWaitEvent(ls, zn.ev_lu_fork, 0));
       }
       int lrc = 0;
+      const int side_by_side = ctx->lu_nstreams > 0 ? std::min<int>(ctx->lu_nstreams, (int)ctx->zones.size()) : 1;
       if (ctx->local_newton) {
         // one sweep pair over the boxes, side by side like the blocks of the reference's threads: neighbour terms across
         // the borders of a box are left out (LU/invlu_l.for:90-215), the Newton update touches the boxes alone
         Zone::BoxBcs &bb = zn.box_bcs[(size_t)nstep - 1];
+        if (!bb.flow) bb.flow = fsk_luflow_new();
+        fsk_luflow_concurrency(bb.flow, side_by_side);
         lrc = fsk_lusgs(z, nbox > 1 ? zn.lu : bb.lu_ranges.data(), nbox, bb.lu_ranges.data(), bb.lu_dev, zn.preal[GAMMA],
-                        zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, true,
-                        bb.flow ? bb.flow : (bb.flow = fsk_luflow_new()));
+                        zn.dev[in], zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, true, bb.flow);
       } else {
       const int sdm[6] = {1, z.iv, 1, z.jv, 1, z.kv};
+      if (!zn.lu_flow) zn.lu_flow = fsk_luflow_new();
+      fsk_luflow_concurrency(zn.lu_flow, side_by_side);
       // lu_match = 1: the sweeps of invlu_overlap_{l,u}.for (with nb_relax > 1, 5 equations: the LU-SSOR sweeps whatever
       // lu_match is, LU/invlu.for:195-340).  The reference also copies the Newton residual into the
       // ghost cells of match joins first (lhs.cpp:1-15); no sweep reads them (the range grows into ghost cells only
@@ -1397,8 +1401,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
                                        zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
                                        zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
                           : fsk_lusgs(z, zn.lu, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.preal[GAMMA], zn.dev[in],
-                                      zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, false,
-                                      zn.lu_flow ? zn.lu_flow : (zn.lu_flow = fsk_luflow_new()));
+                                      zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, false, zn.lu_flow);
       }
       if (sfd && !verif && nstep == z.nssiter - 1)
         fsk_sfd(z, zn.preal[35], zn.preal[36], sfd_pull, zn.dev[out], zn.rof, zn.coe, ls);

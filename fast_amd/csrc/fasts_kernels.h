@@ -130,6 +130,7 @@ void fsk_coe_implicit(const FsZone &z, int first_it, int dtloc, double cfl, doub
 struct FsLuFlow;
 FsLuFlow *fsk_luflow_new();
 void fsk_luflow_free(FsLuFlow *f);
+void fsk_luflow_concurrency(FsLuFlow *f, int n);   // sweeps of n zones run side by side: fewer waves per launch
 int fsk_luflow_gave_up(const FsLuFlow *f);
 int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks, const int *blocks_dev, double gamma,
               const double *rop, double *rop_out, double *scratch, double *dw, const double *coe, hipStream_t s,

@@ -1192,6 +1192,7 @@ static int lusgs_sweeps(const FsZone &z, const int *range, int nblocks, const in
 struct FsLuFlow {
   std::vector<int> key;             // the ranges the tables were built for, and the lines of a pencil
   int ntasks = 0;
+  int concurrent = 1;               // sweep launches of other zones expected on the device at the same time, this one included
   FlowTask *tasks_dev = nullptr;
   FlowBox *boxes_dev = nullptr;
   unsigned *sync_dev = nullptr;     // [counter, abort, ..., one progress word per task] zeroed before every sweep, then the
@@ -1199,6 +1200,7 @@ struct FsLuFlow {
 };
 
 FsLuFlow *fsk_luflow_new() { return new FsLuFlow; }
+void fsk_luflow_concurrency(FsLuFlow *f, int n) { if (f) f->concurrent = n < 1 ? 1 : n; }
 void fsk_luflow_free(FsLuFlow *f)
 {
   if (!f) return;
@@ -1224,7 +1226,7 @@ static int flow_setting(const char *name, int dflt)
 
 // nb ranges swept independently of each other (6 integers each).  The tables are rebuilt when the ranges change; the
 // frees wait for the device, so a sweep that still reads the old tables has ended by then.
-static int flow_prepare(FsLuFlow *f, int nb, const int *ranges, int lpp)
+static int flow_prepare(FsLuFlow *f, int nb, const int *ranges, int lpp, hipStream_t s)
 {
   std::vector<int> key(ranges, ranges + 6 * (size_t)nb);
   key.push_back(lpp);
@@ -1263,9 +1265,12 @@ static int flow_prepare(FsLuFlow *f, int nb, const int *ranges, int lpp)
   if (hipMalloc(&f->tasks_dev, sizeof(FlowTask) * (size_t)ntasks) != hipSuccess) return -1;
   if (hipMalloc(&f->boxes_dev, sizeof(FlowBox) * (size_t)nb) != hipSuccess) return -1;
   if (hipMalloc(&f->sync_dev, f->sync_bytes + 16) != hipSuccess) return -1;
-  if (hipMemcpy(f->tasks_dev, tasks.data(), sizeof(FlowTask) * (size_t)ntasks, hipMemcpyHostToDevice) != hipSuccess) return -1;
-  if (hipMemcpy(f->boxes_dev, boxes.data(), sizeof(FlowBox) * (size_t)nb, hipMemcpyHostToDevice) != hipSuccess) return -1;
-  if (hipMemset(f->sync_dev, 0, f->sync_bytes + 16) != hipSuccess) return -1;
+  // On the stream of the solve, and waited for: a copy or a fill on the null stream is not ordered with a non-blocking
+  // stream (a fill that lands while the first sweep runs would zero its task counter and progress words).
+  if (hipMemcpyAsync(f->tasks_dev, tasks.data(), sizeof(FlowTask) * (size_t)ntasks, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  if (hipMemcpyAsync(f->boxes_dev, boxes.data(), sizeof(FlowBox) * (size_t)nb, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes + 16, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
   f->key = key;
   f->ntasks = ntasks;
   return 0;
@@ -1287,8 +1292,11 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, int nb, const int *ranges, d
   // cells of a unit: 8 lines x 8 cells, or 16 x 4 (FASTS_HIP_LU_FLOW_UNIT=4: half the recurrence per step, 6 % more steps;
   // measured slower, 256^3: 23.7 against 20.5 ms per step -- twice the hand-overs and half-used 64-byte segments)
   const int unit = flow_setting("FASTS_HIP_LU_FLOW_UNIT", 8) == 4 ? 4 : 8;
-  if (flow_prepare(f, nb, ranges, 64 / unit) != 0) return -1;
-  int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 768);
+  if (flow_prepare(f, nb, ranges, 64 / unit, s) != 0) return -1;
+  // pencils in work at a time: 768 for one sweep on the device; when the sweeps of several zones run side by side on streams of
+  // their own, about 1 000 waves in all (four channel blocks of 128 x 256 x 128 cells on four streams, ms per step: 192 waves per
+  // launch 41.7, 256 38.3, 384 38.8, 768 42.7)
+  int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 2304 / (2 * f->concurrent + 1));
   if (waves < 1) waves = 1;
   if (waves > f->ntasks) waves = f->ntasks;
   unsigned *sticky = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(f->sync_dev) + f->sync_bytes);
@@ -1343,6 +1351,46 @@ int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks,
   // whole lines.  Measured, ms per step, one launch per hyperplane / per sweep: 256^3 in 16 blocks 21.4 / 16.0, 64 blocks
   // 15.4 / 15.7, 128 blocks 13.0 / 16.4; the 1024 x 256 C-mesh in 24 blocks 4.06 / 3.75; sub-zones of 32^3 cells,
   // epsi_newton 0.3: 45.5 / 30.9.  FASTS_HIP_LU_FLOW_BLOCKS: 0 never for thread blocks, 1 always, else below 48 blocks.
+  if (flow && flow_setting("FASTS_HIP_LU_FLOW_CHECK", 0) != 0 && nblocks <= 1) {
+    // development aid: the one-launch solve, then the per-hyperplane solve from the same input, compared on the host
+    const size_t n = (size_t)z.neq * (size_t)z.nd, nb = n * sizeof(double);
+    const bool inplace = rop_out == rop;
+    double *dw0 = nullptr, *rop0 = nullptr;
+    if (hipMalloc(&dw0, nb) != hipSuccess || hipMalloc(&rop0, nb) != hipSuccess) return -1;
+    // (every copy on the stream of the solve: a copy on the null stream is not ordered with a non-blocking stream)
+    (void)hipMemcpyAsync(dw0, dw, nb, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(rop0, rop_out, nb, hipMemcpyDeviceToDevice, s);
+    const int *rg = (apart && nblocks == 1 && blocks) ? blocks : range;
+    if (lusgs_flow(flow, z, 1, rg, gamma, rop, rop_out, scratch, dw, coe, s) != 0) return -1;
+    std::vector<double> dwA(n), roA(n), dwB(n), roB(n);
+    (void)hipMemcpyAsync(dwA.data(), dw, nb, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(roA.data(), rop_out, nb, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(dw, dw0, nb, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(rop_out, rop0, nb, hipMemcpyDeviceToDevice, s);
+    const int rc = lusgs_sweeps<8>(z, rg, 0, nullptr, nullptr, gamma, rop, rop_out, scratch, dw, coe, s, false);
+    (void)hipMemcpyAsync(dwB.data(), dw, nb, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(roB.data(), rop_out, nb, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(dw0); (void)hipFree(rop0);
+    size_t bad_dw = 0, bad_ro = 0;
+    static int shown = 0;
+    for (size_t q = 0; q < n; q++) {
+      const bool b1 = memcmp(&dwA[q], &dwB[q], 8) != 0, b2 = memcmp(&roA[q], &roB[q], 8) != 0;
+      bad_dw += b1; bad_ro += b2;
+      if ((b1 || b2) && shown < 40) {
+        shown++;
+        const long long l = (long long)(q % (size_t)z.nd);
+        const int e = (int)(q / (size_t)z.nd);
+        const int k = (int)(l / z.inck), j = (int)((l % z.inck) / z.incj), i = (int)(l % z.incj);
+        fprintf(stderr, "  flow check: eq %d cell (%d,%d,%d) [interior index %d,%d,%d] dw %.17g / %.17g  state %.17g / %.17g\n", e, i, j, k,
+                i - z.ific + 1, j - z.ific + 1, k - z.ifick + 1, dwA[q], dwB[q], roA[q], roB[q]);
+      }
+    }
+    if (bad_dw || bad_ro)
+      fprintf(stderr, "flow check: range %d-%d %d-%d %d-%d inplace %d: %zu increments and %zu state values differ (one launch per sweep / per hyperplane)\n",
+              rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], (int)inplace, bad_dw, bad_ro);
+    return rc;
+  }
   if (flow && flow_setting("FASTS_HIP_LU_FLOW", 1) != 0) {
     if (nblocks <= 1) return lusgs_flow(flow, z, 1, (apart && nblocks == 1 && blocks) ? blocks : range, gamma, rop, rop_out, scratch, dw, coe, s);
     const int fb = flow_setting("FASTS_HIP_LU_FLOW_BLOCKS", -1);
