@@ -1399,7 +1399,7 @@ static int stage_impl(fs_ctx *ctx, int nitrun, int nstep, int part, const char *
       lrc = (zn.pint[NB_RELAX] > 1 || zn.pint[LU_MATCH] != 0)
                           ? fsk_lussor(z, zn.lu, sdm, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.pint[NB_RELAX],
                                        zn.pint[LU_MATCH] != 0 && zn.pint[NB_RELAX] == 1, zn.preal[GAMMA], zn.dev[in],
-                                       zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls)
+                                       zn.dev[out], zn.scratch, zn.drodm, zn.ssor_work, zn.coe, ls, zn.lu_flow)
                           : fsk_lusgs(z, zn.lu, (int)(zn.lu_blocks.size() / 6), zn.lu_blocks.data(), zn.lu_blocks_dev, zn.preal[GAMMA], zn.dev[in],
                                       zn.dev[out], zn.scratch, zn.drodm, zn.coe, ls, false, zn.lu_flow);
       }

@@ -137,7 +137,7 @@ int fsk_lusgs(const FsZone &z, const int *range, int nblocks, const int *blocks,
               bool apart = false, FsLuFlow *flow = nullptr);
 int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nblocks, const int *blocks, const int *blocks_dev,
                int nb_relax, int overlap, double gamma, const double *rop, double *rop_out, double *scratch, const double *din,
-               double *work, const double *coe, hipStream_t s);
+               double *work, const double *coe, hipStream_t s, FsLuFlow *flow = nullptr);
 
 // roe + walls (fasts_wallflux.hip): correction of the balance on the cells next to one wall window (glo/ghi = its
 // ghost-cell window, tag = BC tag of the reference), then the end of the stage redone from the corrected balance

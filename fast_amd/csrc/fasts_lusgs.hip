@@ -1064,6 +1064,176 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const
   }
 }
 
+// LU-SSOR sweeps (nb_relax >= 2) and LU-SGS with lu_match = 1 as one launch per sweep: the pencils, step counts and
+// hand-overs of the two kernels above with the cell operations of k_ssor_lower_wave / k_ssor_upper_wave (neighbour terms
+// in the order i, j, k inside the recurrence, accumulator ssor).  The increments dout are what pencils hand to each
+// other; din, ssor and the states are read and written by the owner of a cell alone.
+template <bool FULL, bool UPPER, bool FIRSTM, bool LAST, bool LUD, int NE>
+__global__ void __launch_bounds__(64) k_ssor_flow(FsZone z, LuConst c, const FlowBox *__restrict__ boxes, LuRange sdm,
+                                                  const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
+                                                  unsigned *sticky, const double *__restrict__ rop, const double *rop_kn,
+                                                  double *rop_new, const double *__restrict__ din, double *dout,
+                                                  double *ssor, const double *__restrict__ coe)
+{
+  constexpr int U = 8, LPP = 8, SGN = UPPER ? -1 : 1;
+  const int lane = threadIdx.x, jj = lane / U, m = lane % U;
+  const int q = UPPER ? LPP - 1 - jj : jj;          // rank of the line in the order of the sweep
+  const int mfirst = UPPER ? U - 1 : 0;             // cell of a unit the recurrence starts from
+  unsigned *flags = sync + FLOW_FLAGS;
+  const long long nd = z.nd;
+  for (bool alive = true; alive;) {
+    const int n = (int)(__builtin_amdgcn_readfirstlane(
+                      __hip_atomic_fetch_add(sync + FLOW_COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 6);
+    if (n >= ntasks) break;
+    const FlowTask t = tasks[UPPER ? ntasks - 1 - n : n];
+    const LuRange r = boxes[t.b].r;
+    const int njb = boxes[t.b].njb;
+    const int ni = r.i1 - r.i0 + 1, nchunk = (ni + U - 1) / U, nsteps = nchunk + LPP - 1;
+    const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
+    const int j = r.j0 + LPP * t.jb + jj, k = t.k;
+    const bool line_ok = j <= r.j1;
+    const bool has_j = UPPER ? j < r.j1 : j > r.j0, has_k = UPPER ? k < r.k1 : k > r.k0;
+    const bool pred_pencil = UPPER ? t.jb < njb - 1 : t.jb > 0;
+    const unsigned *fk = flags + t.fid - SGN * njb, *fj = flags + t.fid - SGN;
+    unsigned *mine = flags + t.fid;
+    const long long lrow = lcell(z, r.i0, line_ok ? j : r.j0, k) + m, ltrow = FULL ? lmtr(z, r.i0, line_ok ? j : r.j0, k) + m : 0;
+    const long long dj_ = has_j ? SGN * z.incj : 0, dk_ = has_k ? SGN * z.inck : 0;   // no neighbour: reads itself, drops the term
+    const bool in_sdm_jk = j >= sdm.j0 && j <= sdm.j1 && k >= sdm.k0 && k <= sdm.k1;
+    auto geom = [&](int s, int &i, bool &active, bool &has_prev, long long &l, long long &lt) {
+      const int cn = UPPER ? nchunk - 1 - (s - q) : s - q, di = cn * U;
+      i = r.i0 + di + m;
+      active = line_ok && cn >= 0 && cn < nchunk && di + m < ni;
+      has_prev = active && (UPPER ? di + m < ni - 1 : di + m > 0);
+      l = active ? lrow + di : lsafe;
+      lt = FULL ? (active ? ltrow + di : ltsafe) : 0;
+    };
+    // loaded one step ahead: what a step reads that no other wave of the launch writes
+    double sA[NE], sS[NE], sq[NE], sxal, sc5, sc6 = 1., sk[4], ck, sj[4], cj, si[4], ci;
+    auto load_stat = [&](int s) {
+      int i; bool active, has_prev; long long l, lt;
+      geom(s, i, active, has_prev, l, lt);
+      const long long lj = l - dj_, lk = l - dk_, li = has_prev ? l - SGN : l;
+      sxal = coe[l]; sc5 = coe[l + 4 * nd];
+      if (NE == 6) sc6 = coe[l + 5 * nd];
+#pragma unroll
+      for (int e = 0; e < NE; e++) {
+        if (UPPER && LUD) sA[e] = dout[l + e * nd];        // the cell's own increment of the lower sweep (the launch before)
+        else { sA[e] = din[l + e * nd]; if (UPPER || !FIRSTM) sS[e] = ssor[l + e * nd]; }
+        if (UPPER && LAST) sq[e] = rop[l + e * nd];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (!(UPPER && LAST)) sk[e] = rop[lk + (e + 1) * nd];
+        sj[e] = rop[lj + (e + 1) * nd]; si[e] = rop[li + (e + 1) * nd];
+      }
+      ck = coe[lk + 3 * nd]; cj = coe[lj + 2 * nd]; ci = coe[li + nd];
+    };
+    load_stat(0);
+    for (int s = 0; s <= nsteps && alive; s++) {   // pass nsteps publishes the last count only
+      int i; bool active, has_prev; long long l, lt;
+      geom(s, i, active, has_prev, l, lt);
+      const long long lj = l - dj_, lk = l - dk_, li = (has_prev && m == mfirst) ? l - SGN : l;
+      const unsigned need_k = (has_k && s < nsteps) ? (unsigned)(s + 1) : 0u;
+      const unsigned need_j = (pred_pencil && s < nchunk) ? (unsigned)(s + LPP) : 0u;
+      alive = flow_wait(fk, need_k, fj, need_j, mine, (unsigned)s, sync, sticky);
+      if (!alive || s == nsteps) continue;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double A[NE], S[NE], P[NE], dk[NE], dj[NE], skn[4], qs[NE];
+#pragma unroll
+      for (int e = 0; e < NE; e++) { dk[e] = ld_sc1(dout + lk + e * nd); dj[e] = ld_sc1(dout + lj + e * nd); P[e] = ld_sc1(dout + li + e * nd); }
+#pragma unroll
+      for (int e = 0; e < 4; e++) skn[e] = (UPPER && LAST) ? ld_sc1(rop_kn + lk + (e + 1) * nd) : sk[e];
+      double MI[26], MJ[26], MK[26];
+      const double XAL = sxal * (UPPER ? -0.5 : 0.5), c5 = sc5, DG = 1. / c5, C6 = sc6, ckk = ck;
+#pragma unroll
+      for (int e = 0; e < NE; e++) {
+        if (UPPER && LUD) A[e] = sA[e];
+        else A[e] = (!UPPER && FIRSTM) ? sA[e] : sA[e] + sS[e];
+        S[e] = 0.;
+        if (UPPER && LAST) qs[e] = sq[e];
+      }
+      if (UPPER && LUD) {
+#pragma unroll
+        for (int e = 0; e < 5; e++) A[e] = A[e] * c5;
+        if (NE == 6) A[NE - 1] = A[NE - 1] * C6;   // LU/lu_d_SA.for
+      }
+      lu_mat<FULL, 1, SGN, NE>(z, c, lt, sj[0], sj[1], sj[2], sj[3], cj, MJ);
+      lu_mat<FULL, 0, SGN, NE>(z, c, lt, si[0], si[1], si[2], si[3], ci, MI);
+      if (s + 1 < nsteps) load_stat(s + 1);
+      lu_mat<FULL, 2, SGN, NE>(z, c, lt, skn[0], skn[1], skn[2], skn[3], ckk, MK);
+      double BJ[NE], BK[NE];
+      {
+        double b[NE];
+        lu_mul<FULL, 1, NE>(MJ, dj[0], dj[1], dj[2], dj[3], dj[4], b, NE == 6 ? dj[NE - 1] : 0.);
+#pragma unroll
+        for (int e = 0; e < NE; e++) BJ[e] = b[e] * XAL;
+        lu_mul<FULL, 2, NE>(MK, dk[0], dk[1], dk[2], dk[3], dk[4], b, NE == 6 ? dk[NE - 1] : 0.);
+#pragma unroll
+        for (int e = 0; e < NE; e++) BK[e] = b[e] * XAL;
+      }
+      auto cell = [&](const double *pin) {
+        bool any = false;
+        if (has_prev) {
+          double b[NE];
+          lu_mul<FULL, 0, NE>(MI, pin[0], pin[1], pin[2], pin[3], pin[4], b, NE == 6 ? pin[NE - 1] : 0.);
+#pragma unroll
+          for (int e = 0; e < NE; e++) { const double tt = b[e] * XAL; A[e] = A[e] + tt; S[e] = (!UPPER && FIRSTM) ? tt : S[e] + tt; }
+          any = true;
+        }
+        if (has_j) {
+#pragma unroll
+          for (int e = 0; e < NE; e++) { A[e] = A[e] + BJ[e]; S[e] = (!UPPER && FIRSTM && !any) ? BJ[e] : S[e] + BJ[e]; }
+          any = true;
+        }
+        if (has_k) {
+#pragma unroll
+          for (int e = 0; e < NE; e++) { A[e] = A[e] + BK[e]; S[e] = (!UPPER && FIRSTM && !any) ? BK[e] : S[e] + BK[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 5; e++) P[e] = A[e] * DG;
+        if (NE == 6) P[NE - 1] = A[NE - 1] / C6;   // LU/lu_dinv_SA.for
+      };
+      if (m == mfirst && active) {
+        double pin[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) pin[e] = P[e];
+        cell(pin);
+      }
+#pragma unroll
+      for (int st = 1; st < U; st++) {
+        double pin[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) pin[e] = UPPER ? lane_next(P[e]) : lane_prev(P[e]);
+        if (m == (UPPER ? U - 1 - st : st) && active) cell(pin);
+      }
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < NE; e++) { st_sc1(dout + l + e * nd, P[e]); if (!(UPPER && LUD)) ssor[l + e * nd] = S[e]; }
+        if (UPPER && LAST && in_sdm_jk && i >= sdm.i0 && i <= sdm.i1) {
+          // Newton update (mjr_newton.for)
+          const double ro_old = qs[0], u_old = qs[1], v_old = qs[2], w_old = qs[3], t_old = qs[4];
+          const double rn = ro_old + P[0];
+          const double r_1 = 1. / rn;
+          const double un = (ro_old * u_old + P[1]) * r_1;
+          const double vn = (ro_old * v_old + P[2]) * r_1;
+          const double wn = (ro_old * w_old + P[3]) * r_1;
+          const double roe_old = ro_old * (c.cv * t_old + 0.5 * (u_old * u_old + v_old * v_old + w_old * w_old));
+          st_sc1(rop_new + l, rn); st_sc1(rop_new + l + nd, un); st_sc1(rop_new + l + 2 * nd, vn); st_sc1(rop_new + l + 3 * nd, wn);
+          const double tn = (roe_old + P[4]) * r_1 * c.cvinv - c.cvinv2 * (un * un + vn * vn + wn * wn);
+          st_sc1(rop_new + l + 4 * nd, tn);
+          if (NE == 6) {   // LU/mjr_newton_SA.for: nu_tilde clipped to [0, ratiom * nu]
+            double anulam = fs_mulam_sa(z, tn);
+            anulam = anulam * r_1 * z.ratiom;
+            double t6 = (ro_old * qs[NE - 1] + P[NE - 1]) * r_1;
+            t6 = fs_min(t6, anulam);
+            st_sc1(rop_new + l + 5 * nd, fs_max(t6, 0.));
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_copy_range(FsZone z, LuRange r, const double *__restrict__ src,
                                                     double *__restrict__ dst)
 {
@@ -1520,10 +1690,67 @@ static int lussor_sweeps(const FsZone &z, const int *range, const int *sdm_, int
   return 0;
 }
 
+// The relaxations of fsk_lussor as one launch per sweep over nb ranges (the range, or the thread blocks)
+static int lussor_flow(FsLuFlow *f, const FsZone &z, const int *range, const int *sdm_, int nb, const int *ranges, int nb_relax,
+                       int overlap, double gamma, const double *rop, double *rop_out, double *scratch, const double *din,
+                       double *work, const double *coe, hipStream_t s)
+{
+  if ((z.neq != 5 && z.neq != 6) || (overlap ? nb_relax != 1 : nb_relax < 2)) return -1;
+  LuConst c;
+  c.gam1 = gamma; c.gamm1 = gamma - 1.; c.cp = gamma * z.cv; c.gam2 = c.gamm1 - 1.;
+  c.cv = z.cv; c.cvinv = 1. / z.cv; c.cvinv2 = 0.5 * c.cvinv;
+  const LuRange r = {range[0], range[1], range[2], range[3], range[4], range[5]};
+  const LuRange sdm = {sdm_[0], sdm_[1], sdm_[2], sdm_[3], sdm_[4], sdm_[5]};
+  const int ni = r.i1 - r.i0 + 1, nj = r.j1 - r.j0 + 1, nk = r.k1 - r.k0 + 1;
+  if (ni < 1 || nj < 1 || nk < 1) return -1;
+  const bool full = z.ityp == 0, sa = z.neq == 6;
+  const bool inplace = rop_out == rop;
+  if (inplace && !scratch) return -1;
+  double *rop_new = inplace ? scratch : rop_out;
+  const double *rop_kn = inplace ? scratch : rop;
+  double *dout = work, *ssor = work + (size_t)z.neq * z.nd;
+  if (flow_prepare(f, nb, ranges, 8, s) != 0) return -1;
+  int waves = flow_setting("FASTS_HIP_LU_FLOW_WAVES", 2304 / (2 * f->concurrent + 1));
+  if (waves < 1) waves = 1;
+  if (waves > f->ntasks) waves = f->ntasks;
+  unsigned *sticky = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(f->sync_dev) + f->sync_bytes);
+  const dim3 g((unsigned)waves);
+  const dim3 gr((unsigned)((ni + 255) / 256), (unsigned)nj, (unsigned)nk);
+  // cells of the range outside sdm keep their state: the copy back below covers the whole range
+  if (inplace) hipLaunchKernelGGL(k_copy_range, gr, dim3(256), 0, s, z, r, rop, scratch);
+#define FS_GO4(F, UP, M1, L, D, N) hipLaunchKernelGGL((k_ssor_flow<F, UP, M1, L, D, N>), g, dim3(64), 0, s, z, c, f->boxes_dev, sdm, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, din, dout, ssor, coe)
+#define FS_GO3(F, UP, M1, L, D) do { if (sa) FS_GO4(F, UP, M1, L, D, 6); else FS_GO4(F, UP, M1, L, D, 5); } while (0)
+#define FS_GO(UP, M1, L, D) do { if (full) FS_GO3(true, UP, M1, L, D); else FS_GO3(false, UP, M1, L, D); } while (0)
+  for (int m = 1; m <= nb_relax; m++) {
+    const bool last = m == nb_relax;
+    if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
+    if (overlap || m == 1) FS_GO(false, true, false, false); else FS_GO(false, false, false, false);
+    if (hipMemsetAsync(f->sync_dev, 0, f->sync_bytes, s) != hipSuccess) return -1;
+    if (overlap) FS_GO(true, false, true, true);
+    else if (last) FS_GO(true, false, true, false);
+    else FS_GO(true, false, false, false);
+  }
+#undef FS_GO
+#undef FS_GO3
+#undef FS_GO4
+  if (inplace) hipLaunchKernelGGL(k_copy_range, gr, dim3(256), 0, s, z, r, (const double *)scratch, rop_out);
+  return 0;
+}
+
 int fsk_lussor(const FsZone &z, const int *range, const int *sdm, int nblocks, const int *blocks, const int *blocks_dev,
                int nb_relax, int overlap, double gamma, const double *rop, double *rop_out, double *scratch, const double *din,
-               double *work, const double *coe, hipStream_t s)
+               double *work, const double *coe, hipStream_t s, FsLuFlow *flow)
 {
+  // one launch per sweep, as fsk_lusgs takes it: one sweep of the range, or few thread blocks
+  if (flow && flow_setting("FASTS_HIP_LU_FLOW", 1) != 0) {
+    const bool multi = nblocks > 1 && blocks && !overlap;
+    const int fb = flow_setting("FASTS_HIP_LU_FLOW_BLOCKS", -1);
+    if (!multi) return lussor_flow(flow, z, range, sdm, 1, range, nb_relax, overlap, gamma, rop, rop_out, scratch, din, work, coe, s);
+    // (two relaxations, ms per step, one launch per hyperplane / per sweep: 256^3 74.0 / 46.9, the 1024 x 256 C-mesh 29.6 / 24.1,
+    // the C-mesh in 24 blocks 8.6 / 8.9, 256^3 in 64 blocks 34.4 / 35.4)
+    if (fb == 1 || (fb != 0 && nblocks < 20))
+      return lussor_flow(flow, z, range, sdm, nblocks, blocks, nb_relax, overlap, gamma, rop, rop_out, scratch, din, work, coe, s);
+  }
   // unit length as in fsk_lusgs: 8 cells for one sweep of the zone, 16 with thread blocks
   if (nblocks > 1 && !overlap)
     return lussor_sweeps<16>(z, range, sdm, nblocks, blocks, blocks_dev, nb_relax, overlap, gamma, rop, rop_out, scratch, din, work, coe, s);
