@@ -778,7 +778,7 @@ FS_DEV double ld_sc1(const double *p)
 FS_DEV void st_sc1(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 enum { FLOW_COUNTER = 0, FLOW_ABORT = 1, FLOW_FLAGS = 16 };
-constexpr unsigned FLOW_SPIN_LIMIT = 1u << 22;
+constexpr unsigned FLOW_SPIN_LIMIT = 1u << 24;   // polls of about a microsecond each: some 20 s
 
 // Lane 0 waits for *fa >= na, lane 1 for *fb >= nb (0: nothing to wait for).  When the first poll has landed every
 // older store of the wave has too: the step count `done` of the wave's own task is published then (0: nothing to
