@@ -313,24 +313,27 @@ def test_selective_frequency_damping_explicit_scheme(n, scheme, model, bcs, pert
     assert rel_err(rof, oz.rof, int(pint[41])).max() < 1e-12
 
 
-@pytest.mark.parametrize("n,scheme,model,perturb,bcs", [
-    ((96, 70, 52), 'senseur', 'NSLaminar', 0., None),
-    ((50, 37, 44), 'ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
-    ((41, 30, 1), 'roe', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}),
+@pytest.mark.parametrize("n,scheme,model,perturb,bcs,numz", [
+    ((96, 70, 52), 'senseur', 'NSLaminar', 0., None, {}),
+    ((50, 37, 44), 'ausmpred', 'NSLaminar', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {}),
+    ((41, 30, 1), 'roe', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {}),
+    ((44, 37, 30), 'senseur', 'NSLaminar', 0.15, {'imin': 'BCWall', 'imax': 'BCFarfield'}, {'nb_relax': 2}),
+    ((41, 30, 1), 'roe', 'NSTurbulent', 0.15, {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {'nb_relax': 2, 'lu_match': 1}),
+    ((33, 26, 20), 'ausmpred', 'NSTurbulent', 0., {'jmin': 'BCWall', 'jmax': 'BCFarfield'}, {'lu_match': 1}),
 ])
-def test_sweeps_in_one_launch_equal_one_launch_per_hyperplane(n, scheme, model, perturb, bcs, monkeypatch):
+def test_sweeps_in_one_launch_equal_one_launch_per_hyperplane(n, scheme, model, perturb, bcs, numz, monkeypatch):
     """The LU-SGS sweeps as one launch each (pencils of 8 lines that wait for each other's step counts) against one
     launch per hyperplane, bit for bit, on zones with many pencils in work at a time, with ragged line and pencil counts;
     with 1, 5 and 64 waves the order in which the pencils are handed out is all that keeps a wave from waiting for
-    a pencil nobody has taken."""
+    a pencil nobody has taken.  LU-SGS, LU-SSOR relaxations and lu_match = 1."""
     def run(flow, waves):
         monkeypatch.setenv('FASTS_HIP_LU_FLOW', str(flow))
         monkeypatch.setenv('FASTS_HIP_LU_FLOW_WAVES', str(waves))
         if len(n) == 3 and n[2] == 1:
-            t = cases.tgv2d(n[:2], scheme, model=model, extra_numz=SINGLE, bcs=bcs, perturb=perturb, time_step=0.02,
+            t = cases.tgv2d(n[:2], scheme, model=model, extra_numz=dict(SINGLE, **numz), bcs=bcs, perturb=perturb, time_step=0.02,
                             temporal_scheme='implicit', extra_numb={'ss_iteration': 3, 'modulo_verif': 1})
         else:
-            t = cases.tgv(n, scheme, model=model, extra_numz=SINGLE, extra_numb={'ss_iteration': 3}, bcs=bcs,
+            t = cases.tgv(n, scheme, model=model, extra_numz=dict(SINGLE, **numz), extra_numb={'ss_iteration': 3}, bcs=bcs,
                           temporal_scheme='implicit', time_step=0.02, perturb=perturb, modulo_verif=1)
         (t, tc, metrics) = FastS.warmup(t, None)
         z = Internal.getZones(t)[0]
