@@ -32,7 +32,6 @@ def oracle():
     return [z.ro.copy() for z in s.zones], zs[0].pint
 
 ref, pint = oracle()
-ni, nj, nk = int(pint[41 - 41 + 0]), 0, 0
 bad = 0
 for rep in range(reps):
     t = cases.tgv(nn, 'senseur', model='NSLaminar', blocks=blocks, **opts)
