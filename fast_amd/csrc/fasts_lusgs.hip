@@ -811,7 +811,8 @@ FS_DEV bool flow_wait(const unsigned *fa, unsigned na, const unsigned *fb, unsig
   return alive;
 }
 
-template <bool FULL, int NE, int U = 8>
+// K3D = false: two-dimensional zone, no plane before: the k term is not formed
+template <bool FULL, int NE, int U = 8, bool K3D = true>
 __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const FlowBox *__restrict__ boxes,
                                                       const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
                                                       unsigned *sticky, const double *__restrict__ rop, double *dw,
@@ -834,7 +835,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const
     const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
     const int j = r.j0 + LPP * t.jb + jj, k = t.k;
     const bool line_ok = j <= r.j1;
-    const bool has_j = j > r.j0, has_k = k > r.k0;
+    const bool has_j = j > r.j0, has_k = K3D && k > r.k0;
     const unsigned *fk = flags + t.fid - njb, *fj = flags + t.fid - 1;
     unsigned *mine = flags + t.fid;
     const long long lrow = lcell(z, r.i0, line_ok ? j : r.j0, k) + m, ltrow = FULL ? lmtr(z, r.i0, line_ok ? j : r.j0, k) + m : 0;
@@ -848,7 +849,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const
       lt = FULL ? (active ? ltrow + di : ltsafe) : 0;
     };
     // what a step reads that no wave of the launch writes, loaded one step ahead
-    double sA[NE], sxal, sc5, sc6 = 1., sk[4], ck, sj[4], cj, si[4], ci;
+    double sA[NE], sxal, sc5, sc6 = 1., sk[4] = {0., 0., 0., 0.}, ck = 0., sj[4], cj, si[4], ci;
     auto load_stat = [&](int s) {
       bool active, has_prev; long long l, lt;
       geom(s, active, has_prev, l, lt);
@@ -858,8 +859,9 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const
 #pragma unroll
       for (int e = 0; e < NE; e++) sA[e] = dw[l + e * nd];
 #pragma unroll
-      for (int e = 0; e < 4; e++) { sk[e] = rop[lk + (e + 1) * nd]; sj[e] = rop[lj + (e + 1) * nd]; si[e] = rop[li + (e + 1) * nd]; }
-      ck = coe[lk + 3 * nd]; cj = coe[lj + 2 * nd]; ci = coe[li + nd];
+      for (int e = 0; e < 4; e++) { if (K3D) sk[e] = rop[lk + (e + 1) * nd]; sj[e] = rop[lj + (e + 1) * nd]; si[e] = rop[li + (e + 1) * nd]; }
+      if (K3D) ck = coe[lk + 3 * nd];
+      cj = coe[lj + 2 * nd]; ci = coe[li + nd];
     };
     load_stat(0);
     for (int s = 0; s <= nsteps && alive; s++) {   // pass nsteps publishes the last count only
@@ -867,7 +869,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const
       geom(s, active, has_prev, l, lt);
       const long long lj = l - dj_, lk = l - dk_, li = (has_prev && m == 0) ? l - 1 : l;
       // the plane before has finished this step; the pencil before has finished the chunk its last line hands over
-      const unsigned need_k = (k > r.k0 && s < nsteps) ? (unsigned)(s + 1) : 0u;
+      const unsigned need_k = (K3D && k > r.k0 && s < nsteps) ? (unsigned)(s + 1) : 0u;
       const unsigned need_j = (t.jb > 0 && s < nchunk) ? (unsigned)(s + LPP) : 0u;
       FLOWSTAMP(0)
       alive = flow_wait(fk, need_k, fj, need_j, mine, (unsigned)s, sync, sticky);
@@ -876,26 +878,26 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       double A[NE], P[NE], dk[NE], dj[NE];
 #pragma unroll
-      for (int e = 0; e < NE; e++) { dk[e] = ld_sc1(dw + lk + e * nd); dj[e] = ld_sc1(dw + lj + e * nd); P[e] = ld_sc1(dw + li + e * nd); }
+      for (int e = 0; e < NE; e++) { if (K3D) dk[e] = ld_sc1(dw + lk + e * nd); dj[e] = ld_sc1(dw + lj + e * nd); P[e] = ld_sc1(dw + li + e * nd); }
       // the matrices of the three neighbours while the increments are on their way, then the loads of the next step
       double MI[26], MJ[26], MK[26];
       const double XAL = sxal * 0.5, DG = 1. / sc5, C6 = sc6;
 #pragma unroll
       for (int e = 0; e < NE; e++) A[e] = sA[e];
-      lu_mat<FULL, 2, 1, NE>(z, c, lt, sk[0], sk[1], sk[2], sk[3], ck, MK);
+      if (K3D) lu_mat<FULL, 2, 1, NE>(z, c, lt, sk[0], sk[1], sk[2], sk[3], ck, MK);
       lu_mat<FULL, 1, 1, NE>(z, c, lt, sj[0], sj[1], sj[2], sj[3], cj, MJ);
       lu_mat<FULL, 0, 1, NE>(z, c, lt, si[0], si[1], si[2], si[3], ci, MI);
       if (s + 1 < nsteps) load_stat(s + 1);
       {
         double bk[NE], bj[NE];
-        lu_mul<FULL, 2, NE>(MK, dk[0], dk[1], dk[2], dk[3], dk[4], bk, NE == 6 ? dk[NE - 1] : 0.);
+        if (K3D) lu_mul<FULL, 2, NE>(MK, dk[0], dk[1], dk[2], dk[3], dk[4], bk, NE == 6 ? dk[NE - 1] : 0.);
         lu_mul<FULL, 1, NE>(MJ, dj[0], dj[1], dj[2], dj[3], dj[4], bj, NE == 6 ? dj[NE - 1] : 0.);
         if (FULL) {
-          if (has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
+          if (K3D && has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
           if (has_j) { for (int e = 0; e < NE; e++) A[e] = A[e] + bj[e] * XAL; }
         } else {
           if (has_j) { for (int e = 0; e < NE; e++) A[e] = A[e] + bj[e] * XAL; }
-          if (has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
+          if (K3D && has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
         }
       }
       FLOWSTAMP(2)
@@ -936,7 +938,7 @@ __global__ void __launch_bounds__(64) k_lu_lower_flow(FsZone z, LuConst c, const
 // Upper sweep and Newton update: the pencils in the opposite order, the lines of a pencil downwards, the chunks of a
 // line from the last to the first.  The state of the k + 1 neighbour is the new one when the update is in place
 // (rop_kn = the array the new iterate is built in): handed over like the increments.
-template <bool FULL, int NE, int U = 8>
+template <bool FULL, int NE, int U = 8, bool K3D = true>
 __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const FlowBox *__restrict__ boxes,
                                                       const FlowTask *__restrict__ tasks, int ntasks, unsigned *sync,
                                                       unsigned *sticky, const double *__restrict__ rop, const double *rop_kn,
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const
     const long long lsafe = lcell(z, r.i0, r.j0, r.k0), ltsafe = FULL ? lmtr(z, r.i0, r.j0, r.k0) : 0;
     const int j = r.j0 + LPP * t.jb + jj, k = t.k;
     const bool line_ok = j <= r.j1;
-    const bool has_j = j < r.j1, has_k = k < r.k1;
+    const bool has_j = j < r.j1, has_k = K3D && k < r.k1;
     const unsigned *fk = flags + t.fid + njb, *fj = flags + t.fid + 1;
     unsigned *mine = flags + t.fid;
     const long long lrow = lcell(z, r.i0, line_ok ? j : r.j0, k) + m, ltrow = FULL ? lmtr(z, r.i0, line_ok ? j : r.j0, k) + m : 0;
@@ -969,7 +971,7 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const
       l = active ? lrow + di : lsafe;
       lt = FULL ? (active ? ltrow + di : ltsafe) : 0;
     };
-    double sA[NE], sq[NE], sxal, sc5, sc6 = 1., ck, sj[4], cj, si[4], ci;
+    double sA[NE], sq[NE], sxal, sc5, sc6 = 1., ck = 0., sj[4], cj, si[4], ci;
     auto load_stat = [&](int s) {
       bool active, has_next; long long l, lt;
       geom(s, active, has_next, l, lt);
@@ -980,7 +982,8 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const
       for (int e = 0; e < NE; e++) { sA[e] = dw[l + e * nd]; sq[e] = rop[l + e * nd]; }
 #pragma unroll
       for (int e = 0; e < 4; e++) { sj[e] = rop[lj + (e + 1) * nd]; si[e] = rop[li + (e + 1) * nd]; }
-      ck = coe[lk + 3 * nd]; cj = coe[lj + 2 * nd]; ci = coe[li + nd];
+      if (K3D) ck = coe[lk + 3 * nd];
+      cj = coe[lj + 2 * nd]; ci = coe[li + nd];
     };
     load_stat(0);
     for (int s = 0; s <= nsteps && alive; s++) {   // pass nsteps publishes the last count only
@@ -988,16 +991,16 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const
       geom(s, active, has_next, l, lt);
       const bool last_of_unit = m == U - 1 || !has_next;
       const long long lj = l + dj_, lk = l + dk_, li = (has_next && last_of_unit) ? l + 1 : l;
-      const unsigned need_k = (k < r.k1 && s < nsteps) ? (unsigned)(s + 1) : 0u;
+      const unsigned need_k = (K3D && k < r.k1 && s < nsteps) ? (unsigned)(s + 1) : 0u;
       const unsigned need_j = (t.jb < njb - 1 && s < nchunk) ? (unsigned)(s + LPP) : 0u;
       alive = flow_wait(fk, need_k, fj, need_j, mine, (unsigned)s, sync, sticky);
       if (!alive || s == nsteps) continue;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       double A[NE], P[NE], dk[NE], dj[NE], sk[4], q[NE];
 #pragma unroll
-      for (int e = 0; e < 4; e++) sk[e] = ld_sc1(rop_kn + lk + (e + 1) * nd);
+      for (int e = 0; e < 4; e++) sk[e] = K3D ? ld_sc1(rop_kn + lk + (e + 1) * nd) : 0.;
 #pragma unroll
-      for (int e = 0; e < NE; e++) { dk[e] = ld_sc1(dw + lk + e * nd); dj[e] = ld_sc1(dw + lj + e * nd); P[e] = ld_sc1(dw + li + e * nd); }
+      for (int e = 0; e < NE; e++) { if (K3D) dk[e] = ld_sc1(dw + lk + e * nd); dj[e] = ld_sc1(dw + lj + e * nd); P[e] = ld_sc1(dw + li + e * nd); }
       double MI[26], MJ[26], MK[26];
       const double XAL = sxal * -0.5, c5 = sc5, DG = 1. / c5, C6 = sc6, ckk = ck;
 #pragma unroll
@@ -1008,10 +1011,12 @@ __global__ void __launch_bounds__(64) k_lu_upper_flow(FsZone z, LuConst c, const
       if (s + 1 < nsteps) load_stat(s + 1);
       {
         double bk[NE], bj[NE];
-        lu_mat<FULL, 2, -1, NE>(z, c, lt, sk[0], sk[1], sk[2], sk[3], ckk, MK);
-        lu_mul<FULL, 2, NE>(MK, dk[0], dk[1], dk[2], dk[3], dk[4], bk, NE == 6 ? dk[NE - 1] : 0.);
+        if (K3D) {
+          lu_mat<FULL, 2, -1, NE>(z, c, lt, sk[0], sk[1], sk[2], sk[3], ckk, MK);
+          lu_mul<FULL, 2, NE>(MK, dk[0], dk[1], dk[2], dk[3], dk[4], bk, NE == 6 ? dk[NE - 1] : 0.);
+        }
         lu_mul<FULL, 1, NE>(MJ, dj[0], dj[1], dj[2], dj[3], dj[4], bj, NE == 6 ? dj[NE - 1] : 0.);
-        if (has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
+        if (K3D && has_k) { for (int e = 0; e < NE; e++) A[e] = A[e] + bk[e] * XAL; }
         if (has_j) { for (int e = 0; e < NE; e++) A[e] = A[e] + bj[e] * XAL; }
       }
       auto cell = [&](const double *pin) {
@@ -1475,6 +1480,7 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, int nb, const int *ranges, d
 #define FS_LOW(F, N)                                                                                                         \
   do {                                                                                                                       \
     if (unit == 4) hipLaunchKernelGGL((k_lu_lower_flow<F, N, 4>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
+    else if (z.twod) hipLaunchKernelGGL((k_lu_lower_flow<F, N, 8, false>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
     else hipLaunchKernelGGL((k_lu_lower_flow<F, N, 8>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, dw, coe); \
   } while (0)
   if (sa && full) FS_LOW(true, 6); else if (sa) FS_LOW(false, 6); else if (full) FS_LOW(true, 5); else FS_LOW(false, 5);
@@ -1495,6 +1501,7 @@ static int lusgs_flow(FsLuFlow *f, const FsZone &z, int nb, const int *ranges, d
 #define FS_UPP(F, N)                                                                                                         \
   do {                                                                                                                       \
     if (unit == 4) hipLaunchKernelGGL((k_lu_upper_flow<F, N, 4>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
+    else if (z.twod) hipLaunchKernelGGL((k_lu_upper_flow<F, N, 8, false>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
     else hipLaunchKernelGGL((k_lu_upper_flow<F, N, 8>), g, dim3(64), 0, s, z, c, f->boxes_dev, f->tasks_dev, f->ntasks, f->sync_dev, sticky, rop, rop_kn, rop_new, dw, coe); \
   } while (0)
   if (sa && full) FS_UPP(true, 6); else if (sa) FS_UPP(false, 6); else if (full) FS_UPP(true, 5); else FS_UPP(false, 5);
