@@ -87,3 +87,23 @@ def test_conservation_full_size():
     assert abs(b[4] - a[4]) / a[4] < 1e-13
     # momentum sums to zero for the Taylor-Green field: compare with the scale rho*U0*ncell
     assert np.abs(b[1:4] - a[1:4]).max() / ncell < 1e-13
+
+
+def test_implicit_step_full_size_one_launch_sweeps_equal_per_hyperplane_sweeps(monkeypatch):
+    """256^3, two implicit time steps of three Newton sub-iterations: the LU-SGS sweeps as one launch each (8 192 pencils,
+    768 in work at a time) give the fields of the sweeps with one launch per hyperplane, bit for bit."""
+    def run(flow):
+        monkeypatch.setenv('FASTS_HIP_LU_FLOW', str(flow))
+        t = cases.tgv(N, 'senseur', extra_numz=SINGLE, temporal_scheme='implicit', time_step=0.003,
+                      extra_numb={'ss_iteration': 3})
+        (t, tc, metrics) = FastS.warmup(t, None)
+        z = Internal.getZones(t)[0]
+        for it in range(1, 3):
+            FastS._compute(t, metrics, it, None)
+        out = FastC.level_buffer(z).copy()
+        FastC.HOOK['ctx'].close()
+        return out
+    ref = run(0)
+    got = run(1)
+    assert np.isfinite(ref).all()
+    assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
