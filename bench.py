@@ -198,6 +198,8 @@ def main():
     ap.add_argument('--slope', default='o3', choices=['o3', 'o3sc'], help="o3sc: the o3 states weighted by a shock sensor "
                     "(kernels of their own, one thread per cell); single GPU, TGV case")
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--sa', action='store_true', help='Spalart-Allmaras on the Cartesian box between two no-slip walls (j faces); '
+                    'single GPU; not the headline workload')
     ap.add_argument('--implicit', type=int, default=0, metavar='SS_ITERATION', help='implicit BDF/LU-SGS steps with '
                     'this many Newton sub-iterations; not the headline workload')
     ap.add_argument('--perturb', type=float, default=0., help='node displacement in mesh steps: > 0 makes the block '
@@ -236,6 +238,10 @@ def main():
     import fast_amd.Mpi as FastSmpi
 
     model = 'Euler' if a.scheme == 'roe' else 'NSLaminar'
+    if a.sa:
+        if world > 1 or a.naca or a.channel or a.slope != 'o3':
+            raise SystemExit("bench.py: --sa is a single-GPU option of the plain box")
+        model = 'NSTurbulent'
     FastC.OMP_NUM_THREADS = max(1, a.lu_threads)
 
     if (a.perturb or a.implicit) and world > 1:
@@ -289,6 +295,8 @@ def main():
             kw['temporal_scheme'] = 'implicit_local'
             kw['modulo_verif'] = 7
             kw['extra_numz'] = dict(kw.get('extra_numz') or {}, ssdom_IJK=[a.local_newton] * 3, epsi_newton=a.epsi_newton)
+        if a.sa:
+            kw['bcs'] = {'jmin': 'BCWall', 'jmax': 'BCWall'}
         t = cases.tgv(a.n, a.scheme, model=model, time_step=0.003 * 32. / a.n * (10. if a.implicit else 1.),
                       perturb=a.perturb, **kw)
         (t, tc, metrics) = FastS.warmup(t, None, device=local_rank)
@@ -350,7 +358,9 @@ def main():
             traffic_source = ("not measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this "
                               "command, recorded in profiles/%s" % os.path.basename(tf))
         # algorithmic bytes per launch; per-cell metrics (9 surface-vector components + volume) are read once per stage
-        bpl = (BYTES_PER_CELL_STEP[a.scheme] + (240.0 if (a.perturb or a.naca) else 0.)) / 3.0 * (ncell_total // world // nblk)
+        # Spalart-Allmaras: six variables instead of five, and the wall distance and the eddy viscosity read once per stage
+        per_cell = BYTES_PER_CELL_STEP[a.scheme] * (1.2 if (a.sa or a.naca) else 1.) + (48.0 if (a.sa or a.naca) else 0.)
+        bpl = (per_cell + (240.0 if (a.perturb or a.naca) else 0.)) / 3.0 * (ncell_total // world // nblk)
         ach = bpl / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.
         out = {
             "metric": "Mcell-iter/s (fp64 RK3 TGV 256^3)",
@@ -364,6 +374,8 @@ def main():
                                    "wake match join" % (2 * a.naca + 2 * (a.naca // 3), 2 * a.naca // 3, a.scheme) if a.naca else
                                    "channel share: %d^3 cells in %d x %d x %d curvilinear blocks, %s, scheme=%s, RK3, no-slip walls on "
                                    "j, periodic i and k through match joins" % ((a.n,) + tuple(a.channel) + (model, a.scheme)) if a.channel else
+                                   "box of %d^3 cells between two no-slip walls, NSTurbulent (Spalart-Allmaras), scheme=%s, RK3"
+                                   % (a.n, a.scheme) if a.sa else
                                    "TGV Re=1600 M=0.1, %d^3 cells per GPU, NSLaminar, scheme=%s, RK3, periodic"
                                    % (a.n, a.scheme) if model != 'Euler' else
                                    "TGV %d^3 cells per GPU, Euler, scheme=%s, RK3, periodic" % (a.n, a.scheme),
