@@ -1,5 +1,5 @@
 #!/bin/bash
-# Final round-1 measurements: default bench (with the CPU baseline leg), the same command under rocprofv3
+# Measurements of the default bench (with the CPU baseline leg), the same command under rocprofv3
 # --kernel-trace --stats, and the curvilinear bench.  Run on the GPU box from the repository root.
 set -e
 R=$GRAFT_REPO_ROOT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 record of the LU-SGS solve in thread blocks: ms per time step of the two implicit workloads against the number
+# Record of the LU-SGS solve in thread blocks: ms per time step of the two implicit workloads against the number
 # of threads, the per-launch trace and the counter passes at 64 threads.  bash profiles/run_profiles_r02_lu.sh
 set -e
 cd $GRAFT_REPO_ROOT

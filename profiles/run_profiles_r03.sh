@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 measurements of the default bench (TGV 256^3 senseur RK3): the bench line, the same command under
+# Measurements of the default bench (TGV 256^3 senseur RK3): the bench line, the same command under
 # rocprofv3 --kernel-trace --stats, and separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ set).  Run on the GPU box
 # from the repository root:   bash profiles/run_profiles_r03.sh <tag>
 set -e

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 measurements of the paths added this round, each as a bench line and the same command under
+# Measurements of the implicit, sub-zone, o3sc and curvilinear paths, each as a bench line and the same command under
 # rocprofv3 --kernel-trace --stats (summaries only are kept).  Run on the GPU box from the repository root:
 #   bash profiles/run_profiles_r03b.sh <tag>
 set -e
