@@ -23,10 +23,16 @@ constexpr int TI = 32, TJ = 8, OI = TI - 1, OJ = TJ - 1, NQ = 6;
 
 template <int DIR> FS_DEV long long inc_of(const FsZone &z) { return DIR == 0 ? 1 : (DIR == 1 ? z.incj : z.inck); }
 
+// Addressing: a cell is (pointer common to the wave) + (byte offset of the lane inside its k-plane, 32 bits, fixed
+// while the patch marches in k).  Everything that moves -- variable, plane, neighbour -- goes into the common pointer,
+// which lives in scalar registers: a load then needs no vector instruction and no vector register pair for its address.
+FS_DEV double ldu(const double *ub, unsigned &vo) { asm volatile("" : "+v"(vo)); return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ub) + vo); }
+FS_DEV void stu(double *ub, unsigned &vo, double v) { asm volatile("" : "+v"(vo)); *reinterpret_cast<double *>(reinterpret_cast<char *>(ub) + vo) = v; }
+
 // Face between cell l - inc(DIR) and cell l; qm2..qp1 = the four cells of the MUSCL stencil (6 variables).
 template <int KFLU, int DIR, bool FIRST>
 FS_DEV void face_sa(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ xmut,
-                    unsigned char *__restrict__ wig, long long l, const double *qm2, const double *qm1,
+                    unsigned char *__restrict__ wig, unsigned &vo, const double *qm2, const double *qm1,
                     const double *q0, const double *qp1, double *flu)
 {
   const long long nd = z.nd;
@@ -35,9 +41,9 @@ FS_DEV void face_sa(const FsZone &z, const double *__restrict__ rop, const doubl
     if (FIRST) {
       auto qs = [&](int e, int o) -> double { return o == -2 ? qm2[e] : (o == -1 ? qm1[e] : (o == 0 ? q0[e] : qp1[e])); };
       wg = fs_wiggle(qs);
-      wig[DIR * nd + l] = wg != 0. ? 1 : 0;
+      (wig + DIR * nd)[vo >> 3] = wg != 0. ? 1 : 0;
     } else {
-      wg = (double)wig[DIR * nd + l];
+      wg = (double)(wig + DIR * nd)[vo >> 3];
     }
   }
   double sa[4];
@@ -68,12 +74,12 @@ FS_DEV void face_sa(const FsZone &z, const double *__restrict__ rop, const doubl
   const long long ib = DIR == 2 ? z.incj : z.inck;
   auto q = [&](int e, int da, int db, int dn) -> double {
     if (da == 0 && db == 0) return dn == 0 ? q0[e] : qm1[e];
-    return rop[e * nd + l + dn * inc + da * ia + db * ib];
+    return ldu(rop + (e * nd + dn * inc + da * ia + db * ib), vo);
   };
   const double Til = qm1[4], Tir = q0[4];
   double xmulam = fs_mulam_sa(z, Til);
   xmulam = xmulam + fs_mulam_sa(z, Tir);
-  const double xmutot = xmut[l] + xmut[l - inc];
+  const double xmutot = ldu(xmut, vo) + ldu(xmut - inc, vo);
   const double xmutur = xmutot - xmulam;
   const double xktvol = (xmulam * z.gam3 + xmutur * z.gam4) * z.volinv;
   const double xmutvol = xmutot * z.volinv;
@@ -90,7 +96,8 @@ FS_DEV void face_sa(const FsZone &z, const double *__restrict__ rop, const doubl
 
 // vol * (production - destruction + cb2 term) of cell l; qc = state of the cell
 // tsb (may be null) receives production - destruction, amu the clipped rho*nu_tilde (SA/sourceSA_LU.for)
-FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ dlng, long long l,
+// rop, dlng: pointers of the cell's k-plane; vo: byte offset of the cell in it
+FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const double *__restrict__ dlng, unsigned &vo,
                         const double *qc, double *tsb = nullptr, double *amu = nullptr)
 {
   const double SA_CKARM = 0.41, SA_CB1 = 0.1355, SA_CB2 = 0.622, SA_CV1 = 357.911, SA_CW2 = 0.3, SA_CW3 = 64.;
@@ -98,7 +105,7 @@ FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const d
   const double c1 = SA_CB2 / SA_SIGMA;
   const double cw1 = (SA_CB1 / SA_CKARM / SA_CKARM) + (1. + SA_CB2) / SA_SIGMA;
   const long long nd = z.nd, incj = z.incj, inck = z.inck;
-  const long long l1 = l + 1, l2 = l - 1, l3 = l + incj, l4 = l - incj, l5 = l + inck, l6 = l - inck;
+  const long long l1 = 1, l2 = -1, l3 = incj, l4 = -incj, l5 = inck, l6 = -inck;
   const double tix = z.tcx, tjy = z.tcy, tkz = z.tcz;
   const double xvol = z.volinv;   // 0.5/vol
   double g[3][3];
@@ -106,8 +113,8 @@ FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const d
   for (int v = 0; v < 3; v++) {
     const double *__restrict__ q = rop + (1 + v) * nd;
     const double c = qc[1 + v];
-    const double u1 = (c + q[l2]), u2 = (c + q[l3]), u3 = (c + q[l1]);
-    const double u4 = (c + q[l4]), u5 = (c + q[l5]), u6 = (c + q[l6]);
+    const double u1 = (c + ldu(q + l2, vo)), u2 = (c + ldu(q + l3, vo)), u3 = (c + ldu(q + l1, vo));
+    const double u4 = (c + ldu(q + l4, vo)), u5 = (c + ldu(q + l5, vo)), u6 = (c + ldu(q + l6, vo));
     g[v][0] = (u3 - u1) * tix; g[v][1] = (u2 - u4) * tjy; g[v][2] = (u5 - u6) * tkz;
   }
   const double rotx = g[2][1] - g[1][2], roty = g[0][2] - g[2][0], rotz = g[1][0] - g[0][1];
@@ -118,11 +125,11 @@ FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const d
   St = sqrt(2 * St) * xvol;
   const double *__restrict__ N = rop + 5 * nd, *__restrict__ R = rop;
   const double nc = qc[5], rc = qc[0];
-  const double n1 = N[l1], n2 = N[l2], n3 = N[l3], n4 = N[l4], n5 = N[l5], n6 = N[l6];
+  const double n1 = ldu(N + l1, vo), n2 = ldu(N + l2, vo), n3 = ldu(N + l3, vo), n4 = ldu(N + l4, vo), n5 = ldu(N + l5, vo), n6 = ldu(N + l6, vo);
   double u1 = (nc + n2), u2 = (nc + n3), u3 = (nc + n1), u4 = (nc + n4), u5 = (nc + n5), u6 = (nc + n6);
   double dudx = (u3 - u1) * tix, dudy = (u2 - u4) * tjy, dudz = (u5 - u6) * tkz;
-  u1 = nc * rc + n2 * R[l2]; u2 = nc * rc + n3 * R[l3]; u3 = nc * rc + n1 * R[l1];
-  u4 = nc * rc + n4 * R[l4]; u5 = nc * rc + n5 * R[l5]; u6 = nc * rc + n6 * R[l6];
+  u1 = nc * rc + n2 * ldu(R + l2, vo); u2 = nc * rc + n3 * ldu(R + l3, vo); u3 = nc * rc + n1 * ldu(R + l1, vo);
+  u4 = nc * rc + n4 * ldu(R + l4, vo); u5 = nc * rc + n5 * ldu(R + l5, vo); u6 = nc * rc + n6 * ldu(R + l6, vo);
   dudx = dudx * (u3 - u1) * tix; dudy = dudy * (u2 - u4) * tjy; dudz = dudz * (u5 - u6) * tkz;
   const double anvisc = c1 * (dudx + dudy + dudz) * xvol * xvol;
   const double amulam = fs_mulam_sa(z, qc[4]);
@@ -131,7 +138,7 @@ FS_DEV double sa_source(const FsZone &z, const double *__restrict__ rop, const d
   const double chi = fs_max(anutild * anulam, 1.e-7);
   const double f1 = 1. / (1. + SA_CV1 / (chi * chi * chi));
   const double f2 = 1. - chi / (1. + chi * f1);
-  const double dist = fs_max(dlng[l], 1.e-27);
+  const double dist = fs_max(ldu(dlng, vo), 1.e-27);
   double stild = rot + (anutild * f2) / (SA_CKARM * SA_CKARM * dist * dist);
   stild = stild + z.sa_rot_corr * SA_CROT * fs_min(0.00000000000000000001, St - rot);
   const double prod = rc * SA_CB1 * stild * anutild;
@@ -169,37 +176,42 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const dou
   const bool do_fi = active && own_j, do_fj = active && own_i;
   const long long nd = z.nd;
   const int ic = active ? i : 1, jc = active ? j : 1;
-  long long l = (long long)(ic + z.ific - 1) + (long long)(jc + z.ific - 1) * z.incj + (long long)(k0 + z.ifick - 1) * z.inck;
+  // byte offset of the lane's cell inside a k-plane (fixed), first cell of the current plane (common to the workgroup)
+  unsigned vo = (unsigned)(((long long)(ic + z.ific - 1) + (long long)(jc + z.ific - 1) * z.incj) * 8);
+  long long lk = (long long)(k0 + z.ifick - 1) * z.inck;
   double qa[NQ], qb[NQ], qc[NQ], qd[NQ];
 #pragma unroll
   for (int e = 0; e < NQ; e++) {
-    qa[e] = rop[e * nd + l - 2 * z.inck];
-    qb[e] = rop[e * nd + l - z.inck];
-    qc[e] = rop[e * nd + l];
+    qa[e] = ldu(rop + (e * nd + lk - 2 * z.inck), vo);
+    qb[e] = ldu(rop + (e * nd + lk - z.inck), vo);
+    qc[e] = ldu(rop + (e * nd + lk), vo);
     qd[e] = 0.;
   }
   double part[NQ] = {0., 0., 0., 0., 0., 0.};
   for (int k = k0; k <= k1 + 1; k++) {
     const bool last = k > k1;
+    const double *__restrict__ rk = rop + lk;
+    const double *__restrict__ xk = xmut + lk;
+    unsigned char *__restrict__ wk = wig + lk;
 #pragma unroll
-    for (int e = 0; e < NQ; e++) qd[e] = rop[e * nd + l + z.inck];
+    for (int e = 0; e < NQ; e++) qd[e] = ldu(rk + (e * nd + z.inck), vo);
     double fk[NQ] = {0., 0., 0., 0., 0., 0.};
     if (own) {
-      face_sa<KFLU, 2, FIRST>(z, rop, xmut, wig, l, qa, qb, qc, qd, fk);
+      face_sa<KFLU, 2, FIRST>(z, rk, xk, wk, vo, qa, qb, qc, qd, fk);
       if (k > k0) {
-        const long long lb = l - z.inck;
+        const long long lb = lk - z.inck;   // plane of the cell that is finished here
         double d[NQ], o[NQ];
 #pragma unroll
         for (int e = 0; e < NQ; e++) d[e] = part[e] - fk[e];
         if (BDF) {
           double qn[NQ] = {0., 0., 0., 0., 0., 0.}, qn1[NQ];
 #pragma unroll
-          for (int e = 0; e < NQ; e++) qn1[e] = bdf.ro_n1[e * nd + lb];
+          for (int e = 0; e < NQ; e++) qn1[e] = ldu(bdf.ro_n1 + (e * nd + lb), vo);
           if (!bdf.nit1) {
 #pragma unroll
-            for (int e = 0; e < NQ; e++) qn[e] = bdf.ro_n[e * nd + lb];
+            for (int e = 0; e < NQ; e++) qn[e] = ldu(bdf.ro_n + (e * nd + lb), vo);
           }
-          const double coe = bdf.coe1 ? bdf.coe1[lb] : z.coe;
+          const double coe = bdf.coe1 ? ldu(bdf.coe1 + lb, vo) : z.coe;
           if (bdf.nit1 && bdf.coe1) {   // local time step, first sub-iteration: no BDF terms (core3as2.for:57-66)
 #pragma unroll
             for (int e = 0; e < NQ; e++) o[e] = coe * d[e];
@@ -210,16 +222,16 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const dou
           }
           if (fs_in_box(bdf, i, j, k - 1)) {   // a sub-zone: the other cells keep their residual
 #pragma unroll
-            for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = o[e];
+            for (int e = 0; e < NQ; e++) stu(drodm + (e * nd + lb), vo, o[e]);
           }
         } else {
         if (keep) {   // the balance of the last Runge-Kutta stage of a step is read by nothing
 #pragma unroll
-          for (int e = 0; e < NQ; e++) drodm[e * nd + lb] = d[e];
+          for (int e = 0; e < NQ; e++) stu(drodm + (e * nd + lb), vo, d[e]);
         }
         fs_rk_update(z, coefW, qb, d, o);
 #pragma unroll
-        for (int e = 0; e < 5; e++) rop_out[e * nd + lb] = o[e];
+        for (int e = 0; e < 5; e++) stu(rop_out + (e * nd + lb), vo, o[e]);
         {   // nu_tilde: conservative update, clipped to [0, ratiom * nu_laminar] (core3ark3.for:196-236)
           const double r_1 = 1. / o[0];
           const double tab6 = d[5] * (coefW * z.coe);
@@ -227,7 +239,7 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const dou
           anulam = anulam * r_1 * z.ratiom;
           double t6 = (qb[0] * qb[5] + tab6) * r_1;
           t6 = fs_min(t6, anulam);
-          rop_out[5 * nd + lb] = fs_max(t6, 0.);
+          stu(rop_out + (5 * nd + lb), vo, fs_max(t6, 0.));
         }
         }
       }
@@ -238,9 +250,9 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const dou
         double m2[NQ], m1[NQ], p1[NQ];
 #pragma unroll
         for (int e = 0; e < NQ; e++) {
-          m2[e] = rop[e * nd + l - 2 * z.incj]; m1[e] = rop[e * nd + l - z.incj]; p1[e] = rop[e * nd + l + z.incj];
+          m2[e] = ldu(rk + (e * nd - 2 * z.incj), vo); m1[e] = ldu(rk + (e * nd - z.incj), vo); p1[e] = ldu(rk + (e * nd + z.incj), vo);
         }
-        face_sa<KFLU, 1, FIRST>(z, rop, xmut, wig, l, m2, m1, qc, p1, fjm);
+        face_sa<KFLU, 1, FIRST>(z, rk, xk, wk, vo, m2, m1, qc, p1, fjm);
       }
       const int buf = (k - k0) & 1;
 #pragma unroll
@@ -249,19 +261,19 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const dou
         double m2[NQ], m1[NQ], p1[NQ];
 #pragma unroll
         for (int e = 0; e < NQ; e++) {
-          m2[e] = rop[e * nd + l - 2]; m1[e] = rop[e * nd + l - 1]; p1[e] = rop[e * nd + l + 1];
+          m2[e] = ldu(rk + (e * nd - 2), vo); m1[e] = ldu(rk + (e * nd - 1), vo); p1[e] = ldu(rk + (e * nd + 1), vo);
         }
-        face_sa<KFLU, 0, FIRST>(z, rop, xmut, wig, l, m2, m1, qc, p1, fim);
+        face_sa<KFLU, 0, FIRST>(z, rk, xk, wk, vo, m2, m1, qc, p1, fim);
       }
       double fip[NQ];
 #pragma unroll
       for (int e = 0; e < NQ; e++) fip[e] = __shfl_down(fim[e], 1);
       __syncthreads();
       if (own) {
-        const double src = sa_source(z, rop, dlng, l, qc);
+        const double src = sa_source(z, rk, dlng + lk, vo, qc);
 #pragma unroll
         for (int e = 0; e < NQ; e++) {
-          double dr = (FIRST || BDF) ? 0. : drodm[e * nd + l] * coefH;
+          double dr = (FIRST || BDF) ? 0. : ldu(drodm + (e * nd + lk), vo) * coefH;
           if (e == 5) dr = dr + src;
           part[e] = dr + fk[e] + fjm[e] + fim[e] - fip[e] - sfj[buf][e][tj + 1][ti];
         }
@@ -269,7 +281,7 @@ k_stage_sa(FsZone z, double coefH, double coefW, int kchunk, int keep, const dou
     }
 #pragma unroll
     for (int e = 0; e < NQ; e++) { qa[e] = qb[e]; qb[e] = qc[e]; qc[e] = qd[e]; }
-    l += z.inck;
+    lk += z.inck;
   }
 }
 
@@ -299,12 +311,14 @@ __global__ void __launch_bounds__(256) k_sa_coe6(FsZone z, const double *__restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;   // 0 .. iv+1
   if (i > z.iv + 1) return;
   const long long nd = z.nd;
-  const long long l = (long long)(i + z.ific - 1) + (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;
+  const long long lk = (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;   // common to the workgroup
+  unsigned vo = (unsigned)(i + z.ific - 1) * 8u;
+  const long long l = lk + (i + z.ific - 1);
   double qc[NQ];
 #pragma unroll
   for (int e = 0; e < NQ; e++) qc[e] = rop[e * nd + l];
   double tsb, amu;
-  sa_source(z, rop, dlng, l, qc, &tsb, &amu);
+  sa_source(z, rop + lk, dlng + lk, vo, qc, &tsb, &amu);
   const double tsourcenu = z.vol0 * tsb / amu;
   coe[l + 5 * nd] = coe[l + 4 * nd] - fs_min(tsourcenu, 0.) * coe[l];
 }
@@ -326,9 +340,12 @@ __global__ void __launch_bounds__(128) k_box_faces_sa(FsZone z, FsBox box, const
   for (int e = 0; e < NQ; e++) {
     qm2[e] = rop[e * nd + l - 2 * st]; qm1[e] = rop[e * nd + l - st]; q0[e] = rop[e * nd + l]; qp1[e] = rop[e * nd + l + st];
   }
-  if (d == 0) face_sa<KFLU, 0, false>(z, rop, xmut, wig, l, qm2, qm1, q0, qp1, f);
-  else if (d == 1) face_sa<KFLU, 1, false>(z, rop, xmut, wig, l, qm2, qm1, q0, qp1, f);
-  else face_sa<KFLU, 2, false>(z, rop, xmut, wig, l, qm2, qm1, q0, qp1, f);
+  // (the k-plane differs from lane to lane here: its pointer is no common one, the loads take vector addresses)
+  const long long lk = (long long)(k + z.ifick - 1) * z.inck;
+  unsigned vo = (unsigned)((l - lk) * 8);
+  if (d == 0) face_sa<KFLU, 0, false>(z, rop + lk, xmut + lk, wig + lk, vo, qm2, qm1, q0, qp1, f);
+  else if (d == 1) face_sa<KFLU, 1, false>(z, rop + lk, xmut + lk, wig + lk, vo, qm2, qm1, q0, qp1, f);
+  else face_sa<KFLU, 2, false>(z, rop + lk, xmut + lk, wig + lk, vo, qm2, qm1, q0, qp1, f);
   if (side & 1) {
     // the cell past the box takes the flux of the five mean-flow equations only (SA/flu_send_scater_vec1.for gives the
     // 6th to the cell inside alone)
@@ -353,7 +370,9 @@ __global__ void __launch_bounds__(256) k_sa_ring(FsZone z, FsBox box, const doub
   double qc[NQ];
 #pragma unroll
   for (int e = 0; e < NQ; e++) qc[e] = rop[e * nd + l];
-  drodm[5 * nd + l] = drodm[5 * nd + l] + sa_source(z, rop, dlng, l, qc);
+  const long long lk = (long long)(j + z.ific - 1) * z.incj + (long long)(k + z.ifick - 1) * z.inck;   // common to the workgroup
+  unsigned vo = (unsigned)(i + z.ific - 1) * 8u;
+  drodm[5 * nd + l] = drodm[5 * nd + l] + sa_source(z, rop + lk, dlng + lk, vo, qc);
 }
 
 }  // namespace
