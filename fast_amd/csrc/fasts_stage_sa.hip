@@ -26,8 +26,8 @@ template <int DIR> FS_DEV long long inc_of(const FsZone &z) { return DIR == 0 ? 
 // Addressing: a cell is (pointer common to the wave) + (byte offset of the lane inside its k-plane, 32 bits, fixed
 // while the patch marches in k).  Everything that moves -- variable, plane, neighbour -- goes into the common pointer,
 // which lives in scalar registers: a load then needs no vector instruction and no vector register pair for its address.
-FS_DEV double ldu(const double *ub, unsigned &vo) { asm volatile("" : "+v"(vo)); return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ub) + vo); }
-FS_DEV void stu(double *ub, unsigned &vo, double v) { asm volatile("" : "+v"(vo)); *reinterpret_cast<double *>(reinterpret_cast<char *>(ub) + vo) = v; }
+FS_DEV double ldu(const double *ub, unsigned &vo) { asm("" : "+v"(vo)); return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ub) + vo); }
+FS_DEV void stu(double *ub, unsigned &vo, double v) { asm("" : "+v"(vo)); *reinterpret_cast<double *>(reinterpret_cast<char *>(ub) + vo) = v; }
 
 // Face between cell l - inc(DIR) and cell l; qm2..qp1 = the four cells of the MUSCL stencil (6 variables).
 template <int KFLU, int DIR, bool FIRST>
