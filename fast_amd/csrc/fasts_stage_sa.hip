@@ -419,6 +419,7 @@ int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const d
                  int keep_balance, hipStream_t s)
 {
   if (z.ityp != 2 || z.neq != 6 || z.iflow != 3 || !dist) return -1;
+  if ((long long)z.inck * 8 >= (1LL << 32)) return -1;   // the kernels address a cell by a 32-bit byte offset inside its k-plane
   int kchunk = 32;
   if (kchunk > z.kv) kchunk = z.kv;
   dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
