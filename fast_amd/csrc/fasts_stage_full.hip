@@ -204,8 +204,11 @@ FS_DEV double sa_source_full(const FsZone &z, const double *__restrict__ rop, co
 // TWOD: one plane, no k faces: the cell is finished in the same step (+Fj- +Fi- -Fi+ -Fj+).
 // LQ: the planes k-1, k, k+1 of the patch (halo included) are staged in LDS, one new plane per step of the march, and
 // the transverse neighbours are read from there instead of the vector L1 (three-dimensional zones, 5 variables).
+// Spalart-Allmaras with the sensor scheme on a three-dimensional zone wants 300-314 registers: held to 256 (two waves per
+// SIMD instead of one, 28-92 bytes of scratch per lane) it runs 6.89 -> 6.39 ms per stage at 256^3; the same limit on the
+// ausmpred variants (256 registers already) only adds scratch: 5.71 -> 7.28 ms.
 template <int KFLU, int IFLOW, bool FIRST, bool BDF, bool TWOD, bool HOMO = false, bool LQ = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (IFLOW == 3 && !TWOD && KFLU == 2) ? 2 : 1)
 k_stage_full(FsZone z, double coefH, double coefW, int kchunk, int keep, const double *__restrict__ rop,
              double *__restrict__ rop_out, double *__restrict__ drodm, const double *__restrict__ xmut,
              unsigned char *__restrict__ wig, FsBdf bdf, const double *__restrict__ dlng,
