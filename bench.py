@@ -352,7 +352,7 @@ def main():
         # own by profiles/run_profiles.sh; counters cannot be read inside a timed run)
         traffic, traffic_source = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic_%s_%d%s.json' % (a.scheme, a.n, '_curvilinear' if a.perturb else ''))
-        if os.path.exists(tf) and not a.naca and world == 1 and not a.implicit and not a.channel:
+        if os.path.exists(tf) and not a.naca and world == 1 and not a.implicit and not a.channel and not a.sa and a.slope == 'o3':
             with open(tf) as fh:
                 traffic = json.load(fh).get('traffic_bytes_per_launch')
             traffic_source = ("not measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this "
