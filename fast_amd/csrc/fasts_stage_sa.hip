@@ -14,6 +14,7 @@
 // (src_term.for:59-96 before the flux loops of template_FluxAndBalance.for:192-271).
 // The fw function of the destruction term takes a 1/6 power: the device pow is not bit-identical to the
 // host one, so this kernel matches the CPU restatement to rounding, not bit for bit.
+#include <cstdlib>
 #include "fasts_kernels.h"
 #include "fasts_flux.h"
 
@@ -420,7 +421,8 @@ int fsk_stage_sa(const FsZone &z, double coefH, double coefW, int first, const d
 {
   if (z.ityp != 2 || z.neq != 6 || z.iflow != 3 || !dist) return -1;
   if ((long long)z.inck * 8 >= (1LL << 32)) return -1;   // the kernels address a cell by a 32-bit byte offset inside its k-plane
-  int kchunk = 32;
+  int kchunk = 16;   // 256^3, ms per stage: 8 planes 2.16, 16 2.14, 32 2.24, 64 2.44, 128 2.69
+  if (const char *ev = getenv("FASTS_HIP_KCHUNK_SA")) { const int v = atoi(ev); if (v >= 1) kchunk = v; }
   if (kchunk > z.kv) kchunk = z.kv;
   dim3 g((z.iv + OI - 1) / OI, (z.jv + OJ - 1) / OJ, (z.kv + kchunk - 1) / kchunk);
   FsBdf b = {nullptr, nullptr, 0., 0., 0., 0, nullptr};
